@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Headline benchmark: chain-leapfrog-steps/sec of batched diagonal-mass HMC on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): 65 536 chains x 1 024-dim
+diagonal Gaussian (sigma_i = 10^(-1+2i/(D-1))), inverse mass = sigma^2, eps = 0.25,
+L = 50 leapfrog steps per transition, fp32.  A "step" is one HMC transition of every
+chain (momentum draw, L leapfrogs each followed by the log-density callable, Metropolis
+accept).  Chains shard over GPUs with no data-path collective (weak scaling: 65 536
+chains PER GPU); per-chain keys come from the global chain index.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (fused kick+drift leapfrog): ALGORITHMIC bytes per launch
+                  (20 B x D x N: read p,g,q; write p,q) / mean launch duration measured with
+                  HIP events on the launch stream inside the timed region; peak 8000 GB/s.
+  cpu_baseline -- the oracle's C/OpenMP port of the same transition timed on the host cores on a
+                  bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def sigma_ladder(D):
+    return (10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32)
+
+
+def cpu_baseline(D, L, eps, target_seconds=15.0):
+    """Time the oracle's C port (all host cores) on a bounded sample of the same workload."""
+    from oracle import cport, prng
+
+    sig = sigma_ladder(D)
+    imm = (sig * sig).astype(np.float32)
+    inv_var = (np.float32(1.0) / imm).astype(np.float32)
+    threads = cport.num_threads()
+    n = 8 * threads
+    rng = np.random.default_rng(0)
+
+    def make(n):
+        q = (sig * rng.standard_normal((n, D))).astype(np.float32)
+        g = -(q * inv_var)
+        logp = (0.5 * np.sum(q.astype(np.float64) * g, axis=-1)).astype(np.float32)
+        return q, logp, g.astype(np.float32)
+
+    n_big = 2048 * threads
+    q, logp, g = make(n_big)
+    cport.hmc_diag_gaussian_step(prng.key(0), q[:n], logp[:n], g[:n], eps, imm, inv_var, L)  # warm
+    keys = prng.split(prng.key(1), 1000)
+    done = 0
+    t0 = time.perf_counter()
+    while done < 2 or (time.perf_counter() - t0 < target_seconds and done < len(keys)):
+        cport.hmc_diag_gaussian_step(keys[done], q, logp, g, eps, imm, inv_var, L)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_big * L * done / dt,
+        "unit": "chain-leapfrog-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_big} chains x {D} dims, L={L}, {done} transitions "
+                  f"({dt:.1f} s) -- C/OpenMP port of the oracle (CPU restatement of BlackJAX "
+                  "arithmetic, NOT JAX: no jax wheel on this box)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--leapfrogs", type=int, default=50)
+    ap.add_argument("--eps", type=float, default=0.25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (blackjax_amd has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import blackjax_amd as bjx
+    from blackjax_amd import _lib
+
+    N, D, L = args.chains, args.dim, args.leapfrogs
+    sig = torch.as_tensor(sigma_ladder(D), device=dev)
+    imm = (sig * sig).contiguous()
+    target = bjx.targets.DiagGaussian((1.0 / imm).contiguous())
+    alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    state = alg.init(sig * torch.randn(N, D, device=dev, generator=gen))
+    keys = bjx.random.split(bjx.random.key(0), args.warmup + args.steps)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for t in range(args.warmup):
+        state, info = alg.step(keys[t], state)
+    torch.cuda.synchronize()
+
+    timer = None
+    if not args.no_launch_timing and rank == 0:
+        timer = _lib.LaunchTimer(["bjx_leapfrog_diag"])
+        _lib.set_timer(timer)
+    acc_sum = torch.zeros((), device=dev)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        state, info = alg.step(keys[t], state)
+        acc_sum += info.acceptance_rate.mean()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # final draws / statistics are the only thing that crosses xGMI (RCCL all-gather)
+        sub = state.position[:256].contiguous()
+        gathered = [torch.empty_like(sub) for _ in range(world)]
+        dist.all_gather(gathered, sub)
+        final_draws = torch.cat(gathered, 0)
+    else:
+        final_draws = state.position[:256]
+
+    if rank == 0:
+        total_chain_leapfrogs = world * N * L * args.steps
+        value = total_chain_leapfrogs / dt
+        roofline = None
+        if timer is not None:
+            d_ms = timer.durations_ms("bjx_leapfrog_diag")
+            avg_s = float(np.mean(d_ms)) * 1e-3
+            alg_bytes = 20.0 * D * N  # read p,g,q ; write p,q (imm (D,) is shared and cached)
+            achieved = alg_bytes / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("chains") == N and tj.get("dim") == D:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {
+                "bound": "hbm", "kernel": "k_leapfrog_diag<4,2>", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": avg_s * 1e6, "launches_timed": len(d_ms),
+            }
+        out = {
+            "metric": "chain-leapfrog-steps/sec (whole node), 65 536 chains x 1 024-dim diag-mass HMC",
+            "value": value,
+            "unit": "chain-leapfrog-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
+                            f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
+                "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
+                "parallelism": f"chains sharded x{world}, no data-path collective",
+            },
+            "mean_acceptance": float(acc_sum.item()) / args.steps,
+            "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
+            "final_draws_gathered": list(final_draws.shape),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(D, L, args.eps)
+            except Exception as e:  # the baseline is a reported extra; never fail the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,31 @@
+"""blackjax_amd -- MI355X-native HMC/NUTS engine behind the blackjax.hmc / blackjax.nuts /
+blackjax.window_adaptation API surface (blackjax/__init__.py:70-80,104-112).
+
+Positions are batched ``(n_chains, dim)`` float32 ROCm tensors; the log-density is a
+PyTorch callable over the batch; all sampler arithmetic runs in hand-written HIP
+kernels (``libbjxhip.so``, C ABI in ``include/bjx_hip.h``).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from . import hmc as _hmc
+from . import integrators, random, targets
+from .base import AdaptationAlgorithm, SamplingAlgorithm
+
+__version__ = "0.1.0"
+
+
+class GenerateSamplingAPI:
+    """blackjax/__init__.py:70-80: callable that also exposes ``init`` / ``build_kernel``."""
+
+    def __init__(self, differentiable, init, build_kernel):
+        self.differentiable = differentiable
+        self.init = init
+        self.build_kernel = build_kernel
+
+    def __call__(self, *args, **kwargs) -> SamplingAlgorithm:
+        return self.differentiable(*args, **kwargs)
+
+
+hmc = GenerateSamplingAPI(_hmc.as_top_level_api, _hmc.init, _hmc.build_kernel)
+
+__all__ = ["hmc", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]

@@ -1,0 +1,99 @@
+"""Host-side plumbing shared by the kernels' Python drivers."""
+from __future__ import annotations
+
+import weakref
+from typing import Callable
+
+import torch
+
+_VG_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def value_and_grad(logdensity_fn: Callable) -> Callable:
+    """Batched counterpart of ``jax.value_and_grad(logdensity_fn)`` (blackjax/mcmc/hmc.py:91,
+    integrators.py:189): returns ``f(q: (N, D)) -> (logp: (N,), grad: (N, D))``.
+
+    ``logdensity_fn`` is a PyTorch callable over the whole batch.  It may either
+    return ``(logp, grad)`` itself (fast path, e.g. ``blackjax_amd.targets``) or
+    return only ``logp`` with an autograd graph, in which case the gradient is taken
+    with ``torch.autograd.grad`` (chains are independent, so d sum(logp) / dq is the
+    per-chain gradient).
+    """
+    if getattr(logdensity_fn, "_bjx_value_and_grad", False):
+        return logdensity_fn
+    try:
+        cached = _VG_CACHE.get(logdensity_fn)
+    except TypeError:
+        cached = None
+    if cached is not None:
+        return cached
+
+    mode = {"kind": None}
+
+    def _autograd(q):
+        q = q.detach().requires_grad_(True)
+        with torch.enable_grad():
+            lp = logdensity_fn(q)
+            (g,) = torch.autograd.grad(lp.sum(), q)
+        return lp.detach(), g
+
+    def vg(q):
+        if mode["kind"] == "autograd":
+            return _autograd(q)
+        if mode["kind"] == "pair":
+            return logdensity_fn(q)
+        out = logdensity_fn(q)
+        if isinstance(out, (tuple, list)) and len(out) == 2:
+            mode["kind"] = "pair"
+            return out
+        mode["kind"] = "autograd"
+        return _autograd(q)
+
+    vg._bjx_value_and_grad = True
+    try:
+        _VG_CACHE[logdensity_fn] = vg
+    except TypeError:
+        pass
+    return vg
+
+
+def check_batch(x: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(x)}")
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{name} lives on {x.device}: blackjax_amd runs on ROCm device tensors only "
+            "(there is no CPU fallback)"
+        )
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {x.dtype}")
+    return x.contiguous()
+
+
+def eval_logdensity(vg: Callable, q: torch.Tensor):
+    """Call the user's value-and-grad and normalise its outputs to contiguous fp32."""
+    logp, g = vg(q)
+    if logp.dtype != torch.float32:
+        logp = logp.float()
+    if g.dtype != torch.float32:
+        g = g.float()
+    if g.shape != q.shape or logp.shape != q.shape[:1]:
+        raise ValueError(
+            f"logdensity_fn must return logp of shape {tuple(q.shape[:1])} and grad of shape "
+            f"{tuple(q.shape)}; got {tuple(logp.shape)} and {tuple(g.shape)}"
+        )
+    return logp.contiguous(), g.contiguous()
+
+
+def step_size_args(step_size, n_chains: int, device):
+    """-> (scalar eps, per-chain tensor or None)."""
+    if isinstance(step_size, torch.Tensor):
+        if step_size.ndim == 0 and not step_size.is_cuda:
+            return float(step_size), None
+        t = step_size.to(device=device, dtype=torch.float32)
+        if t.ndim == 0:
+            t = t.expand(n_chains)
+        if t.shape != (n_chains,):
+            raise ValueError(f"per-chain step_size must have shape ({n_chains},), got {tuple(t.shape)}")
+        return 0.0, t.contiguous()
+    return float(step_size), None

@@ -1,0 +1,126 @@
+// Device-side building blocks shared by every kernel of libbjxhip (gfx950 only).
+//
+// Floating-point contract (see DESIGN.md "Numerics"): built with -ffp-contract=off;
+// every fused multiply-add is an explicit fmaf(); reductions and scalar
+// transcendentals are evaluated in fp64 and rounded once to fp32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BJX_WAVE 64
+
+namespace bjx {
+
+// ---------------------------------------------------------------------------------------
+// threefry2x32 (Salmon et al. 2011), 20 rounds -- the block function under
+// jax.random (jax/_src/prng.py).  Restated from the published algorithm.
+struct Key {
+  uint32_t k0, k1;
+};
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
+  return __builtin_rotateleft32(x, r);
+}
+
+__device__ __forceinline__ Key threefry2x32(Key key, uint32_t x0, uint32_t x1) {
+  const uint32_t ks0 = key.k0, ks1 = key.k1, ks2 = key.k0 ^ key.k1 ^ 0x1BD11BDAu;
+  x0 += ks0;
+  x1 += ks1;
+#define BJX_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  BJX_R(13) BJX_R(15) BJX_R(26) BJX_R(6)
+  x0 += ks1; x1 += ks2 + 1u;
+  BJX_R(17) BJX_R(29) BJX_R(16) BJX_R(24)
+  x0 += ks2; x1 += ks0 + 2u;
+  BJX_R(13) BJX_R(15) BJX_R(26) BJX_R(6)
+  x0 += ks0; x1 += ks1 + 3u;
+  BJX_R(17) BJX_R(29) BJX_R(16) BJX_R(24)
+  x0 += ks1; x1 += ks2 + 4u;
+  BJX_R(13) BJX_R(15) BJX_R(26) BJX_R(6)
+  x0 += ks2; x1 += ks0 + 5u;
+#undef BJX_R
+  return Key{x0, x1};
+}
+
+// split(key, n)[i] == fold_in(key, i) == threefry(key, (hi32(i), lo32(i)))
+__device__ __forceinline__ Key key_child(Key key, uint64_t i) {
+  return threefry2x32(key, (uint32_t)(i >> 32), (uint32_t)i);
+}
+
+// random_bits(key, 32, shape)[i]
+__device__ __forceinline__ uint32_t key_bits32(Key key, uint64_t i) {
+  Key o = threefry2x32(key, (uint32_t)(i >> 32), (uint32_t)i);
+  return o.k0 ^ o.k1;
+}
+
+// [0,1) float from the top 23 bits (jax/_src/random.py::_uniform)
+__device__ __forceinline__ float unit_float(uint32_t bits) {
+  return __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+}
+
+// jax.random.uniform(key, (), float32)
+__device__ __forceinline__ float key_uniform(Key key) {
+  return fmaxf(0.0f, unit_float(key_bits32(key, 0)));
+}
+
+// XLA ErfInv32 (Giles' single-precision polynomial); log1p evaluated in fp64 and rounded once.
+__device__ __forceinline__ float erfinv_f32(float x) {
+  float t = -(x * x);
+  float w = -(float)log1p((double)t);
+  const bool lt = w < 5.0f;
+  float p;
+  if (lt) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f);
+    p = fmaf(p, w, -3.5233877e-06f);
+    p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f);
+    p = fmaf(p, w, -0.00125372503f);
+    p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f);
+    p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f);
+    p = fmaf(p, w, 0.00134934322f);
+    p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f);
+    p = fmaf(p, w, -0.0076224613f);
+    p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f);
+    p = fmaf(p, w, 2.83297682f);
+  }
+  float r = p * x;
+  if (fabsf(x) == 1.0f) r = x * __builtin_inff();
+  return r;
+}
+
+// jax.random.normal element from its 32 random bits:
+//   u = max(lo, f*(1-lo)+lo), lo = nextafter(-1,0) ; (1-lo) rounds to 2.0f ; z = sqrt(2)*erfinv(u)
+__device__ __forceinline__ float normal_from_bits(uint32_t bits) {
+  const float lo = -0.99999994f;
+  float u = fmaxf(lo, fmaf(unit_float(bits), 2.0f, lo));
+  return 1.41421354f * erfinv_f32(u);
+}
+
+// ---------------------------------------------------------------------------------------
+// wave64 reductions (all lanes receive the result)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, BJX_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+
+// 16-byte vector helpers
+struct alignas(16) F4 {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
+__device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) = v; }
+
+}  // namespace bjx

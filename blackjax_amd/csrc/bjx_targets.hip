@@ -1,0 +1,144 @@
+// Built-in synthetic targets: value + gradient in one pass over the row (gfx950).
+// They play the role of the user's log-density callable in the bench and parity
+// tests (the engine itself accepts any PyTorch callable).  logp is accumulated in
+// fp64 and rounded once, the gradient is element-wise fp32.
+#include "../../include/bjx_hip.h"
+#include "bjx_device.h"
+#include "bjx_host.h"
+
+using namespace bjx;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
+
+__device__ __forceinline__ int64_t wave_row0() {
+  return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+}
+__device__ __forceinline__ int64_t wave_row_stride() { return (int64_t)gridDim.x * kWavesPerBlock; }
+
+// g = -(q*inv_var) ; logp = 0.5 * sum q*g
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float* __restrict__ q,
+                float* __restrict__ logp, float* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const int64_t base = r * D;
+    double acc = 0.0;
+    if constexpr (VEC == 4) {
+#pragma unroll 4
+      for (int64_t j = (int64_t)lane * 4; j < D; j += 256) {
+        const F4 qq = ld4(q + base + j);
+        const F4 vv = ld4(iv + j);
+        F4 gg{-(qq.x * vv.x), -(qq.y * vv.y), -(qq.z * vv.z), -(qq.w * vv.w)};
+        acc += (double)qq.x * (double)gg.x;
+        acc += (double)qq.y * (double)gg.y;
+        acc += (double)qq.z * (double)gg.z;
+        acc += (double)qq.w * (double)gg.w;
+        st4(g + base + j, gg);
+      }
+    } else {
+      for (int64_t j = lane; j < D; j += 64) {
+        const float qq = q[base + j];
+        const float gg = -(qq * iv[j]);
+        acc += (double)qq * (double)gg;
+        g[base + j] = gg;
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logp[r] = (float)(0.5 * acc);
+  }
+}
+
+// Neal's funnel (tests/fixtures.py:81-98 of the reference), y = q[0], v = q[1:]
+__global__ void __launch_bounds__(kBlock)
+k_neal_funnel(int64_t N, int64_t D, const float* __restrict__ q, float* __restrict__ logp,
+              float* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const int64_t base = r * D;
+    double S = 0.0;
+    for (int64_t j = 1 + lane; j < D; j += 64) {
+      const double v = (double)q[base + j];
+      S += v * v;
+    }
+    S = wave_sum(S);
+    const float y32 = q[base];
+    const double y = (double)y32;
+    const float ey32 = (float)exp((double)(-y32));
+    const double ey = (double)ey32;
+    const double dm1 = (double)(D - 1);
+    if (lane == 0) {
+      const double t = y / 3.0;
+      logp[r] = (float)(-0.5 * (t * t) - 0.5 * ey * S - 0.5 * dm1 * y);
+      g[base] = (float)(-y / 9.0 + 0.5 * ey * S - 0.5 * dm1);
+    }
+    for (int64_t j = 1 + lane; j < D; j += 64) g[base + j] = -(ey32 * q[base + j]);
+  }
+}
+
+// AR(1) Gaussian, tridiagonal precision: t = d_j q_j ; t = fma(off, q_{j-1}, t) ; t = fma(off, q_{j+1}, t)
+__global__ void __launch_bounds__(kBlock)
+k_ar1_gaussian(int64_t N, int64_t D, float d_edge, float d_mid, float off,
+               const float* __restrict__ q, float* __restrict__ logp, float* __restrict__ g) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const int64_t base = r * D;
+    double acc = 0.0;
+    for (int64_t j = lane; j < D; j += 64) {
+      const float qj = q[base + j];
+      const float ql = j > 0 ? q[base + j - 1] : 0.0f;
+      const float qr = j + 1 < D ? q[base + j + 1] : 0.0f;
+      const float d = (j == 0 || j == D - 1) ? d_edge : d_mid;
+      float t = d * qj;
+      t = fmaf(off, ql, t);
+      t = fmaf(off, qr, t);
+      const float gj = -t;
+      acc += (double)qj * (double)gj;
+      g[base + j] = gj;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logp[r] = (float)(0.5 * acc);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* inv_var,
+                             const float* q, float* logp_out, float* g_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && inv_var && q && logp_out && g_out,
+                "bjx_target_diag_gaussian: bad arguments");
+  if (N == 0) return 0;
+  const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
+  if (bjx_vec4_ok(D, inv_var, q, g_out))
+    hipLaunchKernelGGL(k_diag_gaussian<4>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
+                       logp_out, g_out);
+  else
+    hipLaunchKernelGGL(k_diag_gaussian<1>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
+                       logp_out, g_out);
+  return bjx_check_launch("bjx_target_diag_gaussian");
+}
+
+int bjx_target_neal_funnel(void* stream, int64_t N, int64_t D, const float* q, float* logp_out,
+                           float* g_out) {
+  BJX_CHECK_ARG(N >= 0 && D >= 2 && q && logp_out && g_out, "bjx_target_neal_funnel: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_neal_funnel, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, N, D, q, logp_out, g_out);
+  return bjx_check_launch("bjx_target_neal_funnel");
+}
+
+int bjx_target_ar1_gaussian(void* stream, int64_t N, int64_t D, float diag_edge, float diag_mid,
+                            float off, const float* q, float* logp_out, float* g_out) {
+  BJX_CHECK_ARG(N >= 0 && D >= 2 && q && logp_out && g_out, "bjx_target_ar1_gaussian: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_ar1_gaussian, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, N, D, diag_edge, diag_mid, off, q, logp_out, g_out);
+  return bjx_check_launch("bjx_target_ar1_gaussian");
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""Batched HMC on MI355X behind the ``blackjax.hmc`` API surface.
+
+Mirrors blackjax/mcmc/hmc.py: ``HMCState`` (38-49), ``HMCInfo`` (52-87), ``init``
+(90-92), ``build_kernel`` (251-314), ``as_top_level_api`` (317-414).  The chain
+axis is native: every field carries a leading ``N``; chain ``i`` of
+``step(rng_key, state)`` reproduces the reference's single-chain
+``step(jax.random.split(rng_key, N)[i], state_i)`` (the vmap layout of
+docs/examples/howto_sample_multiple_chains.md:120-127).
+
+The arithmetic runs in libbjxhip's HIP kernels (include/bjx_hip.h); this module
+only sequences launches around the user's PyTorch log-density callable.
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple
+
+import torch
+
+from . import _lib, integrators, metrics
+from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
+from .base import SamplingAlgorithm
+from .random import key_words
+
+__all__ = ["HMCState", "HMCInfo", "IntegratorState", "init", "build_kernel", "as_top_level_api"]
+
+
+class HMCState(NamedTuple):
+    """blackjax/mcmc/hmc.py:38-49, batched: (N, D), (N,), (N, D)."""
+
+    position: torch.Tensor
+    logdensity: torch.Tensor
+    logdensity_grad: torch.Tensor
+
+
+class IntegratorState(NamedTuple):
+    """blackjax/mcmc/integrators.py:43-53, batched."""
+
+    position: torch.Tensor
+    momentum: torch.Tensor
+    logdensity: torch.Tensor
+    logdensity_grad: torch.Tensor
+
+
+class HMCInfo(NamedTuple):
+    """blackjax/mcmc/hmc.py:52-87, batched."""
+
+    momentum: torch.Tensor
+    acceptance_rate: torch.Tensor
+    is_accepted: torch.Tensor
+    is_divergent: torch.Tensor
+    energy: torch.Tensor
+    proposal: IntegratorState
+    num_integration_steps: int
+
+
+def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:
+    """blackjax/mcmc/hmc.py:90-92."""
+    position = check_batch(position, "position")
+    if position.ndim != 2:
+        raise ValueError(f"position must be (n_chains, dim), got {tuple(position.shape)}")
+    logp, grad = eval_logdensity(value_and_grad(logdensity_fn), position)
+    return HMCState(position, logp, grad)
+
+
+def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
+    if metric.kind == "diag":
+        _lib.call("bjx_leapfrog_diag", stream, N, D, n_kicks, eps, _lib.ptr(eps_pc),
+                  metric.imm.data_ptr(), metric.imm_stride, q_in.data_ptr(), p_in.data_ptr(),
+                  g.data_ptr(), q_out.data_ptr(), p_out.data_ptr())
+    else:
+        from . import dense
+
+        dense.leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out)
+
+
+def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: float = 1000,
+                 build_proposal=None):
+    """blackjax/mcmc/hmc.py:251-314.  ``build_proposal`` other than the default endpoint
+    proposal (hmc_proposal, 115-178) is out of scope."""
+    integrators.check_supported(integrator)
+    if build_proposal is not None:
+        raise NotImplementedError("only the default hmc_proposal is implemented")
+    thr = float(divergence_threshold)
+
+    def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+               inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
+        """One HMC transition for all chains (hmc.py:279-312 + hmc_proposal.generate 153-176)."""
+        q0 = check_batch(state.position, "state.position")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        N, D = q0.shape
+        L = int(num_integration_steps)
+        if L < 0:
+            raise ValueError("num_integration_steps must be >= 0")
+        k0, k1 = key_words(rng_key)
+        vg = value_and_grad(logdensity_fn)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
+        eps, eps_pc = step_size_args(step_size, N, q0.device)
+        stream = _lib.current_stream()
+        off = int(chain_offset)
+
+        p0 = torch.empty_like(q0)
+        ke0 = torch.empty_like(logp0)
+        if metric.kind == "diag":
+            _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, N, D, metric.imm.data_ptr(),
+                      metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
+        else:
+            from . import dense
+
+            dense.momentum(stream, metric, k0, k1, off, N, D, p0, ke0)
+
+        if L == 0:
+            q, p, logp, g = q0, p0, logp0, g0
+            eps_fin, eps_pc_fin = 0.0, None
+        else:
+            q = torch.empty_like(q0)
+            p = torch.empty_like(q0)
+            _launch_leapfrog(stream, metric, N, D, 1, eps, eps_pc, q0, p0, g0, q, p)
+            logp, g = eval_logdensity(vg, q)
+            for _ in range(L - 1):
+                _launch_leapfrog(stream, metric, N, D, 2, eps, eps_pc, q, p, g, q, p)
+                logp, g = eval_logdensity(vg, q)
+            eps_fin, eps_pc_fin = eps, eps_pc
+
+        p_end = torch.empty_like(q0)
+        q_new = torch.empty_like(q0)
+        g_new = torch.empty_like(q0)
+        logp_new = torch.empty_like(logp0)
+        acc_rate = torch.empty_like(logp0)
+        energy = torch.empty_like(logp0)
+        is_acc = torch.empty(N, dtype=torch.bool, device=q0.device)
+        is_div = torch.empty(N, dtype=torch.bool, device=q0.device)
+        if metric.kind == "diag":
+            _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, N, D, eps_fin,
+                      _lib.ptr(eps_pc_fin), metric.imm.data_ptr(), metric.imm_stride, thr,
+                      q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
+                      q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(),
+                      p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
+                      acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(),
+                      energy.data_ptr())
+        else:
+            from . import dense
+
+            dense.finish(stream, metric, k0, k1, off, N, D, eps_fin, eps_pc_fin, thr, q0, logp0,
+                         g0, ke0, q, logp, g, p, p_end, q_new, logp_new, g_new, acc_rate,
+                         is_acc, is_div, energy)
+
+        info = HMCInfo(p0, acc_rate, is_acc, is_div, energy,
+                       IntegratorState(q, p_end, logp, g), L)
+        return HMCState(q_new, logp_new, g_new), info
+
+    return kernel
+
+
+def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix,
+                     num_integration_steps: int, *, divergence_threshold: float = 1000,
+                     integrator=integrators.velocity_verlet, build_proposal=None,
+                     chain_offset: int = 0) -> SamplingAlgorithm:
+    """blackjax/mcmc/hmc.py:317-414.  ``chain_offset`` is this process' first global chain
+    index when the chains of one run are sharded over several GPUs."""
+    kernel = build_kernel(integrator, divergence_threshold, build_proposal)
+
+    def init_fn(position, rng_key=None):
+        del rng_key
+        return init(position, logdensity_fn)
+
+    def step_fn(rng_key, state):
+        return kernel(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
+                      num_integration_steps, chain_offset=chain_offset)
+
+    return SamplingAlgorithm(init_fn, step_fn)

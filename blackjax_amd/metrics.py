@@ -1,0 +1,80 @@
+"""Host-side metric preparation (blackjax/mcmc/metrics.py:180-218, 701-729).
+
+The Gaussian-Euclidean metric itself (momentum draw, kinetic energy, U-turn dot
+products) is evaluated inside the HIP kernels; this module only classifies the
+``inverse_mass_matrix`` argument and, for a dense matrix, factorises it once.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+
+
+class Metric(NamedTuple):
+    kind: str  # "diag" | "dense"
+    imm: torch.Tensor  # (D,), (N, D) [diag]  or (D, D) [dense]
+    imm_stride: int  # diag: 0 shared, D per chain
+    mass_sqrt_t: Optional[torch.Tensor]  # dense: (L^{-T})^T = L^{-1}, row-major (D, D)
+
+
+_DENSE_CACHE: dict = {}
+
+
+def default_metric(inverse_mass_matrix, n_chains: int, dim: int, device) -> Metric:
+    """Classify ``inverse_mass_matrix`` like metrics.py:180-218 / _format_covariance 701-729.
+
+    * 1-d ``(D,)``: diagonal, shared by all chains.
+    * 2-d ``(N, D)`` with ``N == n_chains`` and ``N != D``: per-chain diagonal (what a
+      vmapped ``window_adaptation(...).run`` produces in the reference).  For the
+      ambiguous square case ``N == D`` a 2-d array is a dense matrix, exactly as in the
+      reference; pass ``PerChainDiag(imm)`` to force the per-chain reading.
+    * 2-d ``(D, D)``: dense, shared by all chains.
+    """
+    per_chain = False
+    if isinstance(inverse_mass_matrix, PerChainDiag):
+        inverse_mass_matrix = inverse_mass_matrix.imm
+        per_chain = True
+    imm = torch.as_tensor(inverse_mass_matrix, dtype=torch.float32, device=device)
+    if imm.ndim == 1:
+        if imm.shape[0] != dim:
+            raise ValueError(f"inverse_mass_matrix has {imm.shape[0]} entries, position has {dim}")
+        return Metric("diag", imm.contiguous(), 0, None)
+    if imm.ndim == 2 and (per_chain or (imm.shape[0] == n_chains and imm.shape[0] != imm.shape[1])):
+        if imm.shape != (n_chains, dim):
+            raise ValueError(
+                f"per-chain inverse_mass_matrix must be ({n_chains}, {dim}), got {tuple(imm.shape)}")
+        return Metric("diag", imm.contiguous(), dim, None)
+    if imm.ndim == 2 and imm.shape[0] == imm.shape[1]:
+        if imm.shape[0] != dim:
+            raise ValueError(f"inverse_mass_matrix is {tuple(imm.shape)}, position has {dim} dims")
+        return _dense_metric(imm.contiguous())
+    raise ValueError(
+        "The mass matrix has the wrong number of dimensions:"
+        f" expected 1 or 2, got {imm.ndim}."
+    )
+
+
+class PerChainDiag:
+    """Marker wrapper: treat a 2-d array as per-chain diagonals even when N == D."""
+
+    def __init__(self, imm):
+        self.imm = imm
+
+
+def _dense_metric(imm: torch.Tensor) -> Metric:
+    """metrics.py:711-715: ``L = cholesky(imm, lower)``; ``mass_matrix_sqrt = L^{-T}``.
+    Factorised once per distinct matrix (fp64, rounded once to fp32) instead of inside
+    every kernel call as the reference does (hmc.py:289)."""
+    key = (imm.data_ptr(), imm._version, tuple(imm.shape))
+    hit = _DENSE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    L = torch.linalg.cholesky(imm.double())
+    eye = torch.eye(imm.shape[0], dtype=torch.float64, device=imm.device)
+    Linv = torch.linalg.solve_triangular(L, eye, upper=False)  # L^{-1} = (L^{-T})^T
+    m = Metric("dense", imm, 0, Linv.float().contiguous())
+    if len(_DENSE_CACHE) > 8:
+        _DENSE_CACHE.clear()
+    _DENSE_CACHE[key] = m
+    return m

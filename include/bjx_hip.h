@@ -1,0 +1,110 @@
+/*
+ * bjx_hip.h -- C ABI of libbjxhip.so, the MI355X (gfx950) engine behind
+ * blackjax_amd.hmc / .nuts / .window_adaptation.
+ *
+ * The reference (blackjax-devs/blackjax) has no FFI: its hot path is a Python
+ * protocol (blackjax/base.py:88-113, SamplingAlgorithm(init, step)).  This header
+ * is the boundary a maintainer would bind (ctypes stub in INTEGRATION.md); every
+ * entry point cites the reference function(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every function returns 0 on success, non-zero on failure;
+ *     bjx_last_error() returns a thread-local message for the last failure.
+ *   - all array pointers are DEVICE pointers owned by the caller; nothing is
+ *     allocated inside a call; calls are asynchronous on `stream` (a hipStream_t
+ *     passed as void*), re-entrant, no global mutable state.
+ *   - chain-major row layout: an (N, D) array is N rows of D contiguous fp32.
+ *   - `key` arguments are threefry keys passed BY VALUE as two uint32 words
+ *     (jax.random key data); per-chain keys are derived in-kernel as
+ *     split(key, N_total)[chain_offset + i] so sharded runs need no exchange.
+ *   - `eps` (step size): if `eps_per_chain` != NULL it is a device (N,) array,
+ *     otherwise the scalar `eps` is used for every chain.
+ *   - `imm` (diagonal inverse mass matrix): row stride `imm_stride` = 0 for one
+ *     shared (D,) vector, = D for a per-chain (N, D) array.
+ */
+#ifndef BJX_HIP_H
+#define BJX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BJX_ABI_VERSION 1
+
+const char* bjx_last_error(void);
+int bjx_abi_version(void);
+
+/* jax.random.split(key, n)[offset : offset+n] on the host (no device work).
+ * Replaces: jax.random.split at blackjax/util.py:203, adaptation/staged_adaptation.py:868.
+ * out: host uint32[n][2]. */
+int bjx_keys_split(uint32_t key0, uint32_t key1, int64_t n, int64_t offset, uint32_t* out);
+
+/* Debug/parity probes of the in-kernel RNG (device): z[i][j] = jax.random.normal(
+ * split(key, .)[chain_offset+i] , (D,))[j]  and  u[i] = jax.random.uniform(same key, ()).
+ * Replaces: jax.random.normal at blackjax/util.py:90; jax.random.uniform inside bernoulli
+ * at blackjax/mcmc/proposal.py:226. */
+int bjx_rng_normal(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                   int64_t N, int64_t D, float* z_out);
+int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                    int64_t N, float* u_out);
+
+/* Momentum draw for a diagonal metric + initial kinetic energy.
+ *   k_i = split(key, .)[chain_offset+i]; km = split(k_i, 2)[0]
+ *   p0[i] = (1/sqrt(imm)) * normal(km, (D,)) ;  ke0[i] = 0.5 * dot(imm*p0[i], p0[i])
+ * Replaces: blackjax/mcmc/hmc.py:299,302 ; metrics.py:260-261,263-270,704-709 ; util.py:66-91. */
+int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                          int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                          float* p_out, float* ke_out);
+
+/* Fused velocity-Verlet "kick(s) + drift" for a diagonal metric:
+ *   n_kicks = 1:  p = p + (eps/2) g                       (first step of a trajectory)
+ *   n_kicks = 2:  p = (p + (eps/2) g) + (eps/2) g         (closing half kick of the previous
+ *                                                          step + opening half kick of this one;
+ *                                                          two separately rounded fmas)
+ *   v = imm * p ;  q = q + eps * v
+ * reads p_in, g, q_in ; writes p_out, q_out (may alias the inputs).
+ * Replaces: blackjax/mcmc/integrators.py:104-150 (one_step), 191-205, 226-243 with
+ * coefficients [0.5, 1.0, 0.5] (321-322), driven by trajectory.py:155-165. */
+int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                      const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                      const float* q_in, const float* p_in, const float* g, float* q_out,
+                      float* p_out);
+
+/* Closing half kick + flip + energies + Metropolis accept + state select (diag metric).
+ *   p1 = p + (eps/2) g1 ; p_end = -p1 ; ke1 = 0.5 dot(imm*p1, p1)
+ *   H0 = -logp0 + ke0 ; H1 = -logp1 + ke1 ; delta = H0 - H1 (NaN -> -inf)
+ *   is_divergent = -delta > divergence_threshold ; p_acc = min(1, exp(delta))
+ *   ki = split(split(key,.)[chain_offset+i], 2)[1] ; accept = uniform(ki) < p_acc
+ *   (q,logp,g)_out = accept ? (q1,logp1,g1) : (q0,logp0,g0)
+ * p_end_out may be NULL (HMCInfo.proposal.momentum not wanted) or alias p.
+ * Replaces: blackjax/mcmc/hmc.py:95-112,153-176 ; trajectory.py:730-750 ;
+ * proposal.py:45-48,214-235. */
+int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                        int64_t N, int64_t D, float eps, const float* eps_per_chain,
+                        const float* imm, int64_t imm_stride, float divergence_threshold,
+                        const float* q0, const float* logp0, const float* g0, const float* ke0,
+                        const float* q1, const float* logp1, const float* g1, const float* p,
+                        float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                        float* acceptance_rate_out, uint8_t* is_accepted_out,
+                        uint8_t* is_divergent_out, float* energy_out);
+
+/* Built-in synthetic targets (value + gradient in one pass, fp64-accumulated logp) used
+ * as the "user callable" by the bench and parity tests.
+ *   diag gaussian:  g = -(q*inv_var) ; logp = 0.5 * sum q*g     (tests/fixtures.py:60-78)
+ *   neal funnel:    tests/fixtures.py:81-98
+ *   ar1 gaussian:   Sigma_ij = rho^|i-j| (tridiagonal precision)                         */
+int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* inv_var,
+                             const float* q, float* logp_out, float* g_out);
+int bjx_target_neal_funnel(void* stream, int64_t N, int64_t D, const float* q,
+                           float* logp_out, float* g_out);
+int bjx_target_ar1_gaussian(void* stream, int64_t N, int64_t D, float diag_edge,
+                            float diag_mid, float off, const float* q, float* logp_out,
+                            float* g_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BJX_HIP_H */

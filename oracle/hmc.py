@@ -1,0 +1,197 @@
+"""Oracle for the HMC transition (TEST INFRASTRUCTURE, see package docstring).
+
+Batched restatement: every array carries a leading chain axis N; chain ``i``
+of ``kernel(rng_key, state, ...)`` equals the reference's single-chain
+``blackjax.hmc.build_kernel()(jax.random.split(rng_key, N)[i], state_i, ...)``
+i.e. the "step-major" vmap layout of
+docs/examples/howto_sample_multiple_chains.md:120-127.
+
+Reference lines followed
+* HMCState / HMCInfo / init          blackjax/mcmc/hmc.py:38-92
+* velocity_verlet one_step           blackjax/mcmc/integrators.py:104-150,191-205,226-243,321-322
+* static_integration                 blackjax/mcmc/trajectory.py:136-167
+* gaussian_euclidean metric          blackjax/mcmc/metrics.py:221-304,701-729
+* generate_gaussian_noise/linear_map blackjax/util.py:23-61,66-91
+* hmc_energy                         blackjax/mcmc/trajectory.py:730-750
+* safe_energy_diff / static_binomial blackjax/mcmc/proposal.py:45-48,214-235
+* hmc_proposal.generate / kernel     blackjax/mcmc/hmc.py:153-176,279-312
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple
+
+import numpy as np
+
+from . import prng
+from .fp import dot64, exp_cr, f32, f64, fma32
+
+
+class HMCState(NamedTuple):  # hmc.py:38-49
+    position: np.ndarray  # (N, D)
+    logdensity: np.ndarray  # (N,)
+    logdensity_grad: np.ndarray  # (N, D)
+
+
+class IntegratorState(NamedTuple):  # integrators.py:43-53
+    position: np.ndarray
+    momentum: np.ndarray
+    logdensity: np.ndarray
+    logdensity_grad: np.ndarray
+
+
+class HMCInfo(NamedTuple):  # hmc.py:52-87
+    momentum: np.ndarray
+    acceptance_rate: np.ndarray
+    is_accepted: np.ndarray
+    is_divergent: np.ndarray
+    energy: np.ndarray
+    proposal: IntegratorState
+    num_integration_steps: int
+
+
+def init(position, logdensity_fn: Callable) -> HMCState:  # hmc.py:90-92
+    position = np.asarray(position, dtype=f32)
+    logp, grad = logdensity_fn(position)
+    return HMCState(position, np.asarray(logp, f32), np.asarray(grad, f32))
+
+
+# ----------------------------------------------------------------------------- metric
+class Metric(NamedTuple):
+    inverse_mass_matrix: np.ndarray  # (D,), (N, D) or (D, D)
+    mass_matrix_sqrt: np.ndarray  # diag: 1/sqrt(imm) ; dense: L^{-T}
+    is_dense: bool
+
+
+def default_metric(inverse_mass_matrix, n_chains=None) -> Metric:
+    """metrics.py:180-218 -> gaussian_euclidean 221-346 -> _format_covariance 701-729.
+
+    diag: ``inv_cov_sqrt = sqrt(imm)``, ``mass_matrix_sqrt = 1/inv_cov_sqrt``
+    (704-709).  A 2-d array whose leading dimension equals ``n_chains`` and is not
+    square is a per-chain diagonal (the vmapped-warmup case).  dense:
+    ``L = cholesky(imm, lower)``, ``mass_matrix_sqrt = solve_triangular(L, I,
+    lower=True, trans=True) = L^{-T}`` (711-715); factorised in fp64 and rounded
+    once to fp32.
+    """
+    imm = np.asarray(inverse_mass_matrix, dtype=f32)
+    if imm.ndim == 1 or (imm.ndim == 2 and n_chains is not None and imm.shape[0] == n_chains
+                         and imm.shape[0] != imm.shape[1]):
+        inv_sqrt = np.sqrt(imm)
+        return Metric(imm, (f32(1.0) / inv_sqrt).astype(f32), False)
+    if imm.ndim == 2 and imm.shape[0] == imm.shape[1]:
+        L = np.linalg.cholesky(imm.astype(f64))
+        mass_sqrt = np.linalg.solve(L.T, np.eye(L.shape[0]))  # L^{-T}
+        return Metric(imm, mass_sqrt.astype(f32), True)
+    raise ValueError(
+        "The mass matrix has the wrong number of dimensions:"
+        f" expected 1 or 2, got {imm.ndim}."
+    )
+
+
+def linear_map(metric: Metric, mat, x):
+    """util.py:23-61: diag -> elementwise multiply; dense -> mat @ x per chain
+    (fp64 accumulate, rounded once)."""
+    if not metric.is_dense:
+        return (mat * x).astype(f32)
+    return (x.astype(f64) @ mat.astype(f64).T).astype(f32)
+
+
+def sample_momentum(metric: Metric, keys, D):
+    """metrics.py:260-261 -> util.py:89-91: p = mass_matrix_sqrt (.) normal(key, (D,))."""
+    z = prng.normal(keys, (D,))
+    return linear_map(metric, metric.mass_matrix_sqrt, z)
+
+
+def kinetic_energy(metric: Metric, p):
+    """metrics.py:263-270: 0.5 * dot(linear_map(imm, p), p)."""
+    v = linear_map(metric, metric.inverse_mass_matrix, p)
+    return f32(0.5) * dot64(v, p)
+
+
+# ----------------------------------------------------------------------------- integrator
+def _col(x):
+    x = np.asarray(x, dtype=f32)
+    return x[:, None] if x.ndim == 1 else x
+
+
+def velocity_verlet(state: IntegratorState, step_size, logdensity_fn, metric: Metric):
+    """One velocity-Verlet step, coefficients [0.5, 1.0, 0.5]
+    (integrators.py:321-322 -> 104-150).  ``step_size`` scalar or (N,) (may be
+    negative: direction*step_size in NUTS, trajectory.py:323).
+
+    p += (eps*0.5)*g ; v = dK/dp = imm p ; q += (eps*1.0)*v ; (logp,g)=f(q) ; p += (eps*0.5)*g
+    each ``x + s*y`` a single fma (see package docstring).
+    """
+    q, p, _, g = state
+    eps = _col(step_size) if np.ndim(step_size) else f32(step_size)
+    h = (eps * f32(0.5)).astype(f32) if np.ndim(eps) else f32(eps * f32(0.5))
+    p = fma32(h, g, p)
+    v = linear_map(metric, metric.inverse_mass_matrix, p)
+    q = fma32(eps, v, q)
+    logp, g = logdensity_fn(q)
+    p = fma32(h, g, p)
+    return IntegratorState(q, p, np.asarray(logp, f32), np.asarray(g, f32))
+
+
+def hmc_energy(metric: Metric, state: IntegratorState):
+    """trajectory.py:745-748: -logdensity + kinetic_energy(momentum)."""
+    return (-state.logdensity + kinetic_energy(metric, state.momentum)).astype(f32)
+
+
+def safe_energy_diff(e0, e1):
+    """proposal.py:45-48."""
+    with np.errstate(invalid="ignore"):
+        d = (np.asarray(e0, f32) - np.asarray(e1, f32)).astype(f32)
+    return np.where(np.isnan(d), f32(-np.inf), d).astype(f32)
+
+
+# ----------------------------------------------------------------------------- kernel
+def chain_keys(rng_key, n, chain_offset=0):
+    """split(rng_key, N_total)[offset:offset+n] -- per-chain keys (step-major layout)."""
+    return prng.split(rng_key, n, offset=chain_offset)
+
+
+def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
+           num_integration_steps: int, divergence_threshold: float = 1000.0,
+           chain_offset: int = 0, chain_keys_override=None):
+    """hmc.py:279-312 with hmc_proposal.generate 153-176, batched over chains."""
+    N, D = state.position.shape
+    metric = default_metric(inverse_mass_matrix, n_chains=N)
+    keys = chain_keys(rng_key, N, chain_offset) if chain_keys_override is None else chain_keys_override
+    kk = prng.split(keys, 2)  # hmc.py:299
+    key_momentum, key_integrator = kk[:, 0], kk[:, 1]
+
+    p0 = sample_momentum(metric, key_momentum, D)  # hmc.py:302
+    z0 = IntegratorState(state.position, p0, state.logdensity, state.logdensity_grad)
+    z = z0
+    for _ in range(num_integration_steps):  # trajectory.py:155-165
+        z = velocity_verlet(z, step_size, logdensity_fn, metric)
+    end = IntegratorState(z.position, (f32(-1.0) * z.momentum).astype(f32), z.logdensity,
+                          z.logdensity_grad)  # flip_momentum hmc.py:95-112
+    e0 = hmc_energy(metric, z0)
+    e1 = hmc_energy(metric, end)
+    delta = safe_energy_diff(e0, e1)
+    is_div = (-delta) > f32(divergence_threshold)  # hmc.py:162
+    p_acc = np.minimum(exp_cr(delta), f32(1.0))  # proposal.py:225
+    u = prng.uniform(key_integrator, ())  # bernoulli, proposal.py:226
+    acc = u < p_acc
+    new_state = HMCState(
+        np.where(acc[:, None], end.position, state.position).astype(f32),
+        np.where(acc, end.logdensity, state.logdensity).astype(f32),
+        np.where(acc[:, None], end.logdensity_grad, state.logdensity_grad).astype(f32),
+    )
+    info = HMCInfo(p0, p_acc, acc, is_div, e1, end, num_integration_steps)
+    return new_state, info
+
+
+def run(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
+        num_integration_steps, num_steps, divergence_threshold=1000.0, chain_offset=0):
+    """util.py:150-213 run_inference_algorithm, step-major keys:
+    ``keys = split(rng_key, num_steps)``; step t uses ``split(keys[t], N)``."""
+    keys = prng.split(rng_key, num_steps)
+    positions, infos = [], []
+    for t in range(num_steps):
+        state, info = kernel(keys[t], state, logdensity_fn, step_size, inverse_mass_matrix,
+                             num_integration_steps, divergence_threshold, chain_offset)
+        positions.append(state.position)
+        infos.append(info)
+    return state, np.stack(positions, axis=0), infos

@@ -1,0 +1,56 @@
+"""Pins the oracle's threefry PRNG (CPU, no GPU needed)."""
+import json
+import os
+
+import numpy as np
+
+from oracle import prng
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def test_threefry_random123_kats():
+    for key, ctr, out in KATS["threefry2x32"]["cases"]:
+        o0, o1 = prng.threefry2x32(np.uint32(key[0]), np.uint32(key[1]), np.uint32(ctr[0]), np.uint32(ctr[1]))
+        assert [int(o0), int(o1)] == out
+
+
+def test_streams_match_jax_docs_values():
+    d = KATS["jax_docs_streams"]
+    assert prng.split(prng.key(0), 2).tolist() == d["split_key0"]
+    assert abs(float(prng.normal(prng.key(42), ())) - d["normal_key42_scalar"]) < 1e-8
+    # legacy layout words reappear as threefry(key0, (0, 2)) -- ties the block function to JAX's
+    assert prng.split(prng.key(0), 3)[2].tolist() == d["legacy_split_key0_words"]
+
+
+def test_fold_in_is_split_row_and_offsets():
+    k = prng.key(99)
+    s = prng.split(k, 10)
+    assert np.array_equal(prng.fold_in(k, 7), s[7])
+    assert np.array_equal(prng.split(k, 4, offset=5), s[5:9])
+    # batched keys
+    b = prng.split(s[:3], 2)
+    assert b.shape == (3, 2, 2) and np.array_equal(b[1], prng.split(s[1], 2))
+
+
+def test_uniform_normal_bernoulli_basic():
+    k = prng.key(5)
+    u = prng.uniform(k, (200000,))
+    assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1
+    assert abs(u.mean() - 0.5) < 5e-3
+    z = prng.normal(k, (200000,))
+    assert np.isfinite(z).all() and abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2
+    # element i of a vector draw uses counter i: a scalar draw equals element 0
+    assert prng.uniform(k, ()) == u[0]
+    b = prng.bernoulli(prng.split(k, 1000), 0.25)
+    assert b.shape == (1000,) and 0.15 < b.mean() < 0.35
+
+
+def test_erf_inv_accuracy():
+    from scipy.special import erfinv
+
+    x = np.linspace(-0.999999, 0.999999, 20001).astype(np.float32)
+    r = prng.erf_inv(x)
+    ref = erfinv(x.astype(np.float64))
+    assert np.max(np.abs(r - ref) / np.maximum(np.abs(ref), 1e-3)) < 1e-5
+    assert prng.erf_inv(np.float32(1.0)) == np.inf and prng.erf_inv(np.float32(-1.0)) == -np.inf
