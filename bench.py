@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--leapfrogs", type=int, default=50)
     ap.add_argument("--eps", type=float, default=0.25)
+    ap.add_argument("--chain-block", type=int, default=0,
+                    help="run each transition block-by-block over this many chains (0 = all at once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     args = ap.parse_args()
@@ -108,7 +110,8 @@ def main():
     sig = torch.as_tensor(sigma_ladder(D), device=dev)
     imm = (sig * sig).contiguous()
     target = bjx.targets.DiagGaussian((1.0 / imm).contiguous())
-    alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N)
+    alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N,
+                  chain_block=args.chain_block or None)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     state = alg.init(sig * torch.randn(N, D, device=dev, generator=gen))
@@ -191,6 +194,7 @@ def main():
                 "workload": f"HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
                             f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
                 "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
+                "chain_block": args.chain_block or N,
                 "parallelism": f"chains sharded x{world}, no data-path collective",
             },
             "mean_acceptance": float(acc_sum.item()) / args.steps,

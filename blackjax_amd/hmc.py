@@ -73,14 +73,30 @@ def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, 
         dense.leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out)
 
 
+def _default_chain_block():
+    import os
+
+    v = os.environ.get("BJX_CHAIN_BLOCK", "")
+    return int(v) if v else None
+
+
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: float = 1000,
-                 build_proposal=None):
+                 build_proposal=None, *, chain_block=None):
     """blackjax/mcmc/hmc.py:251-314.  ``build_proposal`` other than the default endpoint
-    proposal (hmc_proposal, 115-178) is out of scope."""
+    proposal (hmc_proposal, 115-178) is out of scope.
+
+    ``chain_block``: chains are independent, so a transition may be run block by block
+    (``chain_block`` chains at a time through all L leapfrogs) instead of launch by launch
+    over all N chains.  With a block whose q/p/g working set fits the 256 MiB Infinity Cache
+    the L-step loop re-reads its state from on-die cache instead of HBM.  Results are
+    identical for any blocking (per-chain keys depend only on the global chain index).
+    """
     integrators.check_supported(integrator)
     if build_proposal is not None:
         raise NotImplementedError("only the default hmc_proposal is implemented")
     thr = float(divergence_threshold)
+    if chain_block is None:
+        chain_block = _default_chain_block()
 
     def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
@@ -98,55 +114,82 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         eps, eps_pc = step_size_args(step_size, N, q0.device)
         stream = _lib.current_stream()
         off = int(chain_offset)
+        dev = q0.device
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        if metric.kind == "diag":
-            _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, N, D, metric.imm.data_ptr(),
-                      metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
-        else:
-            from . import dense
-
-            dense.momentum(stream, metric, k0, k1, off, N, D, p0, ke0)
-
-        if L == 0:
-            q, p, logp, g = q0, p0, logp0, g0
-            eps_fin, eps_pc_fin = 0.0, None
-        else:
-            q = torch.empty_like(q0)
-            p = torch.empty_like(q0)
-            _launch_leapfrog(stream, metric, N, D, 1, eps, eps_pc, q0, p0, g0, q, p)
-            logp, g = eval_logdensity(vg, q)
-            for _ in range(L - 1):
-                _launch_leapfrog(stream, metric, N, D, 2, eps, eps_pc, q, p, g, q, p)
-                logp, g = eval_logdensity(vg, q)
-            eps_fin, eps_pc_fin = eps, eps_pc
-
+        q_end = torch.empty_like(q0) if L > 0 else q0
+        p_work = torch.empty_like(q0) if L > 0 else p0
         p_end = torch.empty_like(q0)
         q_new = torch.empty_like(q0)
         g_new = torch.empty_like(q0)
         logp_new = torch.empty_like(logp0)
         acc_rate = torch.empty_like(logp0)
         energy = torch.empty_like(logp0)
-        is_acc = torch.empty(N, dtype=torch.bool, device=q0.device)
-        is_div = torch.empty(N, dtype=torch.bool, device=q0.device)
-        if metric.kind == "diag":
-            _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, N, D, eps_fin,
-                      _lib.ptr(eps_pc_fin), metric.imm.data_ptr(), metric.imm_stride, thr,
-                      q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
-                      q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(),
-                      p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
-                      acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(),
-                      energy.data_ptr())
-        else:
-            from . import dense
+        is_acc = torch.empty(N, dtype=torch.bool, device=dev)
+        is_div = torch.empty(N, dtype=torch.bool, device=dev)
 
-            dense.finish(stream, metric, k0, k1, off, N, D, eps_fin, eps_pc_fin, thr, q0, logp0,
-                         g0, ke0, q, logp, g, p, p_end, q_new, logp_new, g_new, acc_rate,
-                         is_acc, is_div, energy)
+        blk = N if not chain_block or chain_block >= N else int(chain_block)
+        n_blocks = (N + blk - 1) // blk if N else 0
+        g_end = logp_end = None
+        if n_blocks > 1 and L > 0:
+            g_end = torch.empty_like(q0)
+            logp_end = torch.empty_like(logp0)
 
+        for b in range(n_blocks):
+            s, e = b * blk, min(N, (b + 1) * blk)
+            n = e - s
+            sl = slice(s, e)
+            m = metric if metric.imm_stride == 0 else metric._replace(imm=metric.imm[sl])
+            eb = None if eps_pc is None else eps_pc[sl]
+            boff = off + s
+            if m.kind == "diag":
+                _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, n, D, m.imm.data_ptr(),
+                          m.imm_stride, p0[sl].data_ptr(), ke0[sl].data_ptr())
+            else:
+                from . import dense
+
+                dense.momentum(stream, m, k0, k1, boff, n, D, p0[sl], ke0[sl])
+
+            if L == 0:
+                q, p, logp, g = q0[sl], p0[sl], logp0[sl], g0[sl]
+                eps_fin, eps_pc_fin = 0.0, None
+            else:
+                q, p = q_end[sl], p_work[sl]
+                _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
+                logp, g = eval_logdensity(vg, q)
+                for _ in range(L - 1):
+                    _launch_leapfrog(stream, m, n, D, 2, eps, eb, q, p, g, q, p)
+                    logp, g = eval_logdensity(vg, q)
+                eps_fin, eps_pc_fin = eps, eb
+
+            if m.kind == "diag":
+                _lib.call("bjx_hmc_finish_diag", stream, k0, k1, boff, n, D, eps_fin,
+                          _lib.ptr(eps_pc_fin), m.imm.data_ptr(), m.imm_stride, thr,
+                          q0[sl].data_ptr(), logp0[sl].data_ptr(), g0[sl].data_ptr(),
+                          ke0[sl].data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(),
+                          p.data_ptr(), p_end[sl].data_ptr(), q_new[sl].data_ptr(),
+                          logp_new[sl].data_ptr(), g_new[sl].data_ptr(), acc_rate[sl].data_ptr(),
+                          is_acc[sl].data_ptr(), is_div[sl].data_ptr(), energy[sl].data_ptr())
+            else:
+                from . import dense
+
+                dense.finish(stream, m, k0, k1, boff, n, D, eps_fin, eps_pc_fin, thr, q0[sl],
+                             logp0[sl], g0[sl], ke0[sl], q, logp, g, p, p_end[sl], q_new[sl],
+                             logp_new[sl], g_new[sl], acc_rate[sl], is_acc[sl], is_div[sl],
+                             energy[sl])
+            if g_end is not None:
+                g_end[sl].copy_(g)
+                logp_end[sl].copy_(logp)
+            else:
+                g_end_single, logp_end_single = g, logp
+
+        if n_blocks == 0:
+            g_end_single, logp_end_single = g0, logp0
+        if g_end is None:
+            g_end, logp_end = g_end_single, logp_end_single
         info = HMCInfo(p0, acc_rate, is_acc, is_div, energy,
-                       IntegratorState(q, p_end, logp, g), L)
+                       IntegratorState(q_end, p_end, logp_end, g_end), L)
         return HMCState(q_new, logp_new, g_new), info
 
     return kernel
@@ -155,10 +198,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix,
                      num_integration_steps: int, *, divergence_threshold: float = 1000,
                      integrator=integrators.velocity_verlet, build_proposal=None,
-                     chain_offset: int = 0) -> SamplingAlgorithm:
+                     chain_offset: int = 0, chain_block=None) -> SamplingAlgorithm:
     """blackjax/mcmc/hmc.py:317-414.  ``chain_offset`` is this process' first global chain
     index when the chains of one run are sharded over several GPUs."""
-    kernel = build_kernel(integrator, divergence_threshold, build_proposal)
+    kernel = build_kernel(integrator, divergence_threshold, build_proposal,
+                          chain_block=chain_block)
 
     def init_fn(position, rng_key=None):
         del rng_key

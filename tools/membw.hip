@@ -1,0 +1,45 @@
+// Microbenchmark: streaming bandwidth of MI355X vs working-set size (HBM vs Infinity Cache),
+// for the access mix of the leapfrog kernel (3 reads : 2 writes), a plain copy and a read-only sum.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/membw.hip -o tools/membw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+struct alignas(16) F4 { float x, y, z, w; };
+__global__ void __launch_bounds__(256) k_copy(const F4* a, F4* b, size_t n) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) b[i] = a[i];
+}
+__global__ void __launch_bounds__(256) k_read(const F4* a, float* out, size_t n) {
+  float s = 0;
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) { F4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+  if (s == 12345.f) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_lf(F4* q, F4* p, const F4* g, size_t n) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    F4 pp = p[i], gg = g[i], qq = q[i];
+    pp.x = fmaf(0.1f, gg.x, pp.x); pp.y = fmaf(0.1f, gg.y, pp.y); pp.z = fmaf(0.1f, gg.z, pp.z); pp.w = fmaf(0.1f, gg.w, pp.w);
+    qq.x = fmaf(0.2f, pp.x, qq.x); qq.y = fmaf(0.2f, pp.y, qq.y); qq.z = fmaf(0.2f, pp.z, qq.z); qq.w = fmaf(0.2f, pp.w, qq.w);
+    p[i] = pp; q[i] = qq;
+  }
+}
+int main() {
+  size_t maxb = 1ull << 30;
+  F4 *a, *b, *c; float* out;
+  hipMalloc(&a, maxb); hipMalloc(&b, maxb); hipMalloc(&c, maxb); hipMalloc(&out, 4);
+  hipMemset(a, 0, maxb); hipMemset(b, 0, maxb); hipMemset(c, 0, maxb);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int grid : {2048, 4096, 16384}) {
+  for (size_t mb : {8, 16, 32, 64, 128, 256, 1024}) {
+    size_t bytes = mb << 20, n = bytes / 16;
+    int reps = (int)(4096 / mb); if (reps < 4) reps = 4;
+    float ms[3];
+    for (int k = 0; k < 3; ++k) {
+      for (int w = 0; w < 2; ++w) { if (k == 0) k_read<<<grid, 256>>>(a, out, n); else if (k == 1) k_copy<<<grid, 256>>>(a, b, n); else k_lf<<<grid, 256>>>(a, b, c, n); }
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) { if (k == 0) k_read<<<grid, 256>>>(a, out, n); else if (k == 1) k_copy<<<grid, 256>>>(a, b, n); else k_lf<<<grid, 256>>>(a, b, c, n); }
+      hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms[k], e0, e1); ms[k] /= reps;
+    }
+    printf("grid %5d  array %5zu MiB : read %7.0f GB/s | copy %7.0f GB/s | leapfrog(3r2w) %7.0f GB/s  (%.1f us)\n", grid, mb,
+           bytes / ms[0] / 1e6, 2.0 * bytes / ms[1] / 1e6, 5.0 * bytes / ms[2] / 1e6, ms[2] * 1e3);
+  }}
+  return 0;
+}
