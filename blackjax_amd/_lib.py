@@ -22,14 +22,21 @@ SIGNATURES = {
     "bjx_keys_split": [c_uint32, c_uint32, c_int64, c_int64, POINTER(c_uint32)],
     "bjx_rng_normal": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, _f32p],
     "bjx_rng_uniform": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, _f32p],
-    "bjx_hmc_momentum_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, _f32p,
+    "bjx_hmc_momentum_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p,
                               c_int64, _f32p, _f32p],
     "bjx_leapfrog_diag": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, c_int64,
                           _f32p, _f32p, _f32p, _f32p, _f32p],
-    "bjx_hmc_finish_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_float,
+    "bjx_hmc_finish_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_float,
                             _f32p, _f32p, c_int64, c_float,
                             _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                             _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
+    "bjx_da_init": [c_void_p, c_int64, c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_da_update": [c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float, _f32p, _f32p,
+                      _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_exp": [c_void_p, c_int64, _f32p, _f32p],
+    "bjx_welford_update_diag": [c_void_p, c_int64, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_welford_final_diag": [c_void_p, c_int64, c_int64, c_int64, c_float, _f32p, _f32p, c_int64,
+                               _f32p],
     "bjx_target_diag_gaussian": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p],
     "bjx_target_neal_funnel": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
     "bjx_target_ar1_gaussian": [c_void_p, c_int64, c_int64, c_float, c_float, c_float, _f32p,

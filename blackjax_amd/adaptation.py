@@ -1,0 +1,261 @@
+"""Stan-style window adaptation on MI355X behind ``blackjax.window_adaptation``.
+
+Mirrors blackjax/adaptation/window_adaptation.py:296-444 (argument validation + delegate) and the
+single-chain engine of blackjax/adaptation/staged_adaptation.py (``_make_engine`` 111-307,
+``build_schedule`` 315-405, ``run`` 860-876 / 968-981) with dual averaging
+(optimizers/dual_averaging.py:53-129, adaptation/step_size.py:65-150) and the Welford
+mass-matrix estimator (adaptation/mass_matrix.py:111-444).
+
+Semantics: adaptation is PER CHAIN, exactly as in the reference where many chains means
+``jax.vmap(warmup.run)(jax.random.split(rng_key, N), positions)``: every chain owns a step size
+and a (diagonal) inverse mass matrix; chain ``i`` uses key ``split(split(rng_key, N)[i], T)[t]``
+at step ``t`` (chain-major layout).  No collective is needed when chains
+are sharded over GPUs.  All per-chain arithmetic runs in HIP kernels (``bjx_adapt.hip``).
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple, Optional
+
+import torch
+
+from . import _lib, integrators, metrics
+from ._util import check_batch
+from .base import AdaptationAlgorithm
+from .random import ChainMajorKey, key_words
+
+__all__ = ["window_adaptation", "build_schedule", "AdaptationResults", "AdaptationInfo",
+           "return_all_adapt_info", "get_filter_adapt_info_fn", "DualAveragingAdaptationState",
+           "WelfordAlgorithmState", "MassMatrixAdaptationState", "StagedAdaptationState"]
+
+
+# ------------------------------------------------------------------------------- result types
+class AdaptationResults(NamedTuple):  # adaptation/base.py:21-23
+    state: NamedTuple
+    parameters: dict
+
+
+class AdaptationInfo(NamedTuple):  # adaptation/base.py:26-29
+    state: NamedTuple
+    info: NamedTuple
+    adaptation_state: NamedTuple
+
+
+def return_all_adapt_info(state, info, adaptation_state):
+    """adaptation/base.py:32-36.  NOTE: with thousands of chains this retains every step's
+    (N, D) tensors; pass ``get_filter_adapt_info_fn(...)`` to keep only what is needed."""
+    return AdaptationInfo(state, info, adaptation_state)
+
+
+def get_filter_adapt_info_fn(state_keys=frozenset(), info_keys=frozenset(),
+                             adapt_state_keys=frozenset()):
+    """adaptation/base.py:39-60: keep only the named fields (others become ``None``)."""
+
+    def filter_tuple(tup, key_set):
+        return type(tup)(*[v if k in key_set else None for k, v in zip(tup._fields, tup)])
+
+    def filter_fn(state, info, adaptation_state):
+        return AdaptationInfo(filter_tuple(state, state_keys), filter_tuple(info, info_keys),
+                              filter_tuple(adaptation_state, adapt_state_keys))
+
+    return filter_fn
+
+
+class DualAveragingAdaptationState(NamedTuple):  # adaptation/step_size.py:26-62
+    log_step_size: torch.Tensor  # (N,)
+    log_step_size_avg: torch.Tensor
+    step: int  # identical for every chain (same schedule)
+    avg_error: torch.Tensor
+    mu: torch.Tensor
+
+
+class WelfordAlgorithmState(NamedTuple):  # adaptation/mass_matrix.py:364-388
+    mean: torch.Tensor  # (N, D)
+    m2: torch.Tensor  # (N, D)
+    sample_size: int
+
+
+class MassMatrixAdaptationState(NamedTuple):  # adaptation/mass_matrix.py:33-56
+    inverse_mass_matrix: torch.Tensor  # (N, D)
+    wc_state: WelfordAlgorithmState
+
+
+class StagedAdaptationState(NamedTuple):  # adaptation/staged_adaptation.py:69-103
+    ss_state: DualAveragingAdaptationState
+    imm_state: MassMatrixAdaptationState
+    step_size: torch.Tensor  # (N,)
+    inverse_mass_matrix: torch.Tensor  # (N, D)
+
+
+# ------------------------------------------------------------------------------- schedule (host)
+def build_schedule(num_steps: int, initial_buffer_size: int = 75, final_buffer_size: int = 50,
+                   first_window_size: int = 25) -> list:
+    """Stan warmup schedule, list of ``(stage, is_middle_window_end)``
+    (adaptation/staged_adaptation.py:315-405)."""
+    schedule = []
+    if num_steps < 20:
+        return [(0, False)] * num_steps
+    if initial_buffer_size + first_window_size + final_buffer_size > num_steps:
+        initial_buffer_size = int(0.15 * num_steps)
+        final_buffer_size = int(0.1 * num_steps)
+        first_window_size = num_steps - initial_buffer_size - final_buffer_size
+    schedule += [(0, False)] * initial_buffer_size
+    final_buffer_start = num_steps - final_buffer_size
+    size, start = first_window_size, initial_buffer_size
+    while start < final_buffer_start:
+        cur_start, cur_size = start, size
+        if 3 * cur_size <= final_buffer_start - cur_start:
+            size = 2 * cur_size
+        else:
+            cur_size = final_buffer_start - cur_start
+        start = cur_start + cur_size
+        schedule += [(1, False)] * (start - 1 - cur_start)
+        schedule.append((1, True))
+    schedule += [(0, False)] * (num_steps - final_buffer_start)
+    return schedule
+
+
+# ------------------------------------------------------------------------------- engine
+_DA_T0, _DA_GAMMA, _DA_KAPPA = 10.0, 0.05, 0.75  # dual_averaging.py:53-55 defaults
+
+
+def _da_init(x_in: torch.Tensor, from_log_avg: bool) -> tuple:
+    n = x_in.shape[0]
+    outs = [torch.empty_like(x_in) for _ in range(5)]
+    _lib.call("bjx_da_init", _lib.current_stream(), n, int(from_log_avg), x_in.data_ptr(),
+              *[o.data_ptr() for o in outs])
+    log_x, log_x_avg, avg_err, mu, step_size = outs
+    return DualAveragingAdaptationState(log_x, log_x_avg, 1, avg_err, mu), step_size
+
+
+def _da_update(ss: DualAveragingAdaptationState, acceptance_rate: torch.Tensor, target: float):
+    n = acceptance_rate.shape[0]
+    log_x, log_x_avg, avg_err, step_size = (torch.empty_like(acceptance_rate) for _ in range(4))
+    _lib.call("bjx_da_update", _lib.current_stream(), n, ss.step, float(target), _DA_T0, _DA_GAMMA,
+              _DA_KAPPA, acceptance_rate.data_ptr(), ss.log_step_size.data_ptr(),
+              ss.log_step_size_avg.data_ptr(), ss.avg_error.data_ptr(), ss.mu.data_ptr(),
+              log_x.data_ptr(), log_x_avg.data_ptr(), avg_err.data_ptr(), step_size.data_ptr())
+    return DualAveragingAdaptationState(log_x, log_x_avg, ss.step + 1, avg_err, ss.mu), step_size
+
+
+def _welford_update(wc: WelfordAlgorithmState, position: torch.Tensor) -> WelfordAlgorithmState:
+    n, d = position.shape
+    mean, m2 = torch.empty_like(position), torch.empty_like(position)
+    _lib.call("bjx_welford_update_diag", _lib.current_stream(), n, d, wc.sample_size + 1,
+              position.data_ptr(), wc.mean.data_ptr(), wc.m2.data_ptr(), mean.data_ptr(),
+              m2.data_ptr())
+    return WelfordAlgorithmState(mean, m2, wc.sample_size + 1)
+
+
+def _mm_final(mm: MassMatrixAdaptationState, shrinkage: float) -> MassMatrixAdaptationState:
+    n, d = mm.wc_state.m2.shape
+    imm = torch.empty_like(mm.wc_state.m2)
+    prev = mm.inverse_mass_matrix
+    _lib.call("bjx_welford_final_diag", _lib.current_stream(), n, d, mm.wc_state.sample_size,
+              float(shrinkage), mm.wc_state.m2.data_ptr(), prev.data_ptr(),
+              0 if prev.ndim == 1 else d, imm.data_ptr())
+    zeros = torch.zeros_like(imm)
+    return MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, torch.zeros_like(imm), 0))
+
+
+def _stack_history(history):
+    """Stack per-step records along a new leading axis, like the ``lax.scan`` output of the
+    reference (staged_adaptation.py:870-874)."""
+    if not history:
+        return None
+
+    def stack(items):
+        first = items[0]
+        if first is None:
+            return None
+        if isinstance(first, torch.Tensor):
+            if any(it.shape != first.shape for it in items):
+                return items  # e.g. the shared (D,) initial imm vs the per-chain (N, D) adapted ones
+            return torch.stack(items)
+        if isinstance(first, tuple) and hasattr(first, "_fields"):
+            return type(first)(*[stack([it[i] for it in items]) for i in range(len(first))])
+        if isinstance(first, (int, float, bool)):
+            return torch.tensor(items)
+        return items
+
+    return stack(history)
+
+
+def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagonal: bool = True,
+                      initial_inverse_mass_matrix=None, imm_shrinkage_to_previous: float = 0.0,
+                      initial_step_size: float = 1.0, target_acceptance_rate: float = 0.80,
+                      adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
+                      integrator=integrators.velocity_verlet, **extra_parameters) -> AdaptationAlgorithm:
+    """blackjax/adaptation/window_adaptation.py:296-444.  ``algorithm`` is ``blackjax_amd.hmc`` or
+    ``blackjax_amd.nuts``; ``extra_parameters`` are forwarded to its kernel (e.g.
+    ``num_integration_steps=...``).  ``adaptation_info_fn=None`` records nothing."""
+    if initial_inverse_mass_matrix is not None:
+        imm0 = torch.as_tensor(initial_inverse_mass_matrix)
+        if is_mass_matrix_diagonal:
+            if imm0.ndim != 1:
+                raise ValueError(
+                    "is_mass_matrix_diagonal=True requires "
+                    f"initial_inverse_mass_matrix.ndim == 1, got ndim={imm0.ndim}")
+        elif imm0.ndim != 2 or imm0.shape[0] != imm0.shape[1]:
+            raise ValueError(
+                "is_mass_matrix_diagonal=False requires initial_inverse_mass_matrix to be a 2-D "
+                f"square array, got shape={tuple(imm0.shape)}")
+    if imm_shrinkage_to_previous < 0.0:
+        raise ValueError(
+            f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
+    if not is_mass_matrix_diagonal:
+        raise NotImplementedError(
+            "per-chain DENSE mass-matrix adaptation (welford_dense) is not implemented yet: it needs "
+            "N x D x D state; use is_mass_matrix_diagonal=True (see DESIGN.md)")
+    integrators.check_supported(integrator)
+    mcmc_kernel = algorithm.build_kernel(integrator)
+
+    def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0):
+        """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains)."""
+        position = check_batch(position, "position")
+        n, d = position.shape
+        run_key = key_words(rng_key)
+        state = algorithm.init(position, logdensity_fn)
+        # adapt_init: staged_adaptation.py:173-184
+        if initial_inverse_mass_matrix is None:
+            imm = torch.ones(d, dtype=torch.float32, device=position.device)
+        else:
+            imm = torch.as_tensor(initial_inverse_mass_matrix, dtype=torch.float32,
+                                  device=position.device).contiguous()
+        eps0 = torch.full((n,), float(initial_step_size), dtype=torch.float32, device=position.device)
+        ss, _ = _da_init(eps0, from_log_avg=False)
+        zeros = torch.zeros_like(position)
+        ws = StagedAdaptationState(
+            ss, MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, torch.zeros_like(position), 0)),
+            eps0, imm)
+        history = []
+        info = None
+        for t, (stage, is_window_end) in enumerate(build_schedule(int(num_steps))):
+            # one_step: staged_adaptation.py:731-754
+            imm_arg = ws.inverse_mass_matrix
+            if imm_arg.ndim == 2:  # per-chain diagonals (never a dense matrix on this path)
+                imm_arg = metrics.PerChainDiag(imm_arg)
+            state, info = mcmc_kernel(ChainMajorKey(run_key, t), state, logdensity_fn, ws.step_size,
+                                      imm_arg, chain_offset=chain_offset, **extra_parameters)
+            imm_state = ws.imm_state
+            if stage == 1:  # slow_update: staged_adaptation.py:200-231
+                imm_state = MassMatrixAdaptationState(
+                    imm_state.inverse_mass_matrix, _welford_update(imm_state.wc_state, state.position))
+            ss, step_size = _da_update(ws.ss_state, info.acceptance_rate, target_acceptance_rate)
+            ws = StagedAdaptationState(ss, imm_state, step_size, imm_state.inverse_mass_matrix)
+            if is_window_end:  # slow_final: staged_adaptation.py:233-249
+                imm_state = _mm_final(ws.imm_state, imm_shrinkage_to_previous)
+                ss, step_size = _da_init(ws.ss_state.log_step_size_avg, from_log_avg=True)
+                ws = StagedAdaptationState(ss, imm_state, step_size, imm_state.inverse_mass_matrix)
+            if adaptation_info_fn is not None:
+                history.append(adaptation_info_fn(state, info, ws))
+        # final: staged_adaptation.py:299-305
+        step_size = torch.empty_like(ws.ss_state.log_step_size_avg)
+        _lib.call("bjx_exp", _lib.current_stream(), n, ws.ss_state.log_step_size_avg.data_ptr(),
+                  step_size.data_ptr())
+        imm_final = ws.imm_state.inverse_mass_matrix
+        if imm_final.ndim == 1:  # fewer than 20 steps: no window ever ended
+            imm_final = imm_final.expand(n, d).contiguous()
+        parameters = {"step_size": step_size, "inverse_mass_matrix": imm_final, **extra_parameters}
+        return AdaptationResults(state, parameters), _stack_history(history)
+
+    return AdaptationAlgorithm(run)

@@ -47,6 +47,13 @@ __device__ __forceinline__ Key key_child(Key key, uint64_t i) {
   return threefry2x32(key, (uint32_t)(i >> 32), (uint32_t)i);
 }
 
+// per-chain key for global chain index `gidx` under the two layouts of include/bjx_hip.h
+__device__ __forceinline__ Key chain_key(Key key, uint64_t gidx, int64_t step_fold) {
+  Key kc = key_child(key, gidx);
+  if (step_fold >= 0) kc = key_child(kc, (uint64_t)step_fold);
+  return kc;
+}
+
 // random_bits(key, 32, shape)[i]
 __device__ __forceinline__ uint32_t key_bits32(Key key, uint64_t i) {
   Key o = threefry2x32(key, (uint32_t)(i >> 32), (uint32_t)i);

@@ -39,11 +39,11 @@ __global__ void __launch_bounds__(kBlock) k_rng_uniform(Key key, int64_t off, in
 // p0 = (1/sqrt(imm)) * normal(km, (D,)) ; ke0 = 0.5 * sum (imm*p0)*p0   (fp64 accumulate)
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_momentum_diag(Key key, int64_t off, int64_t N, int64_t D, const float* __restrict__ imm,
+k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
                 int64_t imm_stride, float* __restrict__ p_out, float* __restrict__ ke_out) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
-    const Key kc = key_child(key, (uint64_t)(r + off));
+    const Key kc = chain_key(key, (uint64_t)(r + off), fold);
     const Key km = key_child(kc, 0);  // split(kc, 2)[0]
     const float* im = imm + r * imm_stride;
     float* pr = p_out + r * D;
@@ -119,7 +119,7 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
 // ------------------------------------------------------------------------------ finish
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_hmc_finish_diag(Key key, int64_t off, int64_t N, int64_t D, float eps_s,
+k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, float eps_s,
                   const float* __restrict__ eps_pc, const float* __restrict__ imm,
                   int64_t imm_stride, float thr, const float* __restrict__ q0,
                   const float* __restrict__ logp0, const float* __restrict__ g0,
@@ -165,7 +165,7 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t N, int64_t D, float eps_s,
     if (delta != delta) delta = -__builtin_inff();  // proposal.py:45-48
     const bool is_div = (-delta) > thr;              // hmc.py:162
     const float p_acc = fminf(exp_cr(delta), 1.0f);  // proposal.py:225
-    const Key kc = key_child(key, (uint64_t)(r + off));
+    const Key kc = chain_key(key, (uint64_t)(r + off), fold);
     const Key ki = key_child(kc, 1);                  // split(kc, 2)[1]
     const float u = key_uniform(ki);
     const bool accept = u < p_acc;                    // proposal.py:226
@@ -217,7 +217,7 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
 }
 
 int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                          int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                          int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
                           float* p_out, float* ke_out) {
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && p_out && ke_out, "bjx_hmc_momentum_diag: bad arguments");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_momentum_diag: imm_stride must be 0 or D");
@@ -225,11 +225,11 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
   if (bjx_vec4_ok(D, imm, p_out))
-    hipLaunchKernelGGL(k_momentum_diag<4>, grid, block, 0, (hipStream_t)stream, key, chain_offset, N,
-                       D, imm, imm_stride, p_out, ke_out);
+    hipLaunchKernelGGL(k_momentum_diag<4>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out);
   else
-    hipLaunchKernelGGL(k_momentum_diag<1>, grid, block, 0, (hipStream_t)stream, key, chain_offset, N,
-                       D, imm, imm_stride, p_out, ke_out);
+    hipLaunchKernelGGL(k_momentum_diag<1>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out);
   return bjx_check_launch("bjx_hmc_momentum_diag");
 }
 
@@ -257,7 +257,7 @@ int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps
 }
 
 int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                        int64_t N, int64_t D, float eps, const float* eps_per_chain,
+                        int64_t step_fold, int64_t N, int64_t D, float eps, const float* eps_per_chain,
                         const float* imm, int64_t imm_stride, float divergence_threshold,
                         const float* q0, const float* logp0, const float* g0, const float* ke0,
                         const float* q1, const float* logp1, const float* g1, const float* p,
@@ -274,7 +274,8 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
   const Key key{key0, key1};
   hipStream_t s = (hipStream_t)stream;
 #define BJX_FIN(V)                                                                              \
-  hipLaunchKernelGGL(k_hmc_finish_diag<V>, grid, block, 0, s, key, chain_offset, N, D, eps,     \
+  hipLaunchKernelGGL(k_hmc_finish_diag<V>, grid, block, 0, s, key, chain_offset, step_fold, N, D, \
+                     eps,                                                                       \
                      eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0,  \
                      q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out, acceptance_rate_out,  \
                      is_accepted_out, is_divergent_out, energy_out)

@@ -19,7 +19,7 @@ import torch
 from . import _lib, integrators, metrics
 from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
 from .base import SamplingAlgorithm
-from .random import key_words
+from .random import key_spec
 
 __all__ = ["HMCState", "HMCInfo", "IntegratorState", "init", "build_kernel", "as_top_level_api"]
 
@@ -108,7 +108,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         L = int(num_integration_steps)
         if L < 0:
             raise ValueError("num_integration_steps must be >= 0")
-        k0, k1 = key_words(rng_key)
+        k0, k1, fold = key_spec(rng_key)
         vg = value_and_grad(logdensity_fn)
         metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
         eps, eps_pc = step_size_args(step_size, N, q0.device)
@@ -144,12 +144,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             eb = None if eps_pc is None else eps_pc[sl]
             boff = off + s
             if m.kind == "diag":
-                _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, n, D, m.imm.data_ptr(),
+                _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
                           m.imm_stride, p0[sl].data_ptr(), ke0[sl].data_ptr())
             else:
                 from . import dense
 
-                dense.momentum(stream, m, k0, k1, boff, n, D, p0[sl], ke0[sl])
+                dense.momentum(stream, m, k0, k1, boff, fold, n, D, p0[sl], ke0[sl])
 
             if L == 0:
                 q, p, logp, g = q0[sl], p0[sl], logp0[sl], g0[sl]
@@ -164,7 +164,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 eps_fin, eps_pc_fin = eps, eb
 
             if m.kind == "diag":
-                _lib.call("bjx_hmc_finish_diag", stream, k0, k1, boff, n, D, eps_fin,
+                _lib.call("bjx_hmc_finish_diag", stream, k0, k1, boff, fold, n, D, eps_fin,
                           _lib.ptr(eps_pc_fin), m.imm.data_ptr(), m.imm_stride, thr,
                           q0[sl].data_ptr(), logp0[sl].data_ptr(), g0[sl].data_ptr(),
                           ke0[sl].data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(),
@@ -174,7 +174,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             else:
                 from . import dense
 
-                dense.finish(stream, m, k0, k1, boff, n, D, eps_fin, eps_pc_fin, thr, q0[sl],
+                dense.finish(stream, m, k0, k1, boff, fold, n, D, eps_fin, eps_pc_fin, thr, q0[sl],
                              logp0[sl], g0[sl], ke0[sl], q, logp, g, p, p_end[sl], q_new[sl],
                              logp_new[sl], g_new[sl], acc_rate[sl], is_acc[sl], is_div[sl],
                              energy[sl])

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["key", "PRNGKey", "split", "fold_in", "key_words"]
+__all__ = ["key", "PRNGKey", "split", "fold_in", "key_words", "ChainMajorKey", "key_spec"]
 
 
 def key(seed: int) -> np.ndarray:
@@ -52,3 +52,25 @@ def split(rng_key, num: int = 2, offset: int = 0) -> np.ndarray:
 def fold_in(rng_key, data: int) -> np.ndarray:
     """jax.random.fold_in(key, data) == split(key, .)[data] for threefry-partitionable keys."""
     return split(rng_key, 1, offset=int(data) & 0xFFFFFFFF)[0]
+
+
+class ChainMajorKey:
+    """Step ``t`` of a chain-major run: chain ``i`` uses
+    ``split(split(run_key, N)[i], T)[t]`` -- the key layout of a vmapped per-chain loop such
+    as ``jax.vmap(window_adaptation(...).run)(jax.random.split(key, N), positions)``.
+    Accepted wherever a kernel takes ``rng_key``."""
+
+    __slots__ = ("run_key", "step")
+
+    def __init__(self, run_key, step: int):
+        self.run_key = run_key
+        self.step = int(step)
+
+
+def key_spec(rng_key) -> tuple[int, int, int]:
+    """-> (key word 0, key word 1, step_fold) with step_fold = -1 for a plain (step-major) key."""
+    if isinstance(rng_key, ChainMajorKey):
+        k0, k1 = key_words(rng_key.run_key)
+        return k0, k1, rng_key.step
+    k0, k1 = key_words(rng_key)
+    return k0, k1, -1

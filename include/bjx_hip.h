@@ -16,8 +16,13 @@
  *     passed as void*), re-entrant, no global mutable state.
  *   - chain-major row layout: an (N, D) array is N rows of D contiguous fp32.
  *   - `key` arguments are threefry keys passed BY VALUE as two uint32 words
- *     (jax.random key data); per-chain keys are derived in-kernel as
- *     split(key, N_total)[chain_offset + i] so sharded runs need no exchange.
+ *     (jax.random key data); per-chain keys are derived in-kernel so sharded runs need
+ *     no exchange.  Two layouts, selected by `step_fold`:
+ *       step_fold <  0  "step-major":  k_i = split(key, .)[chain_offset+i]
+ *                       (key = this step's key; vmap inside the step)
+ *       step_fold >= 0  "chain-major": k_i = split(split(key, .)[chain_offset+i], .)[step_fold]
+ *                       (key = the run key, step_fold = t; vmap over whole per-chain loops,
+ *                       e.g. a vmapped window_adaptation(...).run)
  *   - `eps` (step size): if `eps_per_chain` != NULL it is a device (N,) array,
  *     otherwise the scalar `eps` is used for every chain.
  *   - `imm` (diagonal inverse mass matrix): row stride `imm_stride` = 0 for one
@@ -56,7 +61,7 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
  *   p0[i] = (1/sqrt(imm)) * normal(km, (D,)) ;  ke0[i] = 0.5 * dot(imm*p0[i], p0[i])
  * Replaces: blackjax/mcmc/hmc.py:299,302 ; metrics.py:260-261,263-270,704-709 ; util.py:66-91. */
 int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                          int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                          int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
                           float* p_out, float* ke_out);
 
 /* Fused velocity-Verlet "kick(s) + drift" for a diagonal metric:
@@ -83,13 +88,53 @@ int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps
  * Replaces: blackjax/mcmc/hmc.py:95-112,153-176 ; trajectory.py:730-750 ;
  * proposal.py:45-48,214-235. */
 int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                        int64_t N, int64_t D, float eps, const float* eps_per_chain,
+                        int64_t step_fold, int64_t N, int64_t D, float eps, const float* eps_per_chain,
                         const float* imm, int64_t imm_stride, float divergence_threshold,
                         const float* q0, const float* logp0, const float* g0, const float* ke0,
                         const float* q1, const float* logp1, const float* g1, const float* p,
                         float* p_end_out, float* q_out, float* logp_out, float* g_out,
                         float* acceptance_rate_out, uint8_t* is_accepted_out,
                         uint8_t* is_divergent_out, float* energy_out);
+
+/* ---- window adaptation (per-chain state; every array is (N,) unless noted) ------------------
+ *
+ * Dual averaging init (from_log_avg = 0: x = x_in) or window-end re-init (from_log_avg = 1:
+ * x = exp(x_in) with x_in = log_step_size_avg):
+ *   mu = log(10 x) ; log_x = log(x) ; log_x_avg = 0 ; avg_error = 0 ; step_size = exp(log_x)
+ * Replaces: blackjax/optimizers/dual_averaging.py:87-99 ; adaptation/staged_adaptation.py:242-243. */
+int bjx_da_init(void* stream, int64_t N, int from_log_avg, const float* x_in, float* log_x_out,
+                float* log_x_avg_out, float* avg_error_out, float* mu_out, float* step_size_out);
+
+/* One dual-averaging update with gradient = target - acceptance_rate (`step` >= 1 is the
+ * reference's DualAveragingState.step, identical for all chains); outputs may alias inputs.
+ *   reg = step + t0 ; eta = step^-kappa ; avg_error = (1 - 1/reg) avg_error + g/reg
+ *   log_x = mu - (sqrt(step)/gamma) avg_error ; log_x_avg = eta log_x_prev + (1-eta) log_x_avg
+ *   step_size = exp(log_x)
+ * Replaces: dual_averaging.py:101-123 ; adaptation/step_size.py:129-145 ;
+ * staged_adaptation.py:186-198. */
+int bjx_da_update(void* stream, int64_t N, int64_t step, float target, float t0, float gamma,
+                  float kappa, const float* acceptance_rate, const float* log_x_in,
+                  const float* log_x_avg_in, const float* avg_error_in, const float* mu,
+                  float* log_x_out, float* log_x_avg_out, float* avg_error_out,
+                  float* step_size_out);
+
+/* y = exp(x) element-wise, fp64 rounded once (final step size exp(log_step_size_avg),
+ * staged_adaptation.py:301-305). */
+int bjx_exp(void* stream, int64_t N, const float* x, float* y);
+
+/* Welford accumulation of one new sample per chain, diagonal: value/mean/m2 are (N, D);
+ * sample_size_new is the count AFTER adding this sample.  Outputs may alias inputs.
+ * Replaces: blackjax/adaptation/mass_matrix.py:288-291,410-435. */
+int bjx_welford_update_diag(void* stream, int64_t N, int64_t D, int64_t sample_size_new,
+                            const float* value, const float* mean_in, const float* m2_in,
+                            float* mean_out, float* m2_out);
+
+/* Window end: imm = (n/(n+5+k)) m2/(n-1) + (k/(n+5+k)) imm_prev + (5/(n+5+k)) 1e-3, k =
+ * imm_shrinkage_to_previous.  imm_prev is (D,) [stride 0] or (N, D) [stride D]; imm_out (N, D).
+ * Replaces: mass_matrix.py:335-357,437-442. */
+int bjx_welford_final_diag(void* stream, int64_t N, int64_t D, int64_t sample_size,
+                           float imm_shrinkage_to_previous, const float* m2, const float* imm_prev,
+                           int64_t imm_prev_stride, float* imm_out);
 
 /* Built-in synthetic targets (value + gradient in one pass, fp64-accumulated logp) used
  * as the "user callable" by the bench and parity tests.

@@ -62,7 +62,7 @@ class Metric(NamedTuple):
     is_dense: bool
 
 
-def default_metric(inverse_mass_matrix, n_chains=None) -> Metric:
+def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False) -> Metric:
     """metrics.py:180-218 -> gaussian_euclidean 221-346 -> _format_covariance 701-729.
 
     diag: ``inv_cov_sqrt = sqrt(imm)``, ``mass_matrix_sqrt = 1/inv_cov_sqrt``
@@ -73,8 +73,9 @@ def default_metric(inverse_mass_matrix, n_chains=None) -> Metric:
     once to fp32.
     """
     imm = np.asarray(inverse_mass_matrix, dtype=f32)
-    if imm.ndim == 1 or (imm.ndim == 2 and n_chains is not None and imm.shape[0] == n_chains
-                         and imm.shape[0] != imm.shape[1]):
+    if imm.ndim == 1 or (imm.ndim == 2 and per_chain_diag) or (
+            imm.ndim == 2 and n_chains is not None and imm.shape[0] == n_chains
+            and imm.shape[0] != imm.shape[1]):
         inv_sqrt = np.sqrt(imm)
         return Metric(imm, (f32(1.0) / inv_sqrt).astype(f32), False)
     if imm.ndim == 2 and imm.shape[0] == imm.shape[1]:
@@ -152,10 +153,10 @@ def chain_keys(rng_key, n, chain_offset=0):
 
 def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
            num_integration_steps: int, divergence_threshold: float = 1000.0,
-           chain_offset: int = 0, chain_keys_override=None):
+           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False):
     """hmc.py:279-312 with hmc_proposal.generate 153-176, batched over chains."""
     N, D = state.position.shape
-    metric = default_metric(inverse_mass_matrix, n_chains=N)
+    metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
     keys = chain_keys(rng_key, N, chain_offset) if chain_keys_override is None else chain_keys_override
     kk = prng.split(keys, 2)  # hmc.py:299
     key_momentum, key_integrator = kk[:, 0], kk[:, 1]

@@ -1,0 +1,112 @@
+"""GPU parity of window_adaptation (dual averaging + Welford + window-end blend) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import blackjax_amd as bjx
+from blackjax_amd import _lib
+from blackjax_amd import adaptation as bad
+from oracle import adaptation as oad
+from oracle import prng, targets as otargets
+
+pytestmark = pytest.mark.gpu
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def dev_t(a, dev):
+    return torch.as_tensor(np.asarray(a), device=dev)
+
+
+def test_da_and_welford_kernels_bit_exact(dev):
+    N, D = 37, 100
+    rng = np.random.default_rng(0)
+    # dual averaging
+    st_o = oad.da_init(np.full(N, 0.7, np.float32))
+    ss, eps = bad._da_init(torch.full((N,), 0.7, device=dev), from_log_avg=False)
+    assert np.array_equal(t2n(ss.mu), st_o.mu) and np.array_equal(t2n(ss.log_step_size), st_o.log_step_size)
+    for t in range(30):
+        acc = rng.uniform(0, 1, N).astype(np.float32)
+        st_o = oad.da_update(st_o, np.float32(0.8) - acc)
+        ss, eps = bad._da_update(ss, dev_t(acc, dev), 0.8)
+        assert np.array_equal(t2n(ss.log_step_size), st_o.log_step_size)
+        assert np.array_equal(t2n(ss.log_step_size_avg), st_o.log_step_size_avg)
+        assert np.array_equal(t2n(ss.avg_error), st_o.avg_error)
+        assert ss.step == st_o.step
+        assert np.array_equal(t2n(eps), np.exp(st_o.log_step_size.astype(np.float64)).astype(np.float32))
+    # re-init at a window end
+    ss2, eps2 = bad._da_init(ss.log_step_size_avg, from_log_avg=True)
+    st2 = oad.da_init(oad.da_final(st_o))
+    assert np.array_equal(t2n(ss2.mu), st2.mu) and np.array_equal(t2n(ss2.log_step_size), st2.log_step_size)
+    # welford + window end
+    wc_o = oad.welford_init(N, D)
+    wc = bad.WelfordAlgorithmState(torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev), 0)
+    for t in range(25):
+        x = (rng.standard_normal((N, D)) * 3 + 1).astype(np.float32)
+        wc_o = oad.welford_update(wc_o, x)
+        wc = bad._welford_update(wc, dev_t(x, dev))
+    assert np.array_equal(t2n(wc.mean), wc_o.mean) and np.array_equal(t2n(wc.m2), wc_o.m2)
+    prev = rng.uniform(0.5, 2, (N, D)).astype(np.float32)
+    for shrink in (0.0, 3.0):
+        mm_o = oad.mm_final(oad.MassMatrixState(prev, wc_o), True, shrink)
+        mm = bad._mm_final(bad.MassMatrixAdaptationState(dev_t(prev, dev), wc), shrink)
+        assert np.array_equal(t2n(mm.inverse_mass_matrix), mm_o.inverse_mass_matrix)
+        assert mm.wc_state.sample_size == 0 and float(mm.wc_state.m2.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,D,num_steps", [(24, 64, 120), (5, 5, 40), (16, 33, 19)])
+def test_window_adaptation_matches_oracle(dev, N, D, num_steps):
+    """Full warmup (scaled-down configs[3]): ill-conditioned diagonal Gaussian, per-chain adaptation.
+    N == D exercises the per-chain-diagonal vs dense disambiguation."""
+    L = 6
+    sig = (10.0 ** (-1.0 + 2.0 * np.arange(D) / max(D - 1, 1))).astype(np.float32)
+    inv_var = (np.float32(1) / (sig * sig)).astype(np.float32)
+    q0 = (prng.normal(prng.key(3), (N, D)) * sig).astype(np.float32)
+    st_o, par_o, hist_o = oad.window_adaptation_run(prng.key(19), q0, otargets.diag_gaussian(inv_var),
+                                                    num_steps, L, chain_offset=7)
+    warm = bjx.window_adaptation(bjx.hmc, bjx.targets.DiagGaussian(dev_t(inv_var, dev)),
+                                 num_integration_steps=L)
+    (st_g, par_g), info = warm.run(prng.key(19), dev_t(q0, dev), num_steps, chain_offset=7)
+    # per-step acceptance rates and step sizes follow the oracle exactly
+    acc_g = t2n(info.info.acceptance_rate)
+    eps_g = t2n(info.adaptation_state.step_size)
+    for t in range(num_steps):
+        np.testing.assert_allclose(acc_g[t], hist_o[t][0], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(eps_g[t], hist_o[t][1], rtol=1e-6)
+    np.testing.assert_allclose(t2n(par_g["step_size"]), par_o["step_size"], rtol=1e-6)
+    np.testing.assert_allclose(t2n(par_g["inverse_mass_matrix"]),
+                               np.broadcast_to(par_o["inverse_mass_matrix"], (N, D)), rtol=1e-6)
+    np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=1e-6, atol=1e-6)
+    assert par_g["num_integration_steps"] == L
+    assert info.state.position.shape == (num_steps, N, D)
+
+
+def test_window_adaptation_then_sampling_statistics(dev):
+    """reference tests/mcmc/test_sampling.py:317-379 flavour: warm up, then sample with the adapted
+    per-chain parameters; pooled moments match the target."""
+    N, D, L = 512, 16, 10
+    sig = (10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32)
+    fn = bjx.targets.DiagGaussian(dev_t(1 / (sig * sig), dev))
+    warm = bjx.window_adaptation(bjx.hmc, fn, num_integration_steps=L, adaptation_info_fn=None)
+    (state, params), _ = warm.run(bjx.random.key(1), torch.randn(N, D, device=dev), 300)
+    ratio = t2n(params["inverse_mass_matrix"]) / (sig * sig)
+    assert np.median(ratio) > 0.5 and np.median(ratio) < 2.0
+    alg = bjx.hmc(fn, params["step_size"], params["inverse_mass_matrix"], L)
+    draws, accs = [], []
+    for k in bjx.random.split(bjx.random.key(2), 40):
+        state, info = alg.step(k, state)
+        draws.append(state.position)
+        accs.append(info.acceptance_rate.mean().item())
+    x = torch.stack(draws[10:]).reshape(-1, D)
+    np.testing.assert_allclose(t2n(x.var(0)), sig * sig, rtol=0.15)
+    assert abs(float(x.mean())) < 0.2
+    assert 0.6 < np.mean(accs) < 0.97
+
+
+def test_window_adaptation_validation():
+    with pytest.raises(ValueError):
+        bjx.window_adaptation(bjx.hmc, lambda q: q, initial_inverse_mass_matrix=np.eye(3))
+    with pytest.raises(ValueError):
+        bjx.window_adaptation(bjx.hmc, lambda q: q, imm_shrinkage_to_previous=-1.0)

@@ -57,7 +57,7 @@ def test_momentum_diag(dev, N, D, per_chain_imm):
     p = torch.empty(N, D, device=dev)
     ke = torch.empty(N, device=dev)
     immt = dev_t(imm, dev)
-    _lib.call("bjx_hmc_momentum_diag", _lib.current_stream(), int(key[0]), int(key[1]), 11, N, D,
+    _lib.call("bjx_hmc_momentum_diag", _lib.current_stream(), int(key[0]), int(key[1]), 11, -1, N, D,
               immt.data_ptr(), D if per_chain_imm else 0, p.data_ptr(), ke.data_ptr())
     metric = ohmc.default_metric(imm, n_chains=N)
     kk = prng.split(prng.split(key, N, offset=11), 2)
