@@ -8,7 +8,7 @@ kernels (``libbjxhip.so``, C ABI in ``include/bjx_hip.h``).  There is no CPU fal
 from __future__ import annotations
 
 from . import hmc as _hmc
-from . import adaptation, integrators, metrics, random, targets
+from . import adaptation, diagnostics, distributed, integrators, metrics, random, targets, util
 from .adaptation import window_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
 
@@ -29,4 +29,4 @@ class GenerateSamplingAPI:
 
 hmc = GenerateSamplingAPI(_hmc.as_top_level_api, _hmc.init, _hmc.build_kernel)
 
-__all__ = ["hmc", "window_adaptation", "adaptation", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
+__all__ = ["hmc", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
