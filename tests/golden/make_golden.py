@@ -54,6 +54,14 @@ kats = {
         "momentum_ckpts": [1.0, 2.0, 3.0, -2.0], "momentum_sum_ckpts": [2.0, 4.0, 4.0, -1.0],
         "cases": [[[3, 2], False], [[3, 3], True], [[0, 0], False], [[0, 1], True], [[1, 3], True]],
     },
+    # tests/mcmc/test_trajectory.py:193-260 -- 1-d standard normal, position 0, momentum =
+    # normal(key(0), (1,)), expansion key = key(0), imm = [1.], divergence_threshold = 1000:
+    # (step_size, should_diverge, should_turn, expected_doublings)
+    "dynamic_expansion": {
+        "source": "tests/mcmc/test_trajectory.py:193-260",
+        "key_seed": 0, "max_doublings": 10, "divergence_threshold": 1000,
+        "cases": [[1e-10, False, False, 10], [1.0, False, True, 2], [100000.0, True, True, 1]],
+    },
     # tests/adaptation/test_adaptation.py:27-49 -- run-length encoded (stage, is_window_end, count)
     "build_schedule": {
         "source": "tests/adaptation/test_adaptation.py:27-49",
