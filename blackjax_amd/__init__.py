@@ -8,6 +8,7 @@ kernels (``libbjxhip.so``, C ABI in ``include/bjx_hip.h``).  There is no CPU fal
 from __future__ import annotations
 
 from . import hmc as _hmc
+from . import nuts as _nuts
 from . import adaptation, diagnostics, distributed, integrators, metrics, random, targets, util
 from .adaptation import window_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
@@ -28,5 +29,6 @@ class GenerateSamplingAPI:
 
 
 hmc = GenerateSamplingAPI(_hmc.as_top_level_api, _hmc.init, _hmc.build_kernel)
+nuts = GenerateSamplingAPI(_nuts.as_top_level_api, _nuts.init, _nuts.build_kernel)
 
-__all__ = ["hmc", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
+__all__ = ["hmc", "nuts", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]

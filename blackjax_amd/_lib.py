@@ -43,6 +43,42 @@ SIGNATURES = {
                                 _f32p, _f32p],
 }
 
+
+
+class NutsDesc(ctypes.Structure):
+    """ctypes mirror of ``bjx_nuts_t`` (include/bjx_nuts.h)."""
+
+    _fields_ = [
+        ("N", c_int64), ("D", c_int64), ("max_depth", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("imm", c_void_p), ("imm_stride", c_int64), ("eps_per_chain", c_void_p),
+        ("eps", c_float), ("divergence_threshold", c_float),
+        ("key0", c_uint32), ("key1", c_uint32), ("chain_offset", c_int64), ("step_fold", c_int64),
+        ("q0", c_void_p), ("g0", c_void_p), ("p0", c_void_p),
+        ("Lq", c_void_p), ("Lp", c_void_p), ("Lg", c_void_p),
+        ("Rq", c_void_p), ("Rp", c_void_p), ("Rg", c_void_p),
+        ("msum", c_void_p), ("Smsum", c_void_p),
+        ("Pq", c_void_p), ("Pg", c_void_p), ("Sq", c_void_p), ("Sg", c_void_p),
+        ("ckpt_r", c_void_p), ("ckpt_rs", c_void_p),
+        ("fs", c_void_p), ("is_", c_void_p),
+    ]
+
+
+# slot indices of the fs / is tables (include/bjx_nuts.h enums; checked by tests/test_abi.py)
+NUTS_F = {"H0": 0, "LLOGP": 1, "RLOGP": 2, "PLOGP": 3, "PENERGY": 4, "PW": 5, "PSLPA": 6,
+          "SLOGP": 7, "SENERGY": 8, "SW": 9, "SSLPA": 10, "ACC": 11}
+NUTS_NF = 12
+NUTS_I = {"ACTIVE": 0, "SUB_ACTIVE": 1, "DIR": 2, "NSTATES": 3, "SUBN": 4, "SDIV": 5, "STURN": 6,
+          "DIV": 7, "TURN": 8, "DEPTH": 9}
+NUTS_NI = 10
+
+SIGNATURES.update({
+    "bjx_nuts_init": [c_void_p, POINTER(NutsDesc), _f32p, _f32p],
+    "bjx_nuts_pre": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p],
+    "bjx_nuts_post": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p,
+                      _f32p, _f32p],
+    "bjx_nuts_merge": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p],
+})
+
 _lib = None
 
 

@@ -1,0 +1,372 @@
+// NUTS kernels (gfx950): lockstep iterative tree doubling for N chains, diagonal metric.
+// C ABI and the algorithm map are in include/bjx_nuts.h.
+//
+// One wavefront per chain row.  Per-chain control state lives in the fs / is slot tables so that
+// every decision (direction, progressive sampling, divergence, U-turn) is wave-uniform.
+// Numerics contract as in bjx_device.h: explicit fmaf, fp64-accumulated reductions, fp64 scalar
+// transcendentals rounded once.
+#include "../../include/bjx_hip.h"
+#include "bjx_device.h"
+#include "bjx_host.h"
+
+using namespace bjx;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
+
+__device__ __forceinline__ int64_t wave_row0() {
+  return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+}
+__device__ __forceinline__ int64_t wave_row_stride() { return (int64_t)gridDim.x * kWavesPerBlock; }
+
+#define FS(slot, c) nt.fs[(int64_t)(slot)*nt.N + (c)]
+#define IS(slot, c) nt.is[(int64_t)(slot)*nt.N + (c)]
+
+// np.logaddexp / jnp.logaddexp in fp64, rounded once
+__device__ __forceinline__ float logaddexp_cr(float a, float b) {
+  const double x = (double)a, y = (double)b;
+  double r;
+  if (x == y) {
+    r = x + 0.6931471805599453;
+  } else {
+    const double t = x - y;
+    if (t > 0) r = x + log1p(exp(-t));
+    else if (t <= 0) r = y + log1p(exp(t));
+    else r = t;  // NaN
+  }
+  return (float)r;
+}
+
+// jax.scipy.special.expit in fp64, rounded once
+__device__ __forceinline__ float expit_cr(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+
+// jnp.minimum(x, 1): NaN propagates
+__device__ __forceinline__ float min1_nan(float x) { return (x < 1.0f || x != x) ? x : 1.0f; }
+
+__device__ __forceinline__ Key integrator_key(const bjx_nuts_t& nt, int64_t c) {
+  const Key kc = chain_key(Key{nt.key0, nt.key1}, (uint64_t)(c + nt.chain_offset), nt.step_fold);
+  return key_child(kc, 1);  // split(kc, 2)[1]   (nuts.py:133)
+}
+
+__device__ __forceinline__ float chain_eps(const bjx_nuts_t& nt, int64_t c) {
+  return nt.eps_per_chain ? nt.eps_per_chain[c] : nt.eps;
+}
+
+// ------------------------------------------------------------------------------------ init
+__global__ void __launch_bounds__(kBlock)
+k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restrict__ ke0) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) {
+    const int64_t base = c * nt.D;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float q = nt.q0[base + j], p = nt.p0[base + j], g = nt.g0[base + j];
+      nt.Lq[base + j] = q; nt.Rq[base + j] = q; nt.Pq[base + j] = q;
+      nt.Lp[base + j] = p; nt.Rp[base + j] = p; nt.msum[base + j] = p;
+      nt.Lg[base + j] = g; nt.Rg[base + j] = g; nt.Pg[base + j] = g;
+    }
+    if (lane == 0) {
+      const float lp = logp0[c];
+      const float H0 = -lp + ke0[c];
+      FS(BJX_NUTS_F_H0, c) = H0;
+      FS(BJX_NUTS_F_LLOGP, c) = lp;
+      FS(BJX_NUTS_F_RLOGP, c) = lp;
+      FS(BJX_NUTS_F_PLOGP, c) = lp;
+      FS(BJX_NUTS_F_PENERGY, c) = H0;
+      FS(BJX_NUTS_F_PW, c) = 0.0f;
+      FS(BJX_NUTS_F_PSLPA, c) = -__builtin_inff();
+      FS(BJX_NUTS_F_SLOGP, c) = lp;
+      FS(BJX_NUTS_F_SENERGY, c) = H0;
+      FS(BJX_NUTS_F_SW, c) = 0.0f;
+      FS(BJX_NUTS_F_SSLPA, c) = -__builtin_inff();
+      FS(BJX_NUTS_F_ACC, c) = __builtin_nanf("");
+      IS(BJX_NUTS_I_ACTIVE, c) = nt.max_depth > 0 ? 1 : 0;
+      IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+      IS(BJX_NUTS_I_DIR, c) = 1;
+      IS(BJX_NUTS_I_NSTATES, c) = 0;
+      IS(BJX_NUTS_I_SUBN, c) = 0;
+      IS(BJX_NUTS_I_SDIV, c) = 0;
+      IS(BJX_NUTS_I_STURN, c) = 0;
+      IS(BJX_NUTS_I_DIV, c) = 0;
+      IS(BJX_NUTS_I_TURN, c) = 0;
+      IS(BJX_NUTS_I_DEPTH, c) = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ pre
+__global__ void __launch_bounds__(kBlock)
+k_nuts_pre(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32_t* __restrict__ idx,
+           float* __restrict__ qf) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
+    int dir;
+    if (s == 0) {
+      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);  // trajectory.py:645
+      const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
+      dir = key_uniform(kd) < 0.5f ? 1 : -1;                                  // trajectory.py:650
+      if (lane == 0) {
+        IS(BJX_NUTS_I_DIR, c) = dir;
+        IS(BJX_NUTS_I_SUB_ACTIVE, c) = 1;
+        IS(BJX_NUTS_I_SDIV, c) = 0;
+        IS(BJX_NUTS_I_STURN, c) = 0;
+        IS(BJX_NUTS_I_SUBN, c) = 0;
+      }
+    } else {
+      if (!IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+      dir = IS(BJX_NUTS_I_DIR, c);
+    }
+    const float deps = (float)dir * chain_eps(nt, c);  // direction * step_size (trajectory.py:323)
+    const float h = deps * 0.5f;
+    const int64_t base = c * nt.D;
+    float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+    float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+    const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+    const float* im = nt.imm + c * nt.imm_stride;
+    float* qo = qf + b * nt.D;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float pn = fmaf(h, fg[j], fp[j]);
+      const float qn = fmaf(deps, im[j] * pn, fq[j]);
+      fp[j] = pn;
+      fq[j] = qn;
+      qo[j] = qn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ post
+__global__ void __launch_bounds__(kBlock)
+k_nuts_post(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32_t* __restrict__ idx,
+            const float* __restrict__ qf, const float* __restrict__ logp_f,
+            const float* __restrict__ gf) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+    const int dir = IS(BJX_NUTS_I_DIR, c);
+    const float deps = (float)dir * chain_eps(nt, c);
+    const float h = deps * 0.5f;
+    const int64_t base = c * nt.D;
+    float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+    float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+    const float* im = nt.imm + c * nt.imm_stride;
+    const float* gn = gf + b * nt.D;
+    const float* qn = qf + b * nt.D;
+
+    // pass 1: closing half kick, store the new end state, kinetic energy
+    double acc = 0.0;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float g = gn[j];
+      const float p = fmaf(h, g, fp[j]);
+      fp[j] = p;
+      fg[j] = g;
+      acc += (double)(im[j] * p) * (double)p;
+    }
+    acc = wave_sum(acc);
+    const float ke = 0.5f * (float)acc;
+    const float lp = logp_f[b];
+    const float e_new = -lp + ke;                       // hmc_energy (trajectory.py:745-748)
+    float w = FS(BJX_NUTS_F_H0, c) - e_new;             // proposal.py:91-95
+    if (w != w) w = -__builtin_inff();
+    const float slpa_new = fminf(w, 0.0f);
+    const bool sdiv = (-w) > nt.divergence_threshold;   // trajectory.py:325
+
+    // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
+    bool take;
+    float Wn, Sn;
+    if (s == 0) {
+      take = true;
+      Wn = w;
+      Sn = slpa_new;
+    } else {
+      const float sw = FS(BJX_NUTS_F_SW, c);
+      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);
+      const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
+      const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
+      const float pa = expit_cr(w - sw);
+      take = u < pa;
+      Wn = logaddexp_cr(sw, w);
+      Sn = logaddexp_cr(FS(BJX_NUTS_F_SSLPA, c), slpa_new);
+    }
+    // checkpoint indices (termination.py:75-84)
+    const uint32_t us = (uint32_t)s;
+    const int idx_max = __popc(us >> 1);
+    const int nsub = __popc((~us & (us + 1u)) - 1u);
+    const int idx_min = idx_max - nsub + 1;
+    const bool even = (us & 1u) == 0u;
+
+    // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
+    float* sm = nt.Smsum + base;
+    float* ckr = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+    float* ckrs = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
+    float* sq = nt.Sq + base;
+    float* sg = nt.Sg + base;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float p = fp[j];
+      const float m = (s == 0) ? p : sm[j] + p;  // append_to_trajectory (trajectory.py:62-67)
+      sm[j] = m;
+      if (even) {
+        ckr[j] = p;
+        ckrs[j] = m;
+      }
+      if (take) {
+        sq[j] = qn[j];
+        sg[j] = gn[j];
+      }
+    }
+
+    // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104)
+    bool turning = false;
+    for (int i = idx_max; i >= idx_min && !turning; --i) {
+      const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
+      const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
+      double a_left = 0.0, a_right = 0.0;
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float p = fp[j], rl = r_ck[j];
+        const float ssum = (sm[j] - rs_ck[j]) + rl;
+        const float rho = ssum - (p + rl) * 0.5f;      // metrics.py:300
+        a_left += (double)(im[j] * rl) * (double)rho;
+        a_right += (double)(im[j] * p) * (double)rho;
+      }
+      a_left = wave_sum(a_left);
+      a_right = wave_sum(a_right);
+      turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+    }
+
+    if (lane == 0) {
+      FS(dir > 0 ? BJX_NUTS_F_RLOGP : BJX_NUTS_F_LLOGP, c) = lp;
+      FS(BJX_NUTS_F_SW, c) = Wn;
+      FS(BJX_NUTS_F_SSLPA, c) = Sn;
+      if (take) {
+        FS(BJX_NUTS_F_SLOGP, c) = lp;
+        FS(BJX_NUTS_F_SENERGY, c) = e_new;
+      }
+      IS(BJX_NUTS_I_SUBN, c) = s + 1;
+      IS(BJX_NUTS_I_SDIV, c) = sdiv ? 1 : 0;
+      IS(BJX_NUTS_I_STURN, c) = turning ? 1 : 0;
+      if (sdiv || turning) IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ merge
+__global__ void __launch_bounds__(kBlock)
+k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
+    const bool sdiv = IS(BJX_NUTS_I_SDIV, c) != 0, sturn = IS(BJX_NUTS_I_STURN, c) != 0;
+    const int64_t base = c * nt.D;
+    const float pw = FS(BJX_NUTS_F_PW, c), sw = FS(BJX_NUTS_F_SW, c);
+    const float pslpa = FS(BJX_NUTS_F_PSLPA, c), sslpa = FS(BJX_NUTS_F_SSLPA, c);
+    bool take = false;
+    float new_pw = pw;
+    const float new_pslpa = logaddexp_cr(pslpa, sslpa);
+    if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
+      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);
+      const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
+      const float pa = min1_nan(exp_cr(sw - pw));
+      take = key_uniform(kp) < pa;
+      new_pw = logaddexp_cr(pw, sw);
+    }
+    // merged trajectory: momentum sum + U-turn of the whole trajectory (trajectory.py:696-710)
+    const float* im = nt.imm + c * nt.imm_stride;
+    double a_left = 0.0, a_right = 0.0;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float m = nt.msum[base + j] + nt.Smsum[base + j];
+      nt.msum[base + j] = m;
+      const float pl = nt.Lp[base + j], pr = nt.Rp[base + j];
+      const float rho = m - (pr + pl) * 0.5f;
+      a_left += (double)(im[j] * pl) * (double)rho;
+      a_right += (double)(im[j] * pr) * (double)rho;
+      if (take) {
+        nt.Pq[base + j] = nt.Sq[base + j];
+        nt.Pg[base + j] = nt.Sg[base + j];
+      }
+    }
+    a_left = wave_sum(a_left);
+    a_right = wave_sum(a_right);
+    const bool turn = sturn || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+    if (lane == 0) {
+      const int n = IS(BJX_NUTS_I_NSTATES, c) + IS(BJX_NUTS_I_SUBN, c);
+      FS(BJX_NUTS_F_PW, c) = new_pw;
+      FS(BJX_NUTS_F_PSLPA, c) = new_pslpa;
+      if (take) {
+        FS(BJX_NUTS_F_PLOGP, c) = FS(BJX_NUTS_F_SLOGP, c);
+        FS(BJX_NUTS_F_PENERGY, c) = FS(BJX_NUTS_F_SENERGY, c);
+      }
+      FS(BJX_NUTS_F_ACC, c) = exp_cr(new_pslpa) / (float)n;  // nuts.py:303-305
+      IS(BJX_NUTS_I_NSTATES, c) = n;
+      IS(BJX_NUTS_I_DIV, c) = sdiv ? 1 : 0;
+      IS(BJX_NUTS_I_TURN, c) = turn ? 1 : 0;
+      IS(BJX_NUTS_I_DEPTH, c) = depth + 1;
+      IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+      IS(BJX_NUTS_I_ACTIVE, c) = (!sdiv && !turn && depth + 1 < nt.max_depth) ? 1 : 0;
+    }
+  }
+}
+
+int check_nuts(const bjx_nuts_t* nt, const char* what) {
+  if (!nt) { bjx_set_error("%s: null descriptor", what); return 1; }
+  const bool ok = nt->N >= 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30 && nt->imm &&
+                  (nt->imm_stride == 0 || nt->imm_stride == nt->D) && nt->q0 && nt->g0 && nt->p0 &&
+                  nt->Lq && nt->Lp && nt->Lg && nt->Rq && nt->Rp && nt->Rg && nt->msum && nt->Smsum &&
+                  nt->Pq && nt->Pg && nt->Sq && nt->Sg && nt->fs && nt->is &&
+                  (nt->max_depth == 0 || (nt->ckpt_r && nt->ckpt_rs));
+  if (!ok) { bjx_set_error("%s: bad descriptor", what); return 1; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, const float* ke0) {
+  if (check_nuts(nuts, "bjx_nuts_init")) return 1;
+  BJX_CHECK_ARG(logp0 && ke0, "bjx_nuts_init: bad arguments");
+  if (nuts->N == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_init, dim3(bjx_row_grid(nuts->N, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, logp0, ke0);
+  return bjx_check_launch("bjx_nuts_init");
+}
+
+int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                 const int32_t* idx, float* qf) {
+  if (check_nuts(nuts, "bjx_nuts_pre")) return 1;
+  BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && s >= 0 && s < ((int64_t)1 << depth) &&
+                    n_rows >= 0 && n_rows <= nuts->N && qf,
+                "bjx_nuts_pre: bad arguments");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_pre, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, qf);
+  return bjx_check_launch("bjx_nuts_pre");
+}
+
+int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                  const int32_t* idx, const float* qf, const float* logp_f, const float* gf) {
+  if (check_nuts(nuts, "bjx_nuts_post")) return 1;
+  BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && s >= 0 && s < ((int64_t)1 << depth) &&
+                    n_rows >= 0 && n_rows <= nuts->N && qf && logp_f && gf,
+                "bjx_nuts_post: bad arguments");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, qf, logp_f, gf);
+  return bjx_check_launch("bjx_nuts_post");
+}
+
+int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t n_rows,
+                   const int32_t* idx) {
+  if (check_nuts(nuts, "bjx_nuts_merge")) return 1;
+  BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && n_rows >= 0 && n_rows <= nuts->N,
+                "bjx_nuts_merge: bad arguments");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_merge, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, depth, n_rows, idx);
+  return bjx_check_launch("bjx_nuts_merge");
+}
+
+}  // extern "C"

@@ -152,4 +152,7 @@ int bjx_target_ar1_gaussian(void* stream, int64_t N, int64_t D, float diag_edge,
 #ifdef __cplusplus
 }
 #endif
+
+#include "bjx_nuts.h" /* NUTS entry points */
+
 #endif /* BJX_HIP_H */

@@ -1,0 +1,111 @@
+/*
+ * bjx_nuts.h -- C ABI of the NUTS part of libbjxhip.so (included by bjx_hip.h).
+ *
+ * Replaces blackjax/mcmc/nuts.py:113-145,223-321 (kernel, iterative_nuts_proposal),
+ * blackjax/mcmc/trajectory.py:242-395,580-727 (dynamic_progressive_integration,
+ * dynamic_multiplicative_expansion), blackjax/mcmc/proposal.py:51-105,118-176 and
+ * blackjax/mcmc/termination.py:31-106 for N chains advanced in lockstep.
+ *
+ * Lockstep structure.  All chains start a transition together and every doubling `depth` has
+ * a fixed length 2^depth unless the chain stops, so every chain that is still running is at the
+ * same (depth, s).  The host loops over (depth, s); per leapfrog it launches
+ *     bjx_nuts_pre   -> user log-density callable on the front positions -> bjx_nuts_post
+ * and per doubling bjx_nuts_merge.  `idx` lists the chains that were running when the doubling
+ * started (active-chain compaction: the callable only sees those rows); a chain whose subtree
+ * has diverged / turned is skipped by the kernels through its SUB_ACTIVE flag.
+ *
+ * All per-chain scalars live in two caller-owned device tables, one row per slot:
+ *     fs : float   [BJX_NUTS_NF][N]      is : int32_t [BJX_NUTS_NI][N]
+ */
+#ifndef BJX_NUTS_H
+#define BJX_NUTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* float slots (fs) */
+enum {
+  BJX_NUTS_F_H0 = 0,      /* initial energy of the transition (nuts.py:282) */
+  BJX_NUTS_F_LLOGP = 1,   /* logdensity of the leftmost / rightmost trajectory state */
+  BJX_NUTS_F_RLOGP = 2,
+  BJX_NUTS_F_PLOGP = 3,   /* main proposal: logdensity, energy, weight, sum_log_p_accept */
+  BJX_NUTS_F_PENERGY = 4,
+  BJX_NUTS_F_PW = 5,
+  BJX_NUTS_F_PSLPA = 6,
+  BJX_NUTS_F_SLOGP = 7,   /* subtree proposal */
+  BJX_NUTS_F_SENERGY = 8,
+  BJX_NUTS_F_SW = 9,
+  BJX_NUTS_F_SSLPA = 10,
+  BJX_NUTS_F_ACC = 11,    /* acceptance_rate = exp(sum_log_p_accept) / num_states (nuts.py:303-305) */
+  BJX_NUTS_NF = 12
+};
+
+/* int slots (is) */
+enum {
+  BJX_NUTS_I_ACTIVE = 0,     /* 1 while the chain keeps doubling */
+  BJX_NUTS_I_SUB_ACTIVE = 1, /* 1 while the current subtree keeps integrating */
+  BJX_NUTS_I_DIR = 2,        /* +1 / -1 direction of the current doubling */
+  BJX_NUTS_I_NSTATES = 3,    /* trajectory.num_states */
+  BJX_NUTS_I_SUBN = 4,       /* states in the current subtree */
+  BJX_NUTS_I_SDIV = 5,       /* subtree diverged / turned */
+  BJX_NUTS_I_STURN = 6,
+  BJX_NUTS_I_DIV = 7,        /* NUTSInfo.is_divergent / is_turning */
+  BJX_NUTS_I_TURN = 8,
+  BJX_NUTS_I_DEPTH = 9,      /* NUTSInfo.num_trajectory_expansions */
+  BJX_NUTS_NI = 10
+};
+
+typedef struct {
+  int64_t N, D;
+  int32_t max_depth;          /* max_num_doublings */
+  int32_t reserved;
+  const float* imm;           /* diagonal inverse mass matrix, (D,) or (N, D) */
+  int64_t imm_stride;         /* 0 or D */
+  const float* eps_per_chain; /* (N,) or NULL */
+  float eps;
+  float divergence_threshold;
+  uint32_t key0, key1;        /* key layout as in bjx_hip.h */
+  int64_t chain_offset, step_fold;
+  /* (N, D) arrays */
+  const float *q0, *g0, *p0;  /* initial position / gradient, drawn momentum */
+  float *Lq, *Lp, *Lg;        /* leftmost trajectory state */
+  float *Rq, *Rp, *Rg;        /* rightmost trajectory state */
+  float *msum, *Smsum;        /* momentum sums: trajectory, current subtree */
+  float *Pq, *Pg;             /* main proposal state (becomes the new chain state) */
+  float *Sq, *Sg;             /* subtree proposal state */
+  float *ckpt_r, *ckpt_rs;    /* (N, max_depth, D) U-turn checkpoints (termination.py:46-54) */
+  float* fs;                  /* (BJX_NUTS_NF, N) */
+  int32_t* is;                /* (BJX_NUTS_NI, N) */
+} bjx_nuts_t;
+
+/* Start of a transition: trajectory = (z0, z0, momentum_sum = p0, num_states = 0), proposal =
+ * (z0, H0, 0, -inf) with H0 = -logp0 + ke0 (nuts.py:278-294).  logp0, ke0: (N,). */
+int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, const float* ke0);
+
+/* Opening half of leapfrog `s` of doubling `depth` for rows idx[0..n_rows) (idx NULL = all chains
+ * in order): at s == 0 draws the direction (trajectory.py:645-650); p += (dir*eps/2) g ;
+ * q += dir*eps * imm*p on the trajectory end in that direction; writes the new position also to
+ * the compact row qf[b] for the user callable (integrators.py:104-150, trajectory.py:323). */
+int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                 const int32_t* idx, float* qf);
+
+/* Closing half: p += (dir*eps/2) g_new; proposal weight, divergence, progressive uniform sampling
+ * (key fold_in(trajectory_key, s)), momentum-sum append, checkpoint update and iterative U-turn
+ * (trajectory.py:321-346, proposal.py:68-103,118-143, termination.py:56-104).
+ * logp_f (n_rows,), gf (n_rows, D): callable outputs for the compact rows. */
+int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                  const int32_t* idx, const float* qf, const float* logp_f, const float* gf);
+
+/* End of doubling `depth`: biased progressive sampling or sum_log_p_accept update, trajectory
+ * merge, U-turn check on the merged trajectory, flags and counters, acceptance rate
+ * (trajectory.py:672-715, proposal.py:146-176, metrics.py:272-304, nuts.py:303-305). */
+int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t n_rows,
+                   const int32_t* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BJX_NUTS_H */

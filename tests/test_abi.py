@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "bjx_hip.h")).read()
+    text += open(os.path.join(ROOT, "include", "bjx_nuts.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bjx_[a-z0-9_]+)\s*\(", text)))
 
@@ -44,3 +45,30 @@ def test_host_key_split_matches_oracle():
     assert np.array_equal(k, prng.key(2**33 + 5))
     assert np.array_equal(bjx.random.split(k, 9, offset=4), prng.split(k, 9, offset=4))
     assert np.array_equal(bjx.random.fold_in(k, 77), prng.fold_in(k, 77))
+
+
+def test_nuts_descriptor_and_slots_match_header():
+    """The ctypes mirror of bjx_nuts_t and the slot tables agree with include/bjx_nuts.h."""
+    from blackjax_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "bjx_nuts.h")).read()
+    text_nc = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    enums = dict((k, int(v)) for k, v in re.findall(r"(BJX_NUTS_[A-Z_0-9]+)\s*=\s*(\d+)", text_nc))
+    for name, i in _lib.NUTS_F.items():
+        assert enums["BJX_NUTS_F_" + name] == i
+    for name, i in _lib.NUTS_I.items():
+        assert enums["BJX_NUTS_I_" + name] == i
+    assert enums["BJX_NUTS_NF"] == _lib.NUTS_NF == len(_lib.NUTS_F)
+    assert enums["BJX_NUTS_NI"] == _lib.NUTS_NI == len(_lib.NUTS_I)
+    # field order of the struct
+    body = re.search(r"typedef struct \{(.*?)\} bjx_nuts_t;", text_nc, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int64_t|int32_t|uint32_t|float)\s*\*?", "", decl)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    py = [f[0].rstrip("_") for f in _lib.NutsDesc._fields_]
+    assert names == py, (names, py)
+    assert ctypes.sizeof(_lib.NutsDesc) == 8 * 2 + 4 * 2 + 8 * 3 + 4 * 2 + 4 * 2 + 8 * 2 + 8 * 19

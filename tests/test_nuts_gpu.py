@@ -1,0 +1,117 @@
+"""GPU parity of the NUTS transition (lockstep doubling + active-chain compaction) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import blackjax_amd as bjx
+from oracle import hmc as ohmc
+from oracle import nuts as onuts
+from oracle import prng, targets as otargets
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-6
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def dev_t(a, dev):
+    return torch.as_tensor(np.asarray(a), device=dev)
+
+
+def _compare(info_g, info_o, st_g, st_o):
+    assert np.array_equal(t2n(info_g.num_integration_steps), info_o.num_integration_steps)
+    assert np.array_equal(t2n(info_g.num_trajectory_expansions), info_o.num_trajectory_expansions)
+    assert np.array_equal(t2n(info_g.is_turning), info_o.is_turning)
+    assert np.array_equal(t2n(info_g.is_divergent), info_o.is_divergent)
+    np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=ATOL, atol=ATOL)
+    np.testing.assert_allclose(t2n(st_g.logdensity), st_o.logdensity, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(t2n(st_g.logdensity_grad), st_o.logdensity_grad, rtol=ATOL, atol=ATOL)
+    np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(t2n(info_g.energy), info_o.energy, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(t2n(info_g.momentum), info_o.momentum, rtol=ATOL, atol=ATOL)
+    for sg, so in ((info_g.trajectory_leftmost_state, info_o.trajectory_leftmost_state),
+                   (info_g.trajectory_rightmost_state, info_o.trajectory_rightmost_state)):
+        np.testing.assert_allclose(t2n(sg.position), so.position, rtol=ATOL, atol=ATOL)
+        np.testing.assert_allclose(t2n(sg.momentum), so.momentum, rtol=ATOL, atol=ATOL)
+        np.testing.assert_allclose(t2n(sg.logdensity), so.logdensity, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("recompact", [0, 3, 16])
+def test_nuts_gaussian_parity(dev, recompact):
+    N, D, T = 24, 16, 4
+    sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(np.float32)
+    inv_var = (np.float32(1) / (sig * sig)).astype(np.float32)
+    imm = np.ones(D, np.float32)
+    fn_o = otargets.diag_gaussian(inv_var)
+    q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    alg = bjx.nuts(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), 0.15, dev_t(imm, dev),
+                   max_num_doublings=7, chain_offset=5, recompact_every=recompact)
+    st_g = alg.init(dev_t(q0, dev))
+    depths = []
+    for k in prng.split(prng.key(0), T):
+        st_o, info_o = onuts.kernel(k, st_o, fn_o, np.float32(0.15), imm, 7, chain_offset=5)
+        st_g, info_g = alg.step(k, st_g)
+        _compare(info_g, info_o, st_g, st_o)
+        depths += list(info_o.num_trajectory_expansions)
+    assert len(set(depths)) > 1  # chains stopped at different depths: compaction was exercised
+
+
+def test_nuts_funnel_parity_per_chain_params(dev):
+    """Scaled-down configs[2]: Neal's funnel; per-chain step size and per-chain diagonal imm;
+    includes chains that hit max depth and chains that diverge."""
+    N, D, T = 16, 10, 3
+    fn_o = otargets.neal_funnel()
+    rng = np.random.default_rng(0)
+    eps = rng.uniform(0.05, 0.6, N).astype(np.float32)
+    eps[0] = 30.0  # a diverging chain
+    eps[1] = 1e-4  # a chain that reaches max depth
+    imm = rng.uniform(0.5, 2.0, (N, D)).astype(np.float32)
+    q0 = (0.1 * prng.normal(prng.key(2), (N, D))).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    alg = bjx.nuts(bjx.targets.NealFunnel(), dev_t(eps, dev), dev_t(imm, dev), max_num_doublings=5)
+    st_g = alg.init(dev_t(q0, dev))
+    assert np.allclose(t2n(st_g.logdensity), st_o.logdensity, rtol=1e-6)
+    seen_div = seen_max = False
+    for k in prng.split(prng.key(4), T):
+        st_o, info_o = onuts.kernel(k, st_o, fn_o, eps, imm, 5)
+        st_g, info_g = alg.step(k, st_g)
+        _compare(info_g, info_o, st_g, st_o)
+        seen_div |= bool(info_o.is_divergent.any())
+        seen_max |= bool((info_o.num_trajectory_expansions == 5).any())
+    assert seen_div and seen_max
+
+
+def test_nuts_statistics_and_window_adaptation(dev):
+    """reference tests/mcmc/test_sampling.py:317-379 flavour: window_adaptation(nuts) then sample."""
+    N, D = 256, 8
+    sig = np.array([0.1, 0.3, 1, 3, 0.5, 2, 1, 0.2], np.float32)
+    fn = bjx.targets.DiagGaussian(dev_t(1 / (sig * sig), dev))
+    warm = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=None, max_num_doublings=6)
+    (state, params), _ = warm.run(bjx.random.key(3), torch.randn(N, D, device=dev), 150)
+    alg = bjx.nuts(fn, params["step_size"], bjx.metrics.PerChainDiag(params["inverse_mass_matrix"]),
+                   max_num_doublings=6)
+    draws, accs = [], []
+    for k in bjx.random.split(bjx.random.key(5), 30):
+        state, info = alg.step(k, state)
+        draws.append(state.position)
+        accs.append(info.acceptance_rate.mean().item())
+    x = torch.stack(draws[5:]).reshape(-1, D)
+    np.testing.assert_allclose(t2n(x.var(0)), sig * sig, rtol=0.2)
+    assert 0.6 < np.mean(accs) < 0.98
+    assert info.num_integration_steps.float().mean().item() < 40
+
+
+def test_nuts_max_depth_zero_and_one(dev):
+    N, D = 4, 6
+    fn = bjx.targets.DiagGaussian(torch.ones(D, device=dev))
+    q0 = torch.randn(N, D, device=dev)
+    alg = bjx.nuts(fn, 0.1, torch.ones(D, device=dev), max_num_doublings=0)
+    st = alg.init(q0)
+    st2, info = alg.step(bjx.random.key(0), st)
+    assert torch.equal(st2.position, q0) and int(info.num_integration_steps.sum()) == 0
+    alg1 = bjx.nuts(fn, 0.1, torch.ones(D, device=dev), max_num_doublings=1)
+    st3, info1 = alg1.step(bjx.random.key(0), st)
+    assert torch.all(info1.num_integration_steps == 1) and torch.all(info1.num_trajectory_expansions == 1)
