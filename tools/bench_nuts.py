@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Secondary benchmark (BASELINE.json configs[2], SURVEY.md 8d "C3"): NUTS, iterative tree doubling,
+max_depth = 10, Neal's funnel D = 256, 32 768 chains, eps = 0.1, imm = ones, one MI355X.
+Reports useful chain-leapfrog-steps/s and lockstep utilisation = sum(chain steps) / (N * launches)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blackjax_amd as bjx  # noqa: E402
+from blackjax_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--chains", type=int, default=32768)
+ap.add_argument("--dim", type=int, default=256)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--eps", type=float, default=0.1)
+ap.add_argument("--max-depth", type=int, default=10)
+ap.add_argument("--recompact", type=int, default=16)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+N, D = args.chains, args.dim
+alg = bjx.nuts(bjx.targets.NealFunnel(), args.eps, torch.ones(D, device=dev),
+               max_num_doublings=args.max_depth, recompact_every=args.recompact)
+g = torch.Generator(device=dev)
+g.manual_seed(0)
+state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=g))
+keys = bjx.random.split(bjx.random.key(0), args.warmup + args.steps)
+for t in range(args.warmup):
+    state, info = alg.step(keys[t], state)
+torch.cuda.synchronize()
+timer = _lib.LaunchTimer(["bjx_nuts_pre", "bjx_nuts_post"])
+_lib.set_timer(timer)
+tot_steps = 0
+launches = 0
+t0 = time.perf_counter()
+for t in range(args.warmup, args.warmup + args.steps):
+    state, info = alg.step(keys[t], state)
+    tot_steps += int(info.num_integration_steps.sum())
+    launches += len(timer.events["bjx_nuts_pre"]) - launches
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+_lib.set_timer(None)
+pre = timer.durations_ms("bjx_nuts_pre")
+post = timer.durations_ms("bjx_nuts_post")
+print(json.dumps({
+    "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot_steps / dt, "unit": "chain-leapfrog-steps/s",
+    "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
+               "recompact_every": args.recompact},
+    "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
+    "mean_leapfrogs_per_chain_transition": tot_steps / (N * args.steps),
+    "leapfrog_launches_per_transition": launches / args.steps,
+    "lockstep_utilisation_vs_uncompacted": tot_steps / (N * launches),
+    "pre_kernel_total_ms": sum(pre), "post_kernel_total_ms": sum(post),
+    "mean_depth": float(info.num_trajectory_expansions.float().mean()),
+    "frac_divergent": float(info.is_divergent.float().mean()),
+}))
