@@ -1,0 +1,352 @@
+// Dense Gaussian-Euclidean metric (gfx950): fp32 MFMA GEMMs for p = L^{-T} z and v = M^{-1} p,
+// fused with the leapfrog kick (A-operand prologue) and drift (epilogue).  C ABI in bjx_hip.h.
+//
+// The reference's dense products are `lax.dot(..., precision="highest")` (blackjax/util.py:23-61):
+// full fp32.  CDNA4 has native fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain at
+// the fp32 vector rate, no TF32), so nothing is down-cast.
+//
+// GEMM: C[M x Nn] = A'[M x K] * B[K x Nn], A' = optional kick prologue of (P, G); M = chains,
+// K = Nn = D, B row-major (D, D) shared by all chains (stays in L2).
+// Tiling: 128 x 128 block tile, K-tile 16, 256 threads = 2 x 2 waves, each wave a 64 x 64 tile =
+// 2 x 2 MFMA 32x32 accumulators (64 acc VGPRs); operands staged k-major in LDS, double buffered.
+#include "../../include/bjx_hip.h"
+#include "bjx_device.h"
+#include "bjx_host.h"
+
+using namespace bjx;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = BM + 1;  // padded k-major A tile: As[k][m]
+constexpr int LDB = BN;      // Bs[k][n]
+constexpr int kThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_STORE = 0, EPI_DRIFT = 1 };
+
+struct GemmArgs {
+  int64_t M, D;          // rows (chains), K = Nn = D
+  const float* A;        // (M, D)  P (or Z)
+  const float* G;        // (M, D)  gradient for the kick prologue, or nullptr
+  int n_kicks;           // 0, 1, 2
+  float eps;             // scalar step size
+  const float* eps_pc;   // per-chain step size or nullptr
+  float* A_out;          // (M, D) kicked A' (written by column-block 0) or nullptr
+  const float* B;        // (D, D) row-major
+  float* C;              // EPI_STORE: (M, D) output
+  const float* Q_in;     // EPI_DRIFT: q_out = fma(eps, C, Q_in)
+  float* Q_out;
+};
+
+template <int EPI, bool ALIGNED>
+__global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
+  __shared__ float As[2][BK * LDA];
+  __shared__ float Bs[2][BK * LDB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t row0 = (int64_t)blockIdx.y * BM;
+  const int64_t col0 = (int64_t)blockIdx.x * BN;
+  const int64_t D = a.D;
+
+  // global->register staging assignments
+  const int a_row = tid >> 1, a_k = (tid & 1) * 8;   // A tile: 128 rows x 16 k, 8 k per thread
+  const int b_k = tid >> 4, b_n = (tid & 15) * 8;    // B tile: 16 k x 128 n, 8 n per thread
+  const int64_t g_row = row0 + a_row;
+  const bool row_ok = g_row < a.M;
+  float h = 0.0f;
+  if (a.n_kicks > 0 && row_ok) h = (a.eps_pc ? a.eps_pc[g_row] : a.eps) * 0.5f;
+
+  float ra[8], rb[8];
+  auto load_tiles = [&](int64_t k0) {
+    // ---- A (with kick prologue)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ra[e] = 0.0f;
+    if (row_ok) {
+      const int64_t kk = k0 + a_k;
+      const float* ap = a.A + g_row * D + kk;
+      float rg[8];
+      if (ALIGNED && kk + 8 <= D) {
+        const F4 x0 = ld4(ap), x1 = ld4(ap + 4);
+        ra[0] = x0.x; ra[1] = x0.y; ra[2] = x0.z; ra[3] = x0.w;
+        ra[4] = x1.x; ra[5] = x1.y; ra[6] = x1.z; ra[7] = x1.w;
+        if (a.n_kicks > 0) {
+          const float* gp = a.G + g_row * D + kk;
+          const F4 g0 = ld4(gp), g1 = ld4(gp + 4);
+          rg[0] = g0.x; rg[1] = g0.y; rg[2] = g0.z; rg[3] = g0.w;
+          rg[4] = g1.x; rg[5] = g1.y; rg[6] = g1.z; rg[7] = g1.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (kk + e < D) {
+            ra[e] = ap[e];
+            rg[e] = a.n_kicks > 0 ? a.G[g_row * D + kk + e] : 0.0f;
+          } else {
+            rg[e] = 0.0f;
+          }
+        }
+      }
+      if (a.n_kicks > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ra[e] = fmaf(h, rg[e], ra[e]);
+          if (a.n_kicks == 2) ra[e] = fmaf(h, rg[e], ra[e]);
+        }
+        if (a.A_out && blockIdx.x == 0) {
+          float* op = a.A_out + g_row * D + kk;
+          if (ALIGNED && kk + 8 <= D) {
+            st4(op, F4{ra[0], ra[1], ra[2], ra[3]});
+            st4(op + 4, F4{ra[4], ra[5], ra[6], ra[7]});
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (kk + e < D) op[e] = ra[e];
+          }
+        }
+      }
+    }
+    // ---- B
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rb[e] = 0.0f;
+    const int64_t bk = k0 + b_k, bn = col0 + b_n;
+    if (bk < D) {
+      const float* bp = a.B + bk * D + bn;
+      if (ALIGNED && bn + 8 <= D) {
+        const F4 x0 = ld4(bp), x1 = ld4(bp + 4);
+        rb[0] = x0.x; rb[1] = x0.y; rb[2] = x0.z; rb[3] = x0.w;
+        rb[4] = x1.x; rb[5] = x1.y; rb[6] = x1.z; rb[7] = x1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (bn + e < D) rb[e] = bp[e];
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) As[buf][(a_k + e) * LDA + a_row] = ra[e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bs[buf][b_k * LDB + b_n + e] = rb[e];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int64_t n_tiles = (D + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int lm = lane & 31, lk = lane >> 5;
+  for (int64_t t = 0; t < n_tiles; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < n_tiles) load_tiles((t + 1) * BK);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = as[(kk + lk) * LDA + wm * 64 + lm];
+      const float a1 = as[(kk + lk) * LDA + wm * 64 + 32 + lm];
+      const float b0 = bs[(kk + lk) * LDB + wn * 64 + lm];
+      const float b1 = bs[(kk + lk) * LDB + wn * 64 + 32 + lm];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < n_tiles) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][4*bq + r] <-> row = 8*bq + 4*(lane/32) + r, col = lane%32 of the 32x32 tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = col0 + wn * 64 + j * 32 + lm;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + wm * 64 + i * 32 + bq * 8 + lk * 4 + r;
+          if (row < a.M && col < D) {
+            const float c = acc[i][j][bq * 4 + r];
+            if constexpr (EPI == EPI_STORE) {
+              a.C[row * D + col] = c;
+            } else {
+              const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
+              a.Q_out[row * D + col] = fmaf(e, c, a.Q_in[row * D + col]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
+__device__ __forceinline__ int64_t wave_row0() {
+  return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+}
+__device__ __forceinline__ int64_t wave_row_stride() { return (int64_t)gridDim.x * kWavesPerBlock; }
+
+// z = normal(km, (D,)), km = split(chain key, 2)[0]   (util.py:89-90)
+__global__ void __launch_bounds__(kBlock)
+k_dense_z(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, float* __restrict__ z) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const Key km = key_child(chain_key(key, (uint64_t)(r + off), fold), 0);
+    for (int64_t j = lane; j < D; j += 64) z[r * D + j] = normal_from_bits(key_bits32(km, (uint64_t)j));
+  }
+}
+
+// ke = 0.5 * sum_j v_j p_j  (metrics.py:263-270), fp64 accumulate
+__global__ void __launch_bounds__(kBlock)
+k_rowdot_half(int64_t N, int64_t D, const float* __restrict__ v, const float* __restrict__ p,
+              float* __restrict__ ke) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    double acc = 0.0;
+    for (int64_t j = lane; j < D; j += 64) acc += (double)v[r * D + j] * (double)p[r * D + j];
+    acc = wave_sum(acc);
+    if (lane == 0) ke[r] = 0.5f * (float)acc;
+  }
+}
+
+// Metropolis tail for the dense metric: p1 (already fully kicked) and v1 = imm @ p1 are inputs.
+__global__ void __launch_bounds__(kBlock)
+k_hmc_finish_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, float thr,
+                   const float* __restrict__ q0, const float* __restrict__ logp0,
+                   const float* __restrict__ g0, const float* __restrict__ ke0,
+                   const float* __restrict__ q1, const float* __restrict__ logp1,
+                   const float* __restrict__ g1, const float* __restrict__ p1,
+                   const float* __restrict__ v1, float* __restrict__ p_end, float* __restrict__ q_out,
+                   float* __restrict__ logp_out, float* __restrict__ g_out,
+                   float* __restrict__ acc_rate_out, uint8_t* __restrict__ is_acc_out,
+                   uint8_t* __restrict__ is_div_out, float* __restrict__ energy_out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const int64_t base = r * D;
+    double acc = 0.0;
+    for (int64_t j = lane; j < D; j += 64) {
+      const float p = p1[base + j];
+      acc += (double)v1[base + j] * (double)p;
+      if (p_end) p_end[base + j] = -1.0f * p;  // flip_momentum (hmc.py:95-112)
+    }
+    acc = wave_sum(acc);
+    const float ke1 = 0.5f * (float)acc;
+    const float lp0 = logp0[r], lp1 = logp1[r];
+    const float H0 = -lp0 + ke0[r];
+    const float H1 = -lp1 + ke1;
+    float delta = H0 - H1;
+    if (delta != delta) delta = -__builtin_inff();
+    const bool is_div = (-delta) > thr;
+    const float p_acc = fminf(exp_cr(delta), 1.0f);
+    const Key ki = key_child(chain_key(key, (uint64_t)(r + off), fold), 1);
+    const bool accept = key_uniform(ki) < p_acc;
+    if (lane == 0) {
+      logp_out[r] = accept ? lp1 : lp0;
+      acc_rate_out[r] = p_acc;
+      is_acc_out[r] = accept ? 1 : 0;
+      is_div_out[r] = is_div ? 1 : 0;
+      energy_out[r] = H1;
+    }
+    const float* qs = accept ? q1 : q0;
+    const float* gs = accept ? g1 : g0;
+    for (int64_t j = lane; j < D; j += 64) {
+      q_out[base + j] = qs[base + j];
+      g_out[base + j] = gs[base + j];
+    }
+  }
+}
+
+int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
+  const dim3 grid((unsigned)((ga.D + BN - 1) / BN), (unsigned)((ga.M + BM - 1) / BM));
+  const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B);
+  if (epi == EPI_STORE) {
+    if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true>), grid, dim3(kThreads), 0, s, ga);
+    else hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, false>), grid, dim3(kThreads), 0, s, ga);
+  } else {
+    if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, true>), grid, dim3(kThreads), 0, s, ga);
+    else hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, false>), grid, dim3(kThreads), 0, s, ga);
+  }
+  return bjx_check_launch("bjx_dense gemm");
+}
+
+}  // namespace
+
+extern "C" {
+
+int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && A && B && C, "bjx_dense_matmul: bad arguments");
+  if (N == 0) return 0;
+  GemmArgs ga{N, D, A, nullptr, 0, 0.0f, nullptr, nullptr, B, C, nullptr, nullptr};
+  return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
+}
+
+int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                           int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
+                           const float* imm, float* z_work, float* v_work, float* p_out,
+                           float* ke_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out,
+                "bjx_hmc_momentum_dense: bad arguments");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 rgrid(bjx_row_grid(N, kWavesPerBlock)), rblock(kBlock);
+  hipLaunchKernelGGL(k_dense_z, rgrid, rblock, 0, s, Key{key0, key1}, chain_offset, step_fold, N, D,
+                     z_work);
+  if (int rc = bjx_check_launch("bjx_hmc_momentum_dense(z)")) return rc;
+  GemmArgs g1{N, D, z_work, nullptr, 0, 0.0f, nullptr, nullptr, mass_sqrt_t, p_out, nullptr, nullptr};
+  if (int rc = launch_gemm(s, EPI_STORE, g1)) return rc;  // p = L^{-T} z   (metrics.py:260-261)
+  GemmArgs g2{N, D, p_out, nullptr, 0, 0.0f, nullptr, nullptr, imm, v_work, nullptr, nullptr};
+  if (int rc = launch_gemm(s, EPI_STORE, g2)) return rc;  // v = imm p
+  hipLaunchKernelGGL(k_rowdot_half, rgrid, rblock, 0, s, N, D, v_work, p_out, ke_out);
+  return bjx_check_launch("bjx_hmc_momentum_dense(ke)");
+}
+
+int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                       const float* eps_per_chain, const float* imm, const float* q_in,
+                       const float* p_in, const float* g, float* q_out, float* p_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
+                "bjx_leapfrog_dense: bad arguments");
+  BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense: n_kicks must be 1 or 2");
+  BJX_CHECK_ARG(p_out != p_in, "bjx_leapfrog_dense: p_out must not alias p_in");
+  if (N == 0) return 0;
+  GemmArgs ga{N, D, p_in, g, n_kicks, eps, eps_per_chain, p_out, imm, nullptr, q_in, q_out};
+  return launch_gemm((hipStream_t)stream, EPI_DRIFT, ga);
+}
+
+int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                         int64_t step_fold, int64_t N, int64_t D, float eps,
+                         const float* eps_per_chain, const float* imm, float divergence_threshold,
+                         const float* q0, const float* logp0, const float* g0, const float* ke0,
+                         const float* q1, const float* logp1, const float* g1, const float* p,
+                         float* p1_work, float* v_work, float* p_end_out, float* q_out,
+                         float* logp_out, float* g_out, float* acceptance_rate_out,
+                         uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
+                    p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
+                    is_accepted_out && is_divergent_out && energy_out,
+                "bjx_hmc_finish_dense: bad arguments");
+  BJX_CHECK_ARG(p1_work != p, "bjx_hmc_finish_dense: p1_work must not alias p");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  // closing half kick fused into the GEMM prologue: p1 = p + (eps/2) g1 ; v1 = imm p1
+  GemmArgs ga{N, D, p, g1, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+  if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
+  hipLaunchKernelGGL(k_hmc_finish_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
+                     Key{key0, key1}, chain_offset, step_fold, N, D, divergence_threshold, q0, logp0,
+                     g0, ke0, q1, logp1, g1, p1_work, v_work, p_end_out, q_out, logp_out, g_out,
+                     acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
+  return bjx_check_launch("bjx_hmc_finish_dense");
+}
+
+}  // extern "C"

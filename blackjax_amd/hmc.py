@@ -67,10 +67,10 @@ def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, 
         _lib.call("bjx_leapfrog_diag", stream, N, D, n_kicks, eps, _lib.ptr(eps_pc),
                   metric.imm.data_ptr(), metric.imm_stride, q_in.data_ptr(), p_in.data_ptr(),
                   g.data_ptr(), q_out.data_ptr(), p_out.data_ptr())
-    else:
-        from . import dense
+        return p_out
+    from . import dense
 
-        dense.leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out)
+    return dense.leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out)
 
 
 def _default_chain_block():
@@ -156,10 +156,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 eps_fin, eps_pc_fin = 0.0, None
             else:
                 q, p = q_end[sl], p_work[sl]
-                _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
+                p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
                 logp, g = eval_logdensity(vg, q)
                 for _ in range(L - 1):
-                    _launch_leapfrog(stream, m, n, D, 2, eps, eb, q, p, g, q, p)
+                    p = _launch_leapfrog(stream, m, n, D, 2, eps, eb, q, p, g, q, p)
                     logp, g = eval_logdensity(vg, q)
                 eps_fin, eps_pc_fin = eps, eb
 

@@ -96,6 +96,39 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                         float* acceptance_rate_out, uint8_t* is_accepted_out,
                         uint8_t* is_divergent_out, float* energy_out);
 
+/* ---- dense Gaussian-Euclidean metric (one (D, D) inverse mass matrix shared by all chains) ----
+ * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32, exact fp32 fma chains: "precision=highest",
+ * blackjax/util.py:23-61).  All matrices row-major.
+ *
+ * C = A @ B with A (N, D), B (D, D): the building block, exported for parity tests. */
+int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C);
+
+/* Momentum draw: z = normal(km, (D,)) ; p = L^{-T} z = z @ mass_sqrt_t with mass_sqrt_t = L^{-1}
+ * (L = cholesky(imm, lower)) ; ke = 0.5 dot(imm @ p, p).  z_work, v_work: (N, D) scratch.
+ * Replaces: blackjax/mcmc/hmc.py:299,302 ; metrics.py:260-261,263-270,711-715 ; util.py:58-61,89-91. */
+int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                           int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
+                           const float* imm, float* z_work, float* v_work, float* p_out,
+                           float* ke_out);
+
+/* Fused kick(s) + drift with a dense metric: p' = kick(p, g) [GEMM A-operand prologue, written to
+ * p_out] ; v = imm @ p' [MFMA] ; q_out = q_in + eps v [epilogue].  p_out must not alias p_in;
+ * q_out may alias q_in.  Replaces: blackjax/mcmc/integrators.py:104-150 with util.py:58-61. */
+int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                       const float* eps_per_chain, const float* imm, const float* q_in,
+                       const float* p_in, const float* g, float* q_out, float* p_out);
+
+/* Closing half kick + energies + Metropolis accept + select with a dense metric (same contract as
+ * bjx_hmc_finish_diag).  p1_work, v_work: (N, D) scratch (p1_work must not alias p). */
+int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                         int64_t step_fold, int64_t N, int64_t D, float eps,
+                         const float* eps_per_chain, const float* imm, float divergence_threshold,
+                         const float* q0, const float* logp0, const float* g0, const float* ke0,
+                         const float* q1, const float* logp1, const float* g1, const float* p,
+                         float* p1_work, float* v_work, float* p_end_out, float* q_out,
+                         float* logp_out, float* g_out, float* acceptance_rate_out,
+                         uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out);
+
 /* ---- window adaptation (per-chain state; every array is (N,) unless noted) ------------------
  *
  * Dual averaging init (from_log_avg = 0: x = x_in) or window-end re-init (from_log_avg = 1:
