@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--eps", type=float, default=0.25)
     ap.add_argument("--chain-block", type=int, default=0,
                     help="run each transition block-by-block over this many chains (0 = all at once)")
+    ap.add_argument("--use-graph", action="store_true",
+                    help="capture each block's inner leapfrog/callable loop in a HIP graph")
+    ap.add_argument("--no-ic-mode", action="store_true",
+                    help="skip the extra Infinity-Cache-mode measurement (chain blocks + HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     args = ap.parse_args()
@@ -111,7 +115,7 @@ def main():
     imm = (sig * sig).contiguous()
     target = bjx.targets.DiagGaussian((1.0 / imm).contiguous())
     alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N,
-                  chain_block=args.chain_block or None)
+                  chain_block=args.chain_block or None, use_graph=args.use_graph)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     state = alg.init(sig * torch.randn(N, D, device=dev, generator=gen))
@@ -130,12 +134,15 @@ def main():
         timer = _lib.LaunchTimer(["bjx_leapfrog_diag"])
         _lib.set_timer(timer)
     acc_sum = torch.zeros((), device=dev)
+    n_sub = min(1024, N)
+    draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(args.warmup, args.warmup + args.steps):
         state, info = alg.step(keys[t], state)
         acc_sum += info.acceptance_rate.mean()
+        draws.append(state.position[:n_sub].clone())
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -152,6 +159,37 @@ def main():
         final_draws = torch.cat(gathered, 0)
     else:
         final_draws = state.position[:256]
+
+    # Extra, separately reported region: the same workload run block-by-block (16 384 chains at a
+    # time, inner loop captured in a HIP graph) so a block's q/p/g stay in the 256 MiB Infinity
+    # Cache across the L steps.  Not the headline `value` (its kernels are not HBM streams).
+    ic_mode = None
+    if not args.no_ic_mode and not args.chain_block and not args.use_graph and N > 16384:
+        alg_ic = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=16384,
+                         use_graph=True)
+        st_ic = state
+        st_ic, _ = alg_ic.step(keys[0], st_ic)  # captures the graph
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(args.warmup, args.warmup + args.steps):
+            st_ic, _ = alg_ic.step(keys[t], st_ic)
+        torch.cuda.synchronize()
+        barrier()
+        dt_ic = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_ic], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ic = float(tt.item())
+        ic_mode = {"value": world * N * L * args.steps / dt_ic, "unit": "chain-leapfrog-steps/s",
+                   "chain_block": 16384, "hip_graph": True, "ms_per_step": dt_ic / args.steps * 1e3}
+
+    # ESS/sec (second half of BASELINE.json's metric): min over dimensions of
+    # effective_sample_size (blackjax/diagnostics.py:157-304) on the retained subset / wall time
+    ess_min = None
+    if args.steps >= 4:
+        ess = bjx.diagnostics.effective_sample_size(torch.stack(draws, dim=1))  # (n_sub, T, D)
+        ess_min = float(ess.min().item())
 
     if rank == 0:
         total_chain_leapfrogs = world * N * L * args.steps
@@ -194,12 +232,18 @@ def main():
                 "workload": f"HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
                             f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
                 "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
-                "chain_block": args.chain_block or N,
+                "chain_block": args.chain_block or N, "hip_graph": bool(args.use_graph),
                 "parallelism": f"chains sharded x{world}, no data-path collective",
             },
             "mean_acceptance": float(acc_sum.item()) / args.steps,
+            "ess": None if ess_min is None else {
+                "min_ess_subset": ess_min, "subset_chains": n_sub, "draws_per_chain": args.steps,
+                "min_ess_per_sec_subset": ess_min / dt,
+                "min_ess_per_sec_all_chains": ess_min / dt * (world * N / n_sub),
+                "note": "rank-0 subset of chains, min over the D dimensions"},
             "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
             "final_draws_gathered": list(final_draws.shape),
+            "infinity_cache_mode": ic_mode,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

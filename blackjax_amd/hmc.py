@@ -80,8 +80,52 @@ def _default_chain_block():
     return int(v) if v else None
 
 
+class _GraphedTrajectory:
+    """HIP-graph capture of the inner loop of one chain block:
+
+        callable(Wq) ; [leapfrog(2 kicks, in place on Wq/Wp) ; callable(Wq)] x (L-1)
+
+    over STATIC workspace buffers (positions ``Wq``, momenta ``Wp``, per-chain step sizes,
+    inverse mass matrix), so one captured graph serves every block of every transition: the
+    caller fills the workspace (the first kick+drift of a trajectory writes straight into it),
+    replays, and reads the end state back.  Removes the per-launch host cost that would
+    otherwise dominate once a block is small enough to live in the Infinity Cache.
+    """
+
+    def __init__(self, n, D, L, vg, imm_per_chain, device):
+        self.n, self.D, self.L = n, D, L
+        self.Wq = torch.empty((n, D), dtype=torch.float32, device=device)
+        self.Wp = torch.empty((n, D), dtype=torch.float32, device=device)
+        self.eps = torch.ones(n, dtype=torch.float32, device=device)
+        self.imm = torch.ones((n, D) if imm_per_chain else (D,), dtype=torch.float32, device=device)
+        self.imm_stride = D if imm_per_chain else 0
+        self.Wq.zero_()
+        self.Wp.zero_()
+        self._vg = vg
+        # warm-up on a side stream (allocator / lazy-init work must not happen inside capture)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            self._body()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logp, self.g = self._body()
+
+    def _body(self):
+        stream = _lib.current_stream()
+        logp, g = eval_logdensity(self._vg, self.Wq)
+        for _ in range(self.L - 1):
+            _lib.call("bjx_leapfrog_diag", stream, self.n, self.D, 2, 0.0, self.eps.data_ptr(),
+                      self.imm.data_ptr(), self.imm_stride, self.Wq.data_ptr(), self.Wp.data_ptr(),
+                      g.data_ptr(), self.Wq.data_ptr(), self.Wp.data_ptr())
+            logp, g = eval_logdensity(self._vg, self.Wq)
+        return logp, g
+
+
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: float = 1000,
-                 build_proposal=None, *, chain_block=None):
+                 build_proposal=None, *, chain_block=None, use_graph: bool = False):
     """blackjax/mcmc/hmc.py:251-314.  ``build_proposal`` other than the default endpoint
     proposal (hmc_proposal, 115-178) is out of scope.
 
@@ -90,6 +134,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     over all N chains.  With a block whose q/p/g working set fits the 256 MiB Infinity Cache
     the L-step loop re-reads its state from on-die cache instead of HBM.  Results are
     identical for any blocking (per-chain keys depend only on the global chain index).
+
+    ``use_graph``: capture the per-block inner loop (the user's callable included) in a HIP
+    graph (diagonal metric; the callable must be capturable: static shapes, no host sync).
     """
     integrators.check_supported(integrator)
     if build_proposal is not None:
@@ -97,6 +144,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     thr = float(divergence_threshold)
     if chain_block is None:
         chain_block = _default_chain_block()
+    graphs: dict = {}
 
     def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
@@ -115,11 +163,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         stream = _lib.current_stream()
         off = int(chain_offset)
         dev = q0.device
+        graphed = bool(use_graph) and L >= 1 and metric.kind == "diag"
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        q_end = torch.empty_like(q0) if L > 0 else q0
-        p_work = torch.empty_like(q0) if L > 0 else p0
         p_end = torch.empty_like(q0)
         q_new = torch.empty_like(q0)
         g_new = torch.empty_like(q0)
@@ -131,10 +178,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
 
         blk = N if not chain_block or chain_block >= N else int(chain_block)
         n_blocks = (N + blk - 1) // blk if N else 0
-        g_end = logp_end = None
-        if n_blocks > 1 and L > 0:
-            g_end = torch.empty_like(q0)
-            logp_end = torch.empty_like(logp0)
+        single = n_blocks <= 1 and not graphed
+        # end-of-trajectory state (HMCInfo.proposal): per-block work buffers are copied out
+        # unless the whole batch is one un-graphed block, in which case they ARE the result
+        q_end = torch.empty_like(q0) if L > 0 else q0
+        p_work = torch.empty_like(q0) if (L > 0 and not graphed) else None
+        g_end = torch.empty_like(q0) if (L > 0 and not single) else None
+        logp_end = torch.empty_like(logp0) if (L > 0 and not single) else None
+        if L == 0:
+            g_end, logp_end = g0, logp0
 
         for b in range(n_blocks):
             s, e = b * blk, min(N, (b + 1) * blk)
@@ -154,6 +206,21 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             if L == 0:
                 q, p, logp, g = q0[sl], p0[sl], logp0[sl], g0[sl]
                 eps_fin, eps_pc_fin = 0.0, None
+            elif graphed:
+                gkey = (n, D, L, id(vg), m.imm_stride != 0, dev.index)
+                ctx = graphs.get(gkey)
+                if ctx is None:
+                    ctx = graphs[gkey] = _GraphedTrajectory(n, D, L, vg, m.imm_stride != 0, dev)
+                if eb is None:
+                    ctx.eps.fill_(eps)
+                else:
+                    ctx.eps.copy_(eb)
+                ctx.imm.copy_(m.imm)
+                # first kick + drift writes straight into the static workspace
+                _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], ctx.Wq, ctx.Wp)
+                ctx.graph.replay()
+                q, p, logp, g = ctx.Wq, ctx.Wp, ctx.logp, ctx.g
+                eps_fin, eps_pc_fin = eps, eb
             else:
                 q, p = q_end[sl], p_work[sl]
                 p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
@@ -178,16 +245,17 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                              logp0[sl], g0[sl], ke0[sl], q, logp, g, p, p_end[sl], q_new[sl],
                              logp_new[sl], g_new[sl], acc_rate[sl], is_acc[sl], is_div[sl],
                              energy[sl])
-            if g_end is not None:
-                g_end[sl].copy_(g)
-                logp_end[sl].copy_(logp)
-            else:
-                g_end_single, logp_end_single = g, logp
+            if L > 0:
+                if single:
+                    g_end, logp_end = g, logp
+                else:
+                    g_end[sl].copy_(g)
+                    logp_end[sl].copy_(logp)
+                    if graphed:
+                        q_end[sl].copy_(q)
 
-        if n_blocks == 0:
-            g_end_single, logp_end_single = g0, logp0
-        if g_end is None:
-            g_end, logp_end = g_end_single, logp_end_single
+        if n_blocks == 0 and L > 0:
+            g_end, logp_end = g0, logp0
         info = HMCInfo(p0, acc_rate, is_acc, is_div, energy,
                        IntegratorState(q_end, p_end, logp_end, g_end), L)
         return HMCState(q_new, logp_new, g_new), info
@@ -198,11 +266,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix,
                      num_integration_steps: int, *, divergence_threshold: float = 1000,
                      integrator=integrators.velocity_verlet, build_proposal=None,
-                     chain_offset: int = 0, chain_block=None) -> SamplingAlgorithm:
+                     chain_offset: int = 0, chain_block=None,
+                     use_graph: bool = False) -> SamplingAlgorithm:
     """blackjax/mcmc/hmc.py:317-414.  ``chain_offset`` is this process' first global chain
     index when the chains of one run are sharded over several GPUs."""
     kernel = build_kernel(integrator, divergence_threshold, build_proposal,
-                          chain_block=chain_block)
+                          chain_block=chain_block, use_graph=use_graph)
 
     def init_fn(position, rng_key=None):
         del rng_key

@@ -229,13 +229,18 @@ def test_chain_block_tiling_is_invisible(dev):
     eps = torch.rand(N, device=dev) * 0.3 + 0.05
     a1 = bjx.hmc(fn, eps, imm, L)
     a2 = bjx.hmc(fn, eps, imm, L, chain_block=48)
-    s1, s2 = a1.init(q0), a2.init(q0)
+    a3 = bjx.hmc(fn, eps, imm, L, chain_block=64, use_graph=True)  # HIP-graph captured inner loop
+    a4 = bjx.hmc(fn, eps, imm, L, use_graph=True)
+    s1, s2, s3, s4 = a1.init(q0), a2.init(q0), a3.init(q0), a4.init(q0)
     for k in bjx.random.split(bjx.random.key(4), 3):
         s1, i1 = a1.step(k, s1)
         s2, i2 = a2.step(k, s2)
-        for x, y in zip(s1, s2):
-            assert torch.equal(x, y)
-        for x, y in zip(i1[:5], i2[:5]):
-            assert torch.equal(x, y)
-        for x, y in zip(i1.proposal, i2.proposal):
-            assert torch.equal(x, y)
+        s3, i3 = a3.step(k, s3)
+        s4, i4 = a4.step(k, s4)
+        for sx, ix in ((s2, i2), (s3, i3), (s4, i4)):
+            for x, y in zip(s1, sx):
+                assert torch.equal(x, y)
+            for x, y in zip(i1[:5], ix[:5]):
+                assert torch.equal(x, y)
+            for x, y in zip(i1.proposal, ix.proposal):
+                assert torch.equal(x, y)
