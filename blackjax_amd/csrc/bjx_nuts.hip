@@ -45,8 +45,33 @@ __device__ __forceinline__ float expit_cr(float x) { return (float)(1.0 / (1.0 +
 // jnp.minimum(x, 1): NaN propagates
 __device__ __forceinline__ float min1_nan(float x) { return (x < 1.0f || x != x) ? x : 1.0f; }
 
-__device__ __forceinline__ Key integrator_key(const bjx_nuts_t& nt, int64_t c) {
-  const Key kc = chain_key(Key{nt.key0, nt.key1}, (uint64_t)(c + nt.chain_offset), nt.step_fold);
+// Launch-time parameters either come from the kernel arguments (eager launches) or, for HIP-graph
+// replays, from a device control block ctl = {depth, s_base, n_rows, key0, key1, step_fold,
+// chain_offset} so that one captured graph serves every chunk of every transition.
+struct StepCtx {
+  int32_t depth, s;
+  int64_t n_rows;
+  Key key;
+  int64_t off, fold;
+};
+
+__device__ __forceinline__ StepCtx make_ctx(const bjx_nuts_t& nt, int32_t depth, int32_t s,
+                                            int64_t n_rows, const int64_t* __restrict__ ctl) {
+  if (ctl) {
+    StepCtx c;
+    c.depth = (int32_t)ctl[0];
+    c.s = (int32_t)ctl[1] + s;  // s is the offset inside the captured chunk
+    c.n_rows = ctl[2] < n_rows ? ctl[2] : n_rows;
+    c.key = Key{(uint32_t)ctl[3], (uint32_t)ctl[4]};
+    c.fold = ctl[5];
+    c.off = ctl[6];
+    return c;
+  }
+  return StepCtx{depth, s, n_rows, Key{nt.key0, nt.key1}, nt.chain_offset, nt.step_fold};
+}
+
+__device__ __forceinline__ Key integrator_key(const StepCtx& cx, int64_t c) {
+  const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
   return key_child(kc, 1);  // split(kc, 2)[1]   (nuts.py:133)
 }
 
@@ -97,15 +122,18 @@ k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restr
 
 // ------------------------------------------------------------------------------------ pre
 __global__ void __launch_bounds__(kBlock)
-k_nuts_pre(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32_t* __restrict__ idx,
-           float* __restrict__ qf) {
+k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
+           const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* __restrict__ qf) {
   const int lane = threadIdx.x & 63;
+  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
+  const int32_t depth = cx.depth, s = cx.s;
+  const int64_t n_rows = cx.n_rows;
   for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
     const int64_t c = idx ? (int64_t)idx[b] : b;
     if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
     int dir;
     if (s == 0) {
-      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);  // trajectory.py:645
+      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);  // trajectory.py:645
       const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
       dir = key_uniform(kd) < 0.5f ? 1 : -1;                                  // trajectory.py:650
       if (lane == 0) {
@@ -139,10 +167,14 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32_
 
 // ------------------------------------------------------------------------------------ post
 __global__ void __launch_bounds__(kBlock)
-k_nuts_post(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32_t* __restrict__ idx,
+k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
+            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl,
             const float* __restrict__ qf, const float* __restrict__ logp_f,
             const float* __restrict__ gf) {
   const int lane = threadIdx.x & 63;
+  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
+  const int32_t depth = cx.depth, s = cx.s;
+  const int64_t n_rows = cx.n_rows;
   for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
     const int64_t c = idx ? (int64_t)idx[b] : b;
     if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
@@ -183,7 +215,7 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth, int32_t s, int64_t n_rows, const int32
       Sn = slpa_new;
     } else {
       const float sw = FS(BJX_NUTS_F_SW, c);
-      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);
+      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
       const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
       const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
       const float pa = expit_cr(w - sw);
@@ -267,7 +299,8 @@ k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __rest
     float new_pw = pw;
     const float new_pslpa = logaddexp_cr(pslpa, sslpa);
     if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
-      const Key subkey = key_child(integrator_key(nt, c), (uint64_t)depth);
+      const StepCtx cx{depth, 0, n_rows, Key{nt.key0, nt.key1}, nt.chain_offset, nt.step_fold};
+      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
       const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
       const float pa = min1_nan(exp_cr(sw - pw));
       take = key_uniform(kp) < pa;
@@ -310,6 +343,53 @@ k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __rest
   }
 }
 
+__global__ void k_nuts_set_ctl(int64_t* ctl, int64_t depth, int64_t s_base, int64_t n_rows,
+                               int64_t key0, int64_t key1, int64_t fold, int64_t off) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    ctl[0] = depth; ctl[1] = s_base; ctl[3] = key0;
+    ctl[4] = key1; ctl[5] = fold; ctl[6] = off; ctl[7] = 0;
+    if (n_rows >= 0) ctl[2] = n_rows;  // negative: keep the count written by k_nuts_compact
+  }
+}
+
+// Device-side active-chain compaction (no host round trip): keeps, in order, the chains of
+// idx_in[0..n_in) (identity list if idx_in == NULL) whose flag slot is set, writes them to
+// idx_out (may alias idx_in) and the count to ctl[2].  One 1024-thread workgroup; wave ballots
+// + a 16-entry LDS scan per 1024-entry slice.
+constexpr int kCompactThreads = 1024;
+__global__ void __launch_bounds__(kCompactThreads)
+k_nuts_compact(bjx_nuts_t nt, int flag_slot, int64_t n_in_arg, const int32_t* idx_in,
+               int32_t* idx_out, int64_t* ctl) {
+  __shared__ int wave_counts[kCompactThreads / 64];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n_in = n_in_arg >= 0 ? n_in_arg : ctl[2];
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int64_t start = 0; start < n_in; start += kCompactThreads) {
+    const int64_t i = start + tid;
+    int32_t c = -1;
+    if (i < n_in) c = idx_in ? idx_in[i] : (int32_t)i;
+    const bool keep = c >= 0 && IS(flag_slot, c) != 0 && IS(BJX_NUTS_I_ACTIVE, c) != 0;
+    const unsigned long long ballot = __ballot(keep);
+    const int lane_prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_counts[wave] = __popcll(ballot);
+    __syncthreads();  // every read of this slice is done before any write below
+    int wave_off = 0, total = 0;
+    for (int w = 0; w < kCompactThreads / 64; ++w) {
+      const int cnt = wave_counts[w];
+      if (w < wave) wave_off += cnt;
+      total += cnt;
+    }
+    const int b0 = base;
+    if (keep) idx_out[b0 + wave_off + lane_prefix] = c;
+    __syncthreads();
+    if (tid == 0) base = b0 + total;
+    __syncthreads();
+  }
+  if (tid == 0) ctl[2] = base;
+}
+
 int check_nuts(const bjx_nuts_t* nt, const char* what) {
   if (!nt) { bjx_set_error("%s: null descriptor", what); return 1; }
   const bool ok = nt->N >= 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30 && nt->imm &&
@@ -342,8 +422,20 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
                 "bjx_nuts_pre: bad arguments");
   if (n_rows == 0) return 0;
   hipLaunchKernelGGL(k_nuts_pre, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, qf);
+                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx,
+                     (const int64_t*)nullptr, qf);
   return bjx_check_launch("bjx_nuts_pre");
+}
+
+int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
+                     const int32_t* idx, const int64_t* ctl, float* qf) {
+  if (check_nuts(nuts, "bjx_nuts_pre_ctl")) return 1;
+  BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf,
+                "bjx_nuts_pre_ctl: bad arguments");
+  if (n_cap == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_pre, dim3(bjx_row_grid(n_cap, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf);
+  return bjx_check_launch("bjx_nuts_pre_ctl");
 }
 
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
@@ -354,8 +446,40 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
                 "bjx_nuts_post: bad arguments");
   if (n_rows == 0) return 0;
   hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, qf, logp_f, gf);
+                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx,
+                     (const int64_t*)nullptr, qf, logp_f, gf);
   return bjx_check_launch("bjx_nuts_post");
+}
+
+int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
+                      const int32_t* idx, const int64_t* ctl, const float* qf, const float* logp_f,
+                      const float* gf) {
+  if (check_nuts(nuts, "bjx_nuts_post_ctl")) return 1;
+  BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf && logp_f && gf,
+                "bjx_nuts_post_ctl: bad arguments");
+  if (n_cap == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_cap, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf);
+  return bjx_check_launch("bjx_nuts_post_ctl");
+}
+
+int bjx_nuts_compact(void* stream, const bjx_nuts_t* nuts, int32_t flag_slot, int64_t n_in,
+                     const int32_t* idx_in, int32_t* idx_out, int64_t* ctl) {
+  if (check_nuts(nuts, "bjx_nuts_compact")) return 1;
+  BJX_CHECK_ARG((flag_slot == BJX_NUTS_I_ACTIVE || flag_slot == BJX_NUTS_I_SUB_ACTIVE) && idx_out &&
+                    ctl && n_in <= nuts->N,
+                "bjx_nuts_compact: bad arguments");
+  hipLaunchKernelGGL(k_nuts_compact, dim3(1), dim3(kCompactThreads), 0, (hipStream_t)stream, *nuts,
+                     (int)flag_slot, n_in, idx_in, idx_out, ctl);
+  return bjx_check_launch("bjx_nuts_compact");
+}
+
+int bjx_nuts_set_ctl(void* stream, int64_t* ctl, int32_t depth, int64_t s_base, int64_t n_rows,
+                     uint32_t key0, uint32_t key1, int64_t step_fold, int64_t chain_offset) {
+  BJX_CHECK_ARG(ctl && depth >= 0 && s_base >= 0, "bjx_nuts_set_ctl: bad arguments");
+  hipLaunchKernelGGL(k_nuts_set_ctl, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, (int64_t)depth,
+                     s_base, n_rows, (int64_t)key0, (int64_t)key1, step_fold, chain_offset);
+  return bjx_check_launch("bjx_nuts_set_ctl");
 }
 
 int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t n_rows,

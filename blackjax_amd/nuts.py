@@ -12,6 +12,13 @@ user's log-density callable and the kernels only see the chains that are still b
 (re-compacted at every doubling and every ``recompact_every`` leapfrogs inside a doubling).
 All tree arithmetic (progressive sampling, momentum sums, U-turn checkpoints, merge) runs in
 ``bjx_nuts.hip``.
+
+Two drivers with identical results:
+* eager (default): three launches per leapfrog (pre, callable, post) issued from Python;
+* ``use_graph=True``: chunks of up to 16 leapfrogs are captured once in HIP graphs over a static
+  workspace and replayed; everything that changes between replays (doubling, leaf index, active
+  row count, keys) lives in a small device control block.  This removes the per-launch host cost,
+  which otherwise dominates because a NUTS transition is hundreds of short launches.
 """
 from __future__ import annotations
 
@@ -28,6 +35,8 @@ from .random import key_spec
 
 __all__ = ["NUTSInfo", "init", "build_kernel", "as_top_level_api"]
 
+_BUFS = ["Lq", "Lp", "Lg", "Rq", "Rp", "Rg", "msum", "Smsum", "Pq", "Pg", "Sq", "Sg"]
+
 
 class NUTSInfo(NamedTuple):
     """blackjax/mcmc/nuts.py:36-74, batched."""
@@ -43,38 +52,130 @@ class NUTSInfo(NamedTuple):
     acceptance_rate: torch.Tensor
 
 
+def _make_info(p0, bufs, fs, is_, clone: bool):
+    F, I = _lib.NUTS_F, _lib.NUTS_I
+    c = (lambda t: t.clone()) if clone else (lambda t: t)
+    info = NUTSInfo(
+        p0,
+        is_[I["DIV"]].bool(),
+        is_[I["TURN"]].bool(),
+        c(fs[F["PENERGY"]]),
+        IntegratorState(c(bufs["Lq"]), c(bufs["Lp"]), c(fs[F["LLOGP"]]), c(bufs["Lg"])),
+        IntegratorState(c(bufs["Rq"]), c(bufs["Rp"]), c(fs[F["RLOGP"]]), c(bufs["Rg"])),
+        c(is_[I["DEPTH"]]),
+        c(is_[I["NSTATES"]]),
+        c(fs[F["ACC"]]),
+    )
+    return HMCState(c(bufs["Pq"]), c(fs[F["PLOGP"]]), c(bufs["Pg"])), info
+
+
+class _GraphWorkspace:
+    """Static device buffers + captured chunk graphs for the ``use_graph`` driver."""
+
+    MAX_CHUNK = 16
+    MIN_BUCKET = 256
+
+    def __init__(self, N, D, max_depth, vg, imm_per_chain, thr, device):
+        self.N, self.D, self.max_depth, self.vg = N, D, max_depth, vg
+        f32 = dict(dtype=torch.float32, device=device)
+        self.bufs = {n: torch.empty((N, D), **f32) for n in _BUFS}
+        self.ck_r = torch.empty((N, max(max_depth, 1), D), **f32)
+        self.ck_rs = torch.empty_like(self.ck_r)
+        self.fs = torch.empty((_lib.NUTS_NF, N), **f32)
+        self.is_ = torch.empty((_lib.NUTS_NI, N), dtype=torch.int32, device=device)
+        self.eps = torch.ones(N, **f32)
+        self.imm = torch.ones((N, D) if imm_per_chain else (D,), **f32)
+        self.idx = torch.arange(N, dtype=torch.int32, device=device)
+        self.qf = torch.zeros((N, D), **f32)
+        self.ctl = torch.zeros(8, dtype=torch.int64, device=device)
+        self.desc = _lib.NutsDesc(
+            N=N, D=D, max_depth=max_depth, reserved=0, imm=self.imm.data_ptr(),
+            imm_stride=D if imm_per_chain else 0, eps_per_chain=self.eps.data_ptr(), eps=0.0,
+            divergence_threshold=thr, key0=0, key1=0, chain_offset=0, step_fold=-1,
+            q0=0, g0=0, p0=0, ckpt_r=self.ck_r.data_ptr(), ckpt_rs=self.ck_rs.data_ptr(),
+            fs=self.fs.data_ptr(), is_=self.is_.data_ptr(),
+            **{n: b.data_ptr() for n, b in self.bufs.items()})
+        self.graphs: dict = {}
+
+    def bucket(self, n_rows: int) -> int:
+        cap = self.MIN_BUCKET
+        while cap < n_rows:
+            cap *= 2
+        return min(cap, self.N)
+
+    def _chunk_body(self, k, n_cap):
+        stream = _lib.current_stream()
+        dref = ctypes.byref(self.desc)
+        qf = self.qf[:n_cap]
+        for i in range(k):
+            _lib.call("bjx_nuts_pre_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
+                      self.ctl.data_ptr(), qf.data_ptr())
+            logp_f, gf = eval_logdensity(self.vg, qf)
+            _lib.call("bjx_nuts_post_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
+                      self.ctl.data_ptr(), qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr())
+        return logp_f, gf
+
+    def chunk_graph(self, k, n_cap):
+        g = self.graphs.get((k, n_cap))
+        if g is None:
+            dev = self.qf.device
+            # capture with n_rows = 0 in the control block: the kernels touch no chain state
+            saved = self.ctl.clone()
+            self.ctl.zero_()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._chunk_body(1, n_cap)  # warm-up outside capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                keep = self._chunk_body(k, n_cap)
+            self.ctl.copy_(saved)
+            g = self.graphs[(k, n_cap)] = (graph, keep)
+        return g[0]
+
+    def set_ctl(self, depth, s_base, n_rows, k0, k1, fold, off):
+        _lib.call("bjx_nuts_set_ctl", _lib.current_stream(), self.ctl.data_ptr(), depth, s_base,
+                  n_rows, k0, k1, fold, off)
+
+
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: int = 1000, *,
-                 recompact_every: int = 16):
-    """blackjax/mcmc/nuts.py:77-147."""
+                 recompact_every: int = 16, use_graph: bool = False, graph_sync_every: int = 4):
+    """blackjax/mcmc/nuts.py:77-147.  ``graph_sync_every``: in graph mode the host reads the
+    active-row count back only every that many 16-leapfrog chunks (to stop early / shrink the
+    callable's batch); compaction itself happens on the device every chunk."""
     integrators.check_supported(integrator)
     thr = float(divergence_threshold)
-    F, I = _lib.NUTS_F, _lib.NUTS_I
+    I = _lib.NUTS_I
+    workspaces: dict = {}
+    sync_every = int(graph_sync_every)
 
-    def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
-               max_num_doublings: int = 10, *, chain_offset: int = 0):
-        """One NUTS transition for all chains (nuts.py:113-145 + iterative_nuts_proposal 278-319)."""
+    def _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset):
         q0 = check_batch(state.position, "state.position")
         logp0 = check_batch(state.logdensity, "state.logdensity")
         g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
         N, D = q0.shape
-        dev = q0.device
-        max_depth = int(max_num_doublings)
         k0, k1, fold = key_spec(rng_key)
         vg = value_and_grad(logdensity_fn)
-        metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
         if metric.kind != "diag":
             raise NotImplementedError("NUTS with a dense mass matrix is not implemented yet")
-        eps, eps_pc = step_size_args(step_size, N, dev)
+        eps, eps_pc = step_size_args(step_size, N, q0.device)
         stream = _lib.current_stream()
-        off = int(chain_offset)
-
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, metric.imm.data_ptr(),
-                  metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
+        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, int(chain_offset), fold, N, D,
+                  metric.imm.data_ptr(), metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
+        return q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0
 
-        names = ["Lq", "Lp", "Lg", "Rq", "Rp", "Rg", "msum", "Smsum", "Pq", "Pg", "Sq", "Sg"]
-        bufs = {n: torch.empty_like(q0) for n in names}
+    def kernel_eager(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+                     inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
+        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0,
+         ke0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
+        dev = q0.device
+        max_depth = int(max_num_doublings)
+        bufs = {n: torch.empty_like(q0) for n in _BUFS}
         ck_r = torch.empty((N, max(max_depth, 1), D), dtype=torch.float32, device=dev)
         ck_rs = torch.empty_like(ck_r)
         fs = torch.empty((_lib.NUTS_NF, N), dtype=torch.float32, device=dev)
@@ -82,8 +183,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=metric.imm.data_ptr(),
             imm_stride=metric.imm_stride, eps_per_chain=_lib.ptr(eps_pc), eps=eps,
-            divergence_threshold=thr, key0=k0, key1=k1, chain_offset=off, step_fold=fold,
-            q0=q0.data_ptr(), g0=g0.data_ptr(), p0=p0.data_ptr(),
+            divergence_threshold=thr, key0=k0, key1=k1, chain_offset=int(chain_offset),
+            step_fold=fold, q0=q0.data_ptr(), g0=g0.data_ptr(), p0=p0.data_ptr(),
             ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(), is_=is_.data_ptr(),
             **{n: b.data_ptr() for n, b in bufs.items()})
         dref = ctypes.byref(desc)
@@ -99,16 +200,14 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     break
             idx_step, n_step = idx_doubling, n_doubling
             qf = torch.empty((n_step, D), dtype=torch.float32, device=dev)
-            n_leaves = 1 << depth
-            for s in range(n_leaves):
+            for s in range(1 << depth):
                 if s > 0 and recompact_every and s % recompact_every == 0:
                     # drop the chains whose subtree has stopped (diverged / turned)
                     sub = is_[I["SUB_ACTIVE"]]
-                    alive = sub.bool() if idx_step is None else sub[idx_step.long()].bool()
                     if idx_step is None:
-                        new_idx = torch.nonzero(alive, as_tuple=False).flatten().to(torch.int32)
+                        new_idx = torch.nonzero(sub, as_tuple=False).flatten().to(torch.int32)
                     else:
-                        new_idx = idx_step[alive]
+                        new_idx = idx_step[sub[idx_step.long()].bool()]
                     n_new = int(new_idx.shape[0])  # host sync
                     if n_new == 0:
                         break
@@ -121,29 +220,69 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                 _lib.call("bjx_nuts_post", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
                           qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr())
             _lib.call("bjx_nuts_merge", stream, dref, depth, n_doubling, _lib.ptr(idx_doubling))
+        return _make_info(p0, bufs, fs, is_, clone=False)
 
-        info = NUTSInfo(
-            p0,
-            is_[I["DIV"]].bool(),
-            is_[I["TURN"]].bool(),
-            fs[F["PENERGY"]],
-            IntegratorState(bufs["Lq"], bufs["Lp"], fs[F["LLOGP"]], bufs["Lg"]),
-            IntegratorState(bufs["Rq"], bufs["Rp"], fs[F["RLOGP"]], bufs["Rg"]),
-            is_[I["DEPTH"]],
-            is_[I["NSTATES"]],
-            fs[F["ACC"]],
-        )
-        return HMCState(bufs["Pq"], fs[F["PLOGP"]], bufs["Pg"]), info
+    def kernel_graph(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+                     inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
+        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0,
+         ke0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
+        max_depth = int(max_num_doublings)
+        off = int(chain_offset)
+        wkey = (N, D, max_depth, id(vg), metric.imm_stride != 0, q0.device.index)
+        ws = workspaces.get(wkey)
+        if ws is None:
+            ws = workspaces[wkey] = _GraphWorkspace(N, D, max_depth, vg, metric.imm_stride != 0, thr,
+                                                    q0.device)
+        if eps_pc is None:
+            ws.eps.fill_(eps)
+        else:
+            ws.eps.copy_(eps_pc)
+        ws.imm.copy_(metric.imm)
+        d = ws.desc
+        d.key0, d.key1, d.chain_offset, d.step_fold = k0, k1, off, fold
+        d.q0, d.g0, d.p0 = q0.data_ptr(), g0.data_ptr(), p0.data_ptr()
+        dref = ctypes.byref(d)
+        _lib.call("bjx_nuts_init", stream, dref, logp0.data_ptr(), ke0.data_ptr())
+        chunk_max = ws.MAX_CHUNK
+        idx_ptr, ctl_ptr = ws.idx.data_ptr(), ws.ctl.data_ptr()
+        for depth in range(max_depth):
+            # chains still doubling -> ws.idx / ctl[2] (device-side compaction)
+            _lib.call("bjx_nuts_compact", stream, dref, I["ACTIVE"], N, None, idx_ptr, ctl_ptr)
+            if depth == 0:
+                n_doubling = N if max_depth > 0 else 0
+            else:
+                n_doubling = int(ws.ctl[2].item())  # host sync, once per doubling
+                if n_doubling == 0:
+                    break
+            idx_doubling = ws.idx[:n_doubling].clone()
+            n_cap = ws.bucket(n_doubling)
+            n_leaves = 1 << depth
+            k = min(chunk_max, n_leaves)
+            for j, s_base in enumerate(range(0, n_leaves, k)):
+                if j > 0:
+                    # drop the chains whose subtree has stopped -- on the device, no host sync
+                    _lib.call("bjx_nuts_compact", stream, dref, I["SUB_ACTIVE"], -1, idx_ptr, idx_ptr,
+                              ctl_ptr)
+                    if sync_every and j % sync_every == 0:
+                        n_now = int(ws.ctl[2].item())  # occasional sync: early exit / smaller bucket
+                        if n_now == 0:
+                            break
+                        n_cap = ws.bucket(n_now)
+                ws.set_ctl(depth, s_base, -1, k0, k1, fold, off)
+                ws.chunk_graph(k, n_cap).replay()
+            _lib.call("bjx_nuts_merge", stream, dref, depth, n_doubling, idx_doubling.data_ptr())
+        return _make_info(p0, ws.bufs, ws.fs, ws.is_, clone=True)
 
-    return kernel
+    return kernel_graph if use_graph else kernel_eager
 
 
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
-                     recompact_every: int = 16) -> SamplingAlgorithm:
+                     recompact_every: int = 16, use_graph: bool = False) -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220."""
-    kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every)
+    kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
+                          use_graph=use_graph)
 
     def init_fn(position, rng_key=None):
         del rng_key

@@ -99,6 +99,31 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
                   const int32_t* idx, const float* qf, const float* logp_f, const float* gf);
 
+/* HIP-graph-replayable variants of bjx_nuts_pre / bjx_nuts_post.  The per-launch parameters that
+ * change between replays are read from a DEVICE control block
+ *     ctl : int64_t[8] = { depth, s_base, n_rows, key0, key1, step_fold, chain_offset, 0 }
+ * so that one captured chunk of k leapfrogs ( [pre_ctl(s_off=i), callable, post_ctl(s_off=i)] for
+ * i = 0..k-1 ) serves every chunk of every transition: leaf index s = s_base + s_off, rows
+ * idx[0 .. min(n_rows, n_cap)) are processed, the key fields of `nuts` are ignored.  idx must be
+ * non-NULL (a caller-owned device buffer whose CONTENTS may change between replays). */
+int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
+                     const int32_t* idx, const int64_t* ctl, float* qf);
+int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
+                      const int32_t* idx, const int64_t* ctl, const float* qf, const float* logp_f,
+                      const float* gf);
+
+/* Device-side active-chain compaction: idx_out <- the chains of idx_in[0..n_in) (identity list if
+ * idx_in is NULL; n_in < 0 means "read the count from ctl[2]") whose `flag_slot`
+ * (BJX_NUTS_I_ACTIVE or BJX_NUTS_I_SUB_ACTIVE) is set, order preserved; the new count is written
+ * to ctl[2].  idx_out may alias idx_in.  No host synchronisation. */
+int bjx_nuts_compact(void* stream, const bjx_nuts_t* nuts, int32_t flag_slot, int64_t n_in,
+                     const int32_t* idx_in, int32_t* idx_out, int64_t* ctl);
+
+/* Stream-ordered update of the control block (a one-thread kernel; no host staging buffer).
+ * n_rows < 0 keeps the count last written by bjx_nuts_compact. */
+int bjx_nuts_set_ctl(void* stream, int64_t* ctl, int32_t depth, int64_t s_base, int64_t n_rows,
+                     uint32_t key0, uint32_t key1, int64_t step_fold, int64_t chain_offset);
+
 /* End of doubling `depth`: biased progressive sampling or sum_log_p_accept update, trajectory
  * merge, U-turn check on the merged trajectory, flags and counters, acceptance rate
  * (trajectory.py:672-715, proposal.py:146-176, metrics.py:272-304, nuts.py:303-305). */

@@ -38,8 +38,8 @@ def _compare(info_g, info_o, st_g, st_o):
         np.testing.assert_allclose(t2n(sg.logdensity), so.logdensity, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("recompact", [0, 3, 16])
-def test_nuts_gaussian_parity(dev, recompact):
+@pytest.mark.parametrize("recompact,use_graph", [(0, False), (3, False), (16, False), (16, True)])
+def test_nuts_gaussian_parity(dev, recompact, use_graph):
     N, D, T = 24, 16, 4
     sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(np.float32)
     inv_var = (np.float32(1) / (sig * sig)).astype(np.float32)
@@ -48,7 +48,8 @@ def test_nuts_gaussian_parity(dev, recompact):
     q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(np.float32)
     st_o = ohmc.init(q0, fn_o)
     alg = bjx.nuts(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), 0.15, dev_t(imm, dev),
-                   max_num_doublings=7, chain_offset=5, recompact_every=recompact)
+                   max_num_doublings=7, chain_offset=5, recompact_every=recompact,
+                   use_graph=use_graph)
     st_g = alg.init(dev_t(q0, dev))
     depths = []
     for k in prng.split(prng.key(0), T):
@@ -59,7 +60,8 @@ def test_nuts_gaussian_parity(dev, recompact):
     assert len(set(depths)) > 1  # chains stopped at different depths: compaction was exercised
 
 
-def test_nuts_funnel_parity_per_chain_params(dev):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_nuts_funnel_parity_per_chain_params(dev, use_graph):
     """Scaled-down configs[2]: Neal's funnel; per-chain step size and per-chain diagonal imm;
     includes chains that hit max depth and chains that diverge."""
     N, D, T = 16, 10, 3
@@ -71,7 +73,8 @@ def test_nuts_funnel_parity_per_chain_params(dev):
     imm = rng.uniform(0.5, 2.0, (N, D)).astype(np.float32)
     q0 = (0.1 * prng.normal(prng.key(2), (N, D))).astype(np.float32)
     st_o = ohmc.init(q0, fn_o)
-    alg = bjx.nuts(bjx.targets.NealFunnel(), dev_t(eps, dev), dev_t(imm, dev), max_num_doublings=5)
+    alg = bjx.nuts(bjx.targets.NealFunnel(), dev_t(eps, dev), dev_t(imm, dev), max_num_doublings=5,
+                   use_graph=use_graph)
     st_g = alg.init(dev_t(q0, dev))
     assert np.allclose(t2n(st_g.logdensity), st_o.logdensity, rtol=1e-6)
     seen_div = seen_max = False

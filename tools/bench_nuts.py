@@ -22,11 +22,13 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--eps", type=float, default=0.1)
 ap.add_argument("--max-depth", type=int, default=10)
 ap.add_argument("--recompact", type=int, default=16)
+ap.add_argument("--use-graph", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 N, D = args.chains, args.dim
 alg = bjx.nuts(bjx.targets.NealFunnel(), args.eps, torch.ones(D, device=dev),
-               max_num_doublings=args.max_depth, recompact_every=args.recompact)
+               max_num_doublings=args.max_depth, recompact_every=args.recompact,
+               use_graph=args.use_graph)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=g))
@@ -35,14 +37,15 @@ for t in range(args.warmup):
     state, info = alg.step(keys[t], state)
 torch.cuda.synchronize()
 timer = _lib.LaunchTimer(["bjx_nuts_pre", "bjx_nuts_post"])
-_lib.set_timer(timer)
+if not args.use_graph:
+    _lib.set_timer(timer)
 tot_steps = 0
 launches = 0
 t0 = time.perf_counter()
 for t in range(args.warmup, args.warmup + args.steps):
     state, info = alg.step(keys[t], state)
     tot_steps += int(info.num_integration_steps.sum())
-    launches += len(timer.events["bjx_nuts_pre"]) - launches
+    launches = len(timer.events["bjx_nuts_pre"])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 _lib.set_timer(None)
@@ -54,8 +57,9 @@ print(json.dumps({
                "recompact_every": args.recompact},
     "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
     "mean_leapfrogs_per_chain_transition": tot_steps / (N * args.steps),
-    "leapfrog_launches_per_transition": launches / args.steps,
-    "lockstep_utilisation_vs_uncompacted": tot_steps / (N * launches),
+    "leapfrog_launches_per_transition": launches / args.steps if launches else None,
+    "lockstep_utilisation_vs_uncompacted": tot_steps / (N * launches) if launches else None,
+    "hip_graph": bool(args.use_graph),
     "pre_kernel_total_ms": sum(pre), "post_kernel_total_ms": sum(post),
     "mean_depth": float(info.num_trajectory_expansions.float().mean()),
     "frac_divergent": float(info.is_divergent.float().mean()),
