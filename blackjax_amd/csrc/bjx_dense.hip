@@ -18,6 +18,7 @@ using namespace bjx;
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int EPT = BK / 2;  // staged elements per thread and operand: BM*BK/256 = BK*BN/256
 constexpr int LDA = BM + 1;  // padded k-major A tile: As[k][m]
 constexpr int LDB = BN;      // Bs[k][n]
 constexpr int kThreads = 256;
@@ -47,89 +48,114 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t row0 = (int64_t)blockIdx.y * BM;
-  const int64_t col0 = (int64_t)blockIdx.x * BN;
+  // XCD-aware tile order (speed only): workgroup b is observed to run on XCD b % 8 and each XCD
+  // has its own L2.  All column blocks of one row panel are mapped to the same XCD at adjacent
+  // dispatch slots so the panel's P/G tiles are fetched from HBM once and shared through that L2
+  // instead of being re-read by every column block from a different XCD.
+  const int64_t n_col = (a.D + BN - 1) / BN, n_row = (a.M + BM - 1) / BM;
+  const int64_t lin = blockIdx.x;
+  int64_t row_blk, col_blk;
+  {
+    const int64_t full = (n_row / 8) * 8 * n_col;  // blocks covered by complete groups of 8 panels
+    if (lin < full) {
+      const int64_t xcd = lin % 8, slot = lin / 8;
+      col_blk = slot % n_col;
+      row_blk = (slot / n_col) * 8 + xcd;
+    } else {  // ragged tail: plain row-major order
+      const int64_t r = lin - full;
+      row_blk = (n_row / 8) * 8 + r / n_col;
+      col_blk = r % n_col;
+    }
+  }
+  const int64_t row0 = row_blk * BM;
+  const int64_t col0 = col_blk * BN;
   const int64_t D = a.D;
 
   // global->register staging assignments
-  const int a_row = tid >> 1, a_k = (tid & 1) * 8;   // A tile: 128 rows x 16 k, 8 k per thread
-  const int b_k = tid >> 4, b_n = (tid & 15) * 8;    // B tile: 16 k x 128 n, 8 n per thread
+  const int a_row = tid >> 1, a_k = (tid & 1) * EPT;              // A tile: 128 rows x BK, EPT k per thread
+  const int b_k = tid / (BN / EPT), b_n = (tid % (BN / EPT)) * EPT;  // B tile: BK x 128, EPT n per thread
   const int64_t g_row = row0 + a_row;
   const bool row_ok = g_row < a.M;
   float h = 0.0f;
   if (a.n_kicks > 0 && row_ok) h = (a.eps_pc ? a.eps_pc[g_row] : a.eps) * 0.5f;
 
-  float ra[8], rb[8];
+  // Staging is split (issue early / consume late): load_tiles only ISSUES the global loads of the
+  // next K-tile; the kick fma, the A_out store and the LDS writes happen in store_tiles AFTER the
+  // MFMA phase of the current tile, so HBM/L2 latency hides under the matrix math.
+  float ra[EPT], rg[EPT], rb[EPT];
+  int64_t cur_kk = 0;
   auto load_tiles = [&](int64_t k0) {
-    // ---- A (with kick prologue)
+    cur_kk = k0 + a_k;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ra[e] = 0.0f;
+    for (int e = 0; e < EPT; ++e) { ra[e] = 0.0f; rg[e] = 0.0f; rb[e] = 0.0f; }
     if (row_ok) {
-      const int64_t kk = k0 + a_k;
+      const int64_t kk = cur_kk;
       const float* ap = a.A + g_row * D + kk;
-      float rg[8];
-      if (ALIGNED && kk + 8 <= D) {
-        const F4 x0 = ld4(ap), x1 = ld4(ap + 4);
-        ra[0] = x0.x; ra[1] = x0.y; ra[2] = x0.z; ra[3] = x0.w;
-        ra[4] = x1.x; ra[5] = x1.y; ra[6] = x1.z; ra[7] = x1.w;
+      if (ALIGNED && kk + EPT <= D) {
+#pragma unroll
+        for (int v = 0; v < EPT / 4; ++v) {
+          const F4 x = ld4(ap + 4 * v);
+          ra[4 * v] = x.x; ra[4 * v + 1] = x.y; ra[4 * v + 2] = x.z; ra[4 * v + 3] = x.w;
+        }
         if (a.n_kicks > 0) {
           const float* gp = a.G + g_row * D + kk;
-          const F4 g0 = ld4(gp), g1 = ld4(gp + 4);
-          rg[0] = g0.x; rg[1] = g0.y; rg[2] = g0.z; rg[3] = g0.w;
-          rg[4] = g1.x; rg[5] = g1.y; rg[6] = g1.z; rg[7] = g1.w;
+#pragma unroll
+          for (int v = 0; v < EPT / 4; ++v) {
+            const F4 x = ld4(gp + 4 * v);
+            rg[4 * v] = x.x; rg[4 * v + 1] = x.y; rg[4 * v + 2] = x.z; rg[4 * v + 3] = x.w;
+          }
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           if (kk + e < D) {
             ra[e] = ap[e];
-            rg[e] = a.n_kicks > 0 ? a.G[g_row * D + kk + e] : 0.0f;
-          } else {
-            rg[e] = 0.0f;
-          }
-        }
-      }
-      if (a.n_kicks > 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ra[e] = fmaf(h, rg[e], ra[e]);
-          if (a.n_kicks == 2) ra[e] = fmaf(h, rg[e], ra[e]);
-        }
-        if (a.A_out && blockIdx.x == 0) {
-          float* op = a.A_out + g_row * D + kk;
-          if (ALIGNED && kk + 8 <= D) {
-            st4(op, F4{ra[0], ra[1], ra[2], ra[3]});
-            st4(op + 4, F4{ra[4], ra[5], ra[6], ra[7]});
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (kk + e < D) op[e] = ra[e];
+            if (a.n_kicks > 0) rg[e] = a.G[g_row * D + kk + e];
           }
         }
       }
     }
-    // ---- B
-#pragma unroll
-    for (int e = 0; e < 8; ++e) rb[e] = 0.0f;
     const int64_t bk = k0 + b_k, bn = col0 + b_n;
     if (bk < D) {
       const float* bp = a.B + bk * D + bn;
-      if (ALIGNED && bn + 8 <= D) {
-        const F4 x0 = ld4(bp), x1 = ld4(bp + 4);
-        rb[0] = x0.x; rb[1] = x0.y; rb[2] = x0.z; rb[3] = x0.w;
-        rb[4] = x1.x; rb[5] = x1.y; rb[6] = x1.z; rb[7] = x1.w;
+      if (ALIGNED && bn + EPT <= D) {
+#pragma unroll
+        for (int v = 0; v < EPT / 4; ++v) {
+          const F4 x = ld4(bp + 4 * v);
+          rb[4 * v] = x.x; rb[4 * v + 1] = x.y; rb[4 * v + 2] = x.z; rb[4 * v + 3] = x.w;
+        }
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int e = 0; e < EPT; ++e)
           if (bn + e < D) rb[e] = bp[e];
       }
     }
   };
   auto store_tiles = [&](int buf) {
+    if (a.n_kicks > 0 && row_ok) {  // kick prologue on the staged A values
 #pragma unroll
-    for (int e = 0; e < 8; ++e) As[buf][(a_k + e) * LDA + a_row] = ra[e];
+      for (int e = 0; e < EPT; ++e) {
+        ra[e] = fmaf(h, rg[e], ra[e]);
+        if (a.n_kicks == 2) ra[e] = fmaf(h, rg[e], ra[e]);
+      }
+      if (a.A_out && col_blk == 0) {
+        const int64_t kk = cur_kk;
+        float* op = a.A_out + g_row * D + kk;
+        if (ALIGNED && kk + EPT <= D) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Bs[buf][b_k * LDB + b_n + e] = rb[e];
+          for (int v = 0; v < EPT / 4; ++v)
+            st4(op + 4 * v, F4{ra[4 * v], ra[4 * v + 1], ra[4 * v + 2], ra[4 * v + 3]});
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPT; ++e)
+            if (kk + e < D) op[e] = ra[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) As[buf][(a_k + e) * LDA + a_row] = ra[e];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) Bs[buf][b_k * LDB + b_n + e] = rb[e];
   };
 
   f32x16 acc[2][2];
@@ -150,16 +176,31 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
     if (t + 1 < n_tiles) load_tiles((t + 1) * BK);
     const float* as = As[buf];
     const float* bs = Bs[buf];
+    // LDS operand reads for the whole K-tile are issued up front (32 VGPRs) so the MFMAs below
+    // run back to back instead of waiting on an LDS round trip before every pair.
+    float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[(kk + lk) * LDA + wm * 64 + lm];
-      const float a1 = as[(kk + lk) * LDA + wm * 64 + 32 + lm];
-      const float b0 = bs[(kk + lk) * LDB + wn * 64 + lm];
-      const float b1 = bs[(kk + lk) * LDB + wn * 64 + 32 + lm];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int u = 0; u < BK / 2; ++u) {
+      const int kk = 2 * u;
+      fa0[u] = as[(kk + lk) * LDA + wm * 64 + lm];
+      fa1[u] = as[(kk + lk) * LDA + wm * 64 + 32 + lm];
+      fb0[u] = bs[(kk + lk) * LDB + wn * 64 + lm];
+      fb1[u] = bs[(kk + lk) * LDB + wn * 64 + 32 + lm];
+    }
+#pragma unroll
+    for (int u = 0; u < BK / 2; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb1[u], acc[1][1], 0, 0, 0);
+    }
+    // Pin the interleave (LLVM otherwise sinks every LDS read next to its MFMA and waits on it):
+    // two K-steps of operand reads up front, then 4 MFMAs per 2 further (paired) LDS reads.
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int u = 0; u < BK / 2; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
     if (t + 1 < n_tiles) store_tiles(buf ^ 1);
     __syncthreads();
@@ -269,7 +310,7 @@ k_hmc_finish_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, flo
 }
 
 int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
-  const dim3 grid((unsigned)((ga.D + BN - 1) / BN), (unsigned)((ga.M + BM - 1) / BM));
+  const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B);
   if (epi == EPI_STORE) {
     if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true>), grid, dim3(kThreads), 0, s, ga);

@@ -244,3 +244,75 @@ def test_chain_block_tiling_is_invisible(dev):
                 assert torch.equal(x, y)
             for x, y in zip(i1.proposal, ix.proposal):
                 assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------ full-size (BASELINE.json configs[1]) properties
+FULL_N, FULL_D = 65536, 1024
+
+
+def _full_setup(dev):
+    sig = sigma_ladder(FULL_D)
+    imm = dev_t(sig * sig, dev)
+    fn = bjx.targets.DiagGaussian(dev_t(1.0 / (sig * sig), dev))
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    q0 = dev_t(sig, dev) * torch.randn(FULL_N, FULL_D, device=dev, generator=g)
+    return sig, imm, fn, q0
+
+
+def test_full_size_sharding_invariance_and_determinism(dev):
+    """At 65 536 x 1 024: (a) the same seed twice gives bit-identical output; (b) running the chain
+    range as two shards with chain_offset (what two GPUs would do) reproduces the unsharded
+    transition bit for bit -- results do not depend on the number of ranks."""
+    sig, imm, fn, q0 = _full_setup(dev)
+    L = 5
+    key = bjx.random.key(2024)
+    alg = bjx.hmc(fn, 0.25, imm, L)
+    st0 = alg.init(q0)
+    s1, i1 = alg.step(key, st0)
+    s2, i2 = alg.step(key, st0)
+    assert torch.equal(s1.position, s2.position) and torch.equal(i1.is_accepted, i2.is_accepted)
+    half = FULL_N // 2
+    outs = []
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        a = bjx.hmc(fn, 0.25, imm, L, chain_offset=r * half)
+        sr, ir = a.step(key, bjx.hmc.init(q0[sl].contiguous(), fn))
+        outs.append((sr, ir))
+    assert torch.equal(torch.cat([o[0].position for o in outs]), s1.position)
+    assert torch.equal(torch.cat([o[1].is_accepted for o in outs]), i1.is_accepted)
+    assert torch.equal(torch.cat([o[1].acceptance_rate for o in outs]), i1.acceptance_rate)
+    acc = i1.acceptance_rate.mean().item()
+    assert 0.5 < acc <= 1.0 + 1e-5
+
+
+def test_full_size_leapfrog_reversibility_and_energy(dev):
+    """Size-independent integrator properties at 65 536 x 1 024: integrating L steps, flipping the
+    momentum and integrating L more steps returns to the start (velocity-Verlet is time
+    reversible) and the Hamiltonian is conserved to O(eps^2)."""
+    sig, imm, fn, q0 = _full_setup(dev)
+    N, D, L, eps = FULL_N, FULL_D, 10, 0.25
+    s = _lib.current_stream()
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    p0 = torch.randn(N, D, device=dev, generator=g) / dev_t(sig, dev)
+    logp0, grad = fn(q0)
+    h0 = -logp0 + 0.5 * (imm * p0 * p0).sum(-1)
+
+    def integrate(q, p, grad, steps):
+        q, p = q.clone(), p.clone()
+        for i in range(steps):
+            _lib.call("bjx_leapfrog_diag", s, N, D, 1 if i == 0 else 2, eps, None, imm.data_ptr(), 0,
+                      q.data_ptr(), p.data_ptr(), grad.data_ptr(), q.data_ptr(), p.data_ptr())
+            logp, grad = fn(q)
+        p = p + (eps * 0.5) * grad  # closing half kick
+        return q, p, logp, grad
+
+    q1, p1, logp1, g1 = integrate(q0, p0, grad, L)
+    h1 = -logp1 + 0.5 * (imm * p1 * p1).sum(-1)
+    rel = ((h1 - h0).abs() / h0.abs()).max().item()
+    assert rel < 5e-3
+    q2, p2, _, _ = integrate(q1, -p1, g1, L)
+    scale = dev_t(sig, dev)
+    assert ((q2 - q0).abs() / scale).max().item() < 2e-4
+    assert ((p2 + p0).abs() * scale).max().item() < 2e-4
