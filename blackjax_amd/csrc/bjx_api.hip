@@ -19,7 +19,7 @@ unsigned bjx_row_grid(int64_t n_rows, int waves_per_block) {
   static const int64_t cap = [] {
     const char* e = getenv("BJX_MAX_BLOCKS");
     int64_t v = e ? atoll(e) : 0;
-    return v > 0 ? v : (int64_t)256 * 16;
+    return v > 0 ? v : (int64_t)256 * 256;  // measured on MI355X: one row per wave (no grid-stride) is 2-3 % faster than a 4096-block cap
   }();
   int64_t blocks = (n_rows + waves_per_block - 1) / waves_per_block;
   if (blocks < 1) blocks = 1;

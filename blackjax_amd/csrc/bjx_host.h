@@ -25,7 +25,7 @@ static inline int bjx_check_launch(const char* what) {
 }
 
 // Row-per-wave kernels: enough workgroups to cover every CU several times over
-// (256 CUs x 8 resident 256-thread workgroups), grid-stride beyond that.
+// several times over; grid-stride only beyond 65536 workgroups (BJX_MAX_BLOCKS overrides).
 unsigned bjx_row_grid(int64_t n_rows, int waves_per_block);
 
 // 16-byte vector path is legal when D % 4 == 0 and every non-null pointer is 16-B aligned.

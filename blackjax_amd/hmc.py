@@ -120,6 +120,9 @@ class _GraphedTrajectory:
             _lib.call("bjx_leapfrog_diag", stream, self.n, self.D, 2, 0.0, self.eps.data_ptr(),
                       self.imm.data_ptr(), self.imm_stride, self.Wq.data_ptr(), self.Wp.data_ptr(),
                       g.data_ptr(), self.Wq.data_ptr(), self.Wp.data_ptr())
+            # release the consumed gradient first so the (stream-ordered) allocator hands the same
+            # block to the callable again: the block's working set stays q, p, g (3 arrays)
+            del logp, g
             logp, g = eval_logdensity(self._vg, self.Wq)
         return logp, g
 
