@@ -84,10 +84,10 @@ SIGNATURES.update({
     "bjx_nuts_init": [c_void_p, POINTER(NutsDesc), _f32p, _f32p],
     "bjx_nuts_pre": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p],
     "bjx_nuts_post": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p,
-                      _f32p, _f32p],
+                      _f32p, _f32p, ctypes.c_int32],
     "bjx_nuts_pre_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p],
     "bjx_nuts_post_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p,
-                          _f32p, _f32p],
+                          _f32p, _f32p, ctypes.c_int32],
     "bjx_nuts_compact": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p,
                          c_void_p],
     "bjx_nuts_set_ctl": [c_void_p, c_void_p, ctypes.c_int32, c_int64, c_int64, c_uint32, c_uint32,

@@ -168,9 +168,8 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 // ------------------------------------------------------------------------------------ post
 __global__ void __launch_bounds__(kBlock)
 k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
-            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl,
-            const float* __restrict__ qf, const float* __restrict__ logp_f,
-            const float* __restrict__ gf) {
+            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* qf,
+            const float* __restrict__ logp_f, const float* __restrict__ gf, int fuse_next) {
   const int lane = threadIdx.x & 63;
   const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
   const int32_t depth = cx.depth, s = cx.s;
@@ -186,7 +185,7 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
     const float* im = nt.imm + c * nt.imm_stride;
     const float* gn = gf + b * nt.D;
-    const float* qn = qf + b * nt.D;
+    float* qn = qf + b * nt.D;
 
     // pass 1: closing half kick, store the new end state, kinetic energy
     double acc = 0.0;
@@ -280,6 +279,19 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
       IS(BJX_NUTS_I_SDIV, c) = sdiv ? 1 : 0;
       IS(BJX_NUTS_I_STURN, c) = turning ? 1 : 0;
       if (sdiv || turning) IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+    }
+
+    // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
+    // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
+    if (fuse_next && !(sdiv || turning)) {
+      float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float pn = fmaf(h, gn[j], fp[j]);
+        const float qv = fmaf(deps, im[j] * pn, fq[j]);
+        fp[j] = pn;
+        fq[j] = qv;
+        qn[j] = qv;
+      }
     }
   }
 }
@@ -439,7 +451,8 @@ int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_
 }
 
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
-                  const int32_t* idx, const float* qf, const float* logp_f, const float* gf) {
+                  const int32_t* idx, float* qf, const float* logp_f, const float* gf,
+                  int32_t fuse_next) {
   if (check_nuts(nuts, "bjx_nuts_post")) return 1;
   BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && s >= 0 && s < ((int64_t)1 << depth) &&
                     n_rows >= 0 && n_rows <= nuts->N && qf && logp_f && gf,
@@ -447,19 +460,21 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
   if (n_rows == 0) return 0;
   hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx,
-                     (const int64_t*)nullptr, qf, logp_f, gf);
+                     (const int64_t*)nullptr, qf, logp_f, gf,
+                     (int)(fuse_next && s + 1 < ((int64_t)1 << depth)));
   return bjx_check_launch("bjx_nuts_post");
 }
 
 int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
-                      const int32_t* idx, const int64_t* ctl, const float* qf, const float* logp_f,
-                      const float* gf) {
+                      const int32_t* idx, const int64_t* ctl, float* qf, const float* logp_f,
+                      const float* gf, int32_t fuse_next) {
   if (check_nuts(nuts, "bjx_nuts_post_ctl")) return 1;
   BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf && logp_f && gf,
                 "bjx_nuts_post_ctl: bad arguments");
   if (n_cap == 0) return 0;
   hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_cap, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf);
+                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf,
+                     (int)fuse_next);
   return bjx_check_launch("bjx_nuts_post_ctl");
 }
 

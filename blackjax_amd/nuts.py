@@ -107,12 +107,14 @@ class _GraphWorkspace:
         stream = _lib.current_stream()
         dref = ctypes.byref(self.desc)
         qf = self.qf[:n_cap]
+        _lib.call("bjx_nuts_pre_ctl", stream, dref, 0, n_cap, self.idx.data_ptr(),
+                  self.ctl.data_ptr(), qf.data_ptr())
         for i in range(k):
-            _lib.call("bjx_nuts_pre_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
-                      self.ctl.data_ptr(), qf.data_ptr())
             logp_f, gf = eval_logdensity(self.vg, qf)
+            # post(i) fused with pre(i+1) inside the chunk (row order is fixed within a chunk)
             _lib.call("bjx_nuts_post_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
-                      self.ctl.data_ptr(), qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr())
+                      self.ctl.data_ptr(), qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr(),
+                      1 if i < k - 1 else 0)
         return logp_f, gf
 
     def chunk_graph(self, k, n_cap):
@@ -200,7 +202,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     break
             idx_step, n_step = idx_doubling, n_doubling
             qf = torch.empty((n_step, D), dtype=torch.float32, device=dev)
-            for s in range(1 << depth):
+            n_leaves = 1 << depth
+            need_pre = True
+            for s in range(n_leaves):
                 if s > 0 and recompact_every and s % recompact_every == 0:
                     # drop the chains whose subtree has stopped (diverged / turned)
                     sub = is_[I["SUB_ACTIVE"]]
@@ -214,11 +218,16 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     if n_new < n_step:
                         idx_step, n_step = new_idx.contiguous(), n_new
                         qf = qf[:n_step]
-                _lib.call("bjx_nuts_pre", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
-                          qf.data_ptr())
+                if need_pre:
+                    _lib.call("bjx_nuts_pre", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
+                              qf.data_ptr())
                 logp_f, gf = eval_logdensity(vg, qf)
+                # fuse the next leaf's opening half into post unless rows are re-compacted before it
+                nxt = s + 1
+                fuse = nxt < n_leaves and not (recompact_every and nxt % recompact_every == 0)
                 _lib.call("bjx_nuts_post", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
-                          qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr())
+                          qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr(), 1 if fuse else 0)
+                need_pre = not fuse
             _lib.call("bjx_nuts_merge", stream, dref, depth, n_doubling, _lib.ptr(idx_doubling))
         return _make_info(p0, bufs, fs, is_, clone=False)
 

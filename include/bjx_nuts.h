@@ -95,22 +95,27 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
 /* Closing half: p += (dir*eps/2) g_new; proposal weight, divergence, progressive uniform sampling
  * (key fold_in(trajectory_key, s)), momentum-sum append, checkpoint update and iterative U-turn
  * (trajectory.py:321-346, proposal.py:68-103,118-143, termination.py:56-104).
- * logp_f (n_rows,), gf (n_rows, D): callable outputs for the compact rows. */
+ * logp_f (n_rows,), gf (n_rows, D): callable outputs for the compact rows.
+ * fuse_next != 0: for chains whose subtree keeps integrating, also perform the opening half of
+ * leapfrog s + 1 (exactly bjx_nuts_pre's arithmetic; the new position overwrites qf[b]) so the
+ * caller skips the bjx_nuts_pre launch of the next leaf.  Ignored at the last leaf of a doubling.
+ * The caller must not fuse across a re-compaction of idx (row order of qf would change). */
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
-                  const int32_t* idx, const float* qf, const float* logp_f, const float* gf);
+                  const int32_t* idx, float* qf, const float* logp_f, const float* gf,
+                  int32_t fuse_next);
 
 /* HIP-graph-replayable variants of bjx_nuts_pre / bjx_nuts_post.  The per-launch parameters that
  * change between replays are read from a DEVICE control block
  *     ctl : int64_t[8] = { depth, s_base, n_rows, key0, key1, step_fold, chain_offset, 0 }
- * so that one captured chunk of k leapfrogs ( [pre_ctl(s_off=i), callable, post_ctl(s_off=i)] for
- * i = 0..k-1 ) serves every chunk of every transition: leaf index s = s_base + s_off, rows
+ * so that one captured chunk of k leapfrogs ( pre_ctl(s_off=0), then [callable, post_ctl(s_off=i,
+ * fuse_next = i < k-1)] for i = 0..k-1 ) serves every chunk of every transition: leaf index s = s_base + s_off, rows
  * idx[0 .. min(n_rows, n_cap)) are processed, the key fields of `nuts` are ignored.  idx must be
  * non-NULL (a caller-owned device buffer whose CONTENTS may change between replays). */
 int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
                      const int32_t* idx, const int64_t* ctl, float* qf);
 int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
-                      const int32_t* idx, const int64_t* ctl, const float* qf, const float* logp_f,
-                      const float* gf);
+                      const int32_t* idx, const int64_t* ctl, float* qf, const float* logp_f,
+                      const float* gf, int32_t fuse_next);
 
 /* Device-side active-chain compaction: idx_out <- the chains of idx_in[0..n_in) (identity list if
  * idx_in is NULL; n_in < 0 means "read the count from ctl[2]") whose `flag_slot`
