@@ -8,7 +8,8 @@ mass-matrix estimator (adaptation/mass_matrix.py:111-444).
 
 Semantics: adaptation is PER CHAIN, exactly as in the reference where many chains means
 ``jax.vmap(warmup.run)(jax.random.split(rng_key, N), positions)``: every chain owns a step size
-and a (diagonal) inverse mass matrix; chain ``i`` uses key ``split(split(rng_key, N)[i], T)[t]``
+and an inverse mass matrix (diagonal ``(N, D)``, or dense ``(N, D, D)`` with
+``is_mass_matrix_diagonal=False``); chain ``i`` uses key ``split(split(rng_key, N)[i], T)[t]``
 at step ``t`` (chain-major layout).  No collective is needed when chains
 are sharded over GPUs.  All per-chain arithmetic runs in HIP kernels (``bjx_adapt.hip``).
 """
@@ -138,23 +139,31 @@ def _da_update(ss: DualAveragingAdaptationState, acceptance_rate: torch.Tensor, 
 
 
 def _welford_update(wc: WelfordAlgorithmState, position: torch.Tensor) -> WelfordAlgorithmState:
+    """mass_matrix.py:410-435; ``wc.m2`` is (N, D) [diagonal] or (N, D, D) [dense]."""
     n, d = position.shape
-    mean, m2 = torch.empty_like(position), torch.empty_like(position)
-    _lib.call("bjx_welford_update_diag", _lib.current_stream(), n, d, wc.sample_size + 1,
-              position.data_ptr(), wc.mean.data_ptr(), wc.m2.data_ptr(), mean.data_ptr(),
-              m2.data_ptr())
+    mean, m2 = torch.empty_like(position), torch.empty_like(wc.m2)
+    name = "bjx_welford_update_diag" if wc.m2.ndim == 2 else "bjx_welford_update_dense"
+    _lib.call(name, _lib.current_stream(), n, d, wc.sample_size + 1, position.data_ptr(),
+              wc.mean.data_ptr(), wc.m2.data_ptr(), mean.data_ptr(), m2.data_ptr())
     return WelfordAlgorithmState(mean, m2, wc.sample_size + 1)
 
 
 def _mm_final(mm: MassMatrixAdaptationState, shrinkage: float) -> MassMatrixAdaptationState:
-    n, d = mm.wc_state.m2.shape
-    imm = torch.empty_like(mm.wc_state.m2)
+    """mass_matrix.py:335-357 (diagonal and dense)."""
+    m2 = mm.wc_state.m2
+    n, d = m2.shape[0], m2.shape[1]
+    imm = torch.empty_like(m2)
     prev = mm.inverse_mass_matrix
-    _lib.call("bjx_welford_final_diag", _lib.current_stream(), n, d, mm.wc_state.sample_size,
-              float(shrinkage), mm.wc_state.m2.data_ptr(), prev.data_ptr(),
-              0 if prev.ndim == 1 else d, imm.data_ptr())
-    zeros = torch.zeros_like(imm)
-    return MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, torch.zeros_like(imm), 0))
+    if m2.ndim == 2:
+        _lib.call("bjx_welford_final_diag", _lib.current_stream(), n, d, mm.wc_state.sample_size,
+                  float(shrinkage), m2.data_ptr(), prev.data_ptr(), 0 if prev.ndim == 1 else d,
+                  imm.data_ptr())
+    else:
+        _lib.call("bjx_welford_final_dense", _lib.current_stream(), n, d, mm.wc_state.sample_size,
+                  float(shrinkage), m2.data_ptr(), prev.data_ptr(), 1 if prev.ndim == 3 else 0,
+                  imm.data_ptr())
+    mean0 = torch.zeros_like(mm.wc_state.mean)
+    return MassMatrixAdaptationState(imm, WelfordAlgorithmState(mean0, torch.zeros_like(m2), 0))
 
 
 def _stack_history(history):
@@ -202,10 +211,6 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
     if imm_shrinkage_to_previous < 0.0:
         raise ValueError(
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
-    if not is_mass_matrix_diagonal:
-        raise NotImplementedError(
-            "per-chain DENSE mass-matrix adaptation (welford_dense) is not implemented yet: it needs "
-            "N x D x D state; use is_mass_matrix_diagonal=True (see DESIGN.md)")
     integrators.check_supported(integrator)
     mcmc_kernel = algorithm.build_kernel(integrator)
 
@@ -217,22 +222,28 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         state = algorithm.init(position, logdensity_fn)
         # adapt_init: staged_adaptation.py:173-184
         if initial_inverse_mass_matrix is None:
-            imm = torch.ones(d, dtype=torch.float32, device=position.device)
+            if is_mass_matrix_diagonal:
+                imm = torch.ones(d, dtype=torch.float32, device=position.device)
+            else:  # mass_matrix.py:243-244: identity, shared by all chains until the first window end
+                imm = torch.eye(d, dtype=torch.float32, device=position.device)
         else:
             imm = torch.as_tensor(initial_inverse_mass_matrix, dtype=torch.float32,
                                   device=position.device).contiguous()
         eps0 = torch.full((n,), float(initial_step_size), dtype=torch.float32, device=position.device)
         ss, _ = _da_init(eps0, from_log_avg=False)
         zeros = torch.zeros_like(position)
+        # Welford second moments: (N, D) diagonal, or (N, D, D) dense -- one matrix PER CHAIN, the
+        # semantics of a vmapped dense warmup (N * D^2 words: meant for moderate N * D^2)
+        m2_0 = (torch.zeros_like(position) if is_mass_matrix_diagonal
+                else torch.zeros((n, d, d), dtype=torch.float32, device=position.device))
         ws = StagedAdaptationState(
-            ss, MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, torch.zeros_like(position), 0)),
-            eps0, imm)
+            ss, MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, m2_0, 0)), eps0, imm)
         history = []
         info = None
         for t, (stage, is_window_end) in enumerate(build_schedule(int(num_steps))):
             # one_step: staged_adaptation.py:731-754
             imm_arg = ws.inverse_mass_matrix
-            if imm_arg.ndim == 2:  # per-chain diagonals (never a dense matrix on this path)
+            if is_mass_matrix_diagonal and imm_arg.ndim == 2:  # per-chain diagonals, not a dense matrix
                 imm_arg = metrics.PerChainDiag(imm_arg)
             state, info = mcmc_kernel(ChainMajorKey(run_key, t), state, logdensity_fn, ws.step_size,
                                       imm_arg, chain_offset=chain_offset, **extra_parameters)
@@ -255,6 +266,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         imm_final = ws.imm_state.inverse_mass_matrix
         if imm_final.ndim == 1:  # fewer than 20 steps: no window ever ended
             imm_final = imm_final.expand(n, d).contiguous()
+        elif not is_mass_matrix_diagonal and imm_final.ndim == 2:
+            imm_final = imm_final.expand(n, d, d).contiguous()
         parameters = {"step_size": step_size, "inverse_mass_matrix": imm_final, **extra_parameters}
         return AdaptationResults(state, parameters), _stack_history(history)
 

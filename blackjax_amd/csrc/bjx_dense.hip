@@ -309,6 +309,130 @@ k_hmc_finish_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PER-CHAIN dense metric (one (D, D) matrix per chain: what a vmapped dense window_adaptation
+// produces).  Each chain has its own matrix, so this is a batched matrix-vector product, bound by
+// reading D^2 words per chain, not by MFMA.  One wave per chain: x (after the optional kick) is
+// staged in LDS, lane i accumulates y_i = sum_j M[j][i] x_j in fp64 (row j is read coalesced; for
+// the symmetric inverse mass matrix M^T = M, for the momentum draw M = L^{-1} gives L^{-T} z).
+// The fp64 accumulation makes this path bit-compatible with the oracle's reductions.
+struct PcArgs {
+  int64_t N, D;
+  const float* M;       // (N, D, D)
+  const float* X;       // (N, D)
+  const float* G;       // gradient for the kick prologue or nullptr
+  int n_kicks;
+  float eps;
+  const float* eps_pc;
+  float* X_out;         // kicked x or nullptr (may alias X)
+  float* Y;             // EPI_STORE
+  const float* Q_in;    // EPI_DRIFT
+  float* Q_out;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(kBlock) k_pc_gemv(PcArgs a) {
+  extern __shared__ float pc_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* xs = pc_lds + (int64_t)wave * a.D;
+  // uniform trip count across the workgroup so that __syncthreads() is legal
+  for (int64_t base = (int64_t)blockIdx.x * kWavesPerBlock; base < a.N;
+       base += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t c = base + wave;
+    const bool ok = c < a.N;
+    float e = 0.0f;
+    if (ok) {
+      e = a.eps_pc ? a.eps_pc[c] : a.eps;
+      const float h = e * 0.5f;
+      for (int64_t j = lane; j < a.D; j += 64) {
+        float x = a.X[c * a.D + j];
+        if (a.n_kicks > 0) {
+          const float g = a.G[c * a.D + j];
+          x = fmaf(h, g, x);
+          if (a.n_kicks == 2) x = fmaf(h, g, x);
+          if (a.X_out) a.X_out[c * a.D + j] = x;
+        }
+        xs[j] = x;
+      }
+    }
+    __syncthreads();
+    if (ok) {
+      const float* m = a.M + c * a.D * a.D;
+      for (int64_t i = lane; i < a.D; i += 64) {
+        double acc = 0.0;
+        for (int64_t j = 0; j < a.D; ++j) acc += (double)m[j * a.D + i] * (double)xs[j];
+        const float y = (float)acc;
+        if constexpr (EPI == EPI_STORE) a.Y[c * a.D + i] = y;
+        else a.Q_out[c * a.D + i] = fmaf(e, y, a.Q_in[c * a.D + i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Welford with a dense M2 (mass_matrix.py:424-435): m2 += outer(updated_delta, delta)
+__global__ void __launch_bounds__(kBlock)
+k_welford_update_dense(int64_t N, int64_t D, float n, const float* __restrict__ x,
+                       const float* mean_in, const float* m2_in, float* mean_out, float* m2_out) {
+  extern __shared__ float pc_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* delta = pc_lds + (int64_t)wave * 2 * D;
+  float* upd = delta + D;
+  for (int64_t base = (int64_t)blockIdx.x * kWavesPerBlock; base < N;
+       base += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t c = base + wave;
+    const bool ok = c < N;
+    if (ok) {
+      for (int64_t j = lane; j < D; j += 64) {
+        const float xv = x[c * D + j], mv = mean_in[c * D + j];
+        const float d = xv - mv;
+        const float mo = mv + d / n;
+        mean_out[c * D + j] = mo;
+        delta[j] = d;
+        upd[j] = xv - mo;
+      }
+    }
+    __syncthreads();
+    if (ok) {
+      const float* mi = m2_in + c * D * D;
+      float* mo = m2_out + c * D * D;
+      for (int64_t i = 0; i < D; ++i) {
+        const float u = upd[i];
+        for (int64_t j = lane; j < D; j += 64) mo[i * D + j] = fmaf(u, delta[j], mi[i * D + j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// mass_matrix.py:335-357 (dense): imm = beta_data*cov + beta_prev*prev + beta_ident*1e-3*I
+__global__ void __launch_bounds__(kBlock)
+k_welford_final_dense(int64_t total, int64_t D, float nm1, float beta_data, float beta_prev,
+                      float reg, const float* __restrict__ m2, const float* __restrict__ prev,
+                      int64_t prev_per_chain, float* __restrict__ imm_out) {
+  const int64_t dd = D * D;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t % dd;
+    const float cov = m2[t] / nm1;
+    const float pv = prev_per_chain ? prev[t] : prev[r];
+    const float diag = (r / D == r % D) ? reg : 0.0f;
+    imm_out[t] = fmaf(beta_prev, pv, beta_data * cov) + diag;
+  }
+}
+
+int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
+  const dim3 grid(bjx_row_grid(pa.N, kWavesPerBlock)), block(kBlock);
+  const size_t lds = (size_t)kWavesPerBlock * pa.D * sizeof(float);
+  if (lds > 64 * 1024) {
+    bjx_set_error("per-chain dense metric: D = %lld does not fit the LDS staging buffer", (long long)pa.D);
+    return 1;
+  }
+  if (epi == EPI_STORE) hipLaunchKernelGGL(k_pc_gemv<EPI_STORE>, grid, block, lds, s, pa);
+  else hipLaunchKernelGGL(k_pc_gemv<EPI_DRIFT>, grid, block, lds, s, pa);
+  return bjx_check_launch("bjx_dense_pc gemv");
+}
+
 int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B);
@@ -388,6 +512,103 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
                      g0, ke0, q1, logp1, g1, p1_work, v_work, p_end_out, q_out, logp_out, g_out,
                      acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
   return bjx_check_launch("bjx_hmc_finish_dense");
+}
+
+// ------------------------------------------------------------------ per-chain dense metric
+int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, const float* x, float* y) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && M && x && y, "bjx_pc_matvec_t: bad arguments");
+  if (N == 0) return 0;
+  PcArgs pa{N, D, M, x, nullptr, 0, 0.0f, nullptr, nullptr, y, nullptr, nullptr};
+  return launch_pc((hipStream_t)stream, EPI_STORE, pa);
+}
+
+int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
+                              const float* imm, float* z_work, float* v_work, float* p_out,
+                              float* ke_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out,
+                "bjx_hmc_momentum_dense_pc: bad arguments");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 rgrid(bjx_row_grid(N, kWavesPerBlock)), rblock(kBlock);
+  hipLaunchKernelGGL(k_dense_z, rgrid, rblock, 0, s, Key{key0, key1}, chain_offset, step_fold, N, D,
+                     z_work);
+  if (int rc = bjx_check_launch("bjx_hmc_momentum_dense_pc(z)")) return rc;
+  PcArgs p1{N, D, mass_sqrt_t, z_work, nullptr, 0, 0.0f, nullptr, nullptr, p_out, nullptr, nullptr};
+  if (int rc = launch_pc(s, EPI_STORE, p1)) return rc;  // p = L^{-T} z
+  PcArgs p2{N, D, imm, p_out, nullptr, 0, 0.0f, nullptr, nullptr, v_work, nullptr, nullptr};
+  if (int rc = launch_pc(s, EPI_STORE, p2)) return rc;  // v = imm p
+  hipLaunchKernelGGL(k_rowdot_half, rgrid, rblock, 0, s, N, D, v_work, p_out, ke_out);
+  return bjx_check_launch("bjx_hmc_momentum_dense_pc(ke)");
+}
+
+int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                          const float* eps_per_chain, const float* imm, const float* q_in,
+                          const float* p_in, const float* g, float* q_out, float* p_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
+                "bjx_leapfrog_dense_pc: bad arguments");
+  BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense_pc: n_kicks must be 1 or 2");
+  if (N == 0) return 0;
+  PcArgs pa{N, D, imm, p_in, g, n_kicks, eps, eps_per_chain, p_out, nullptr, q_in, q_out};
+  return launch_pc((hipStream_t)stream, EPI_DRIFT, pa);
+}
+
+int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                            int64_t step_fold, int64_t N, int64_t D, float eps,
+                            const float* eps_per_chain, const float* imm,
+                            float divergence_threshold, const float* q0, const float* logp0,
+                            const float* g0, const float* ke0, const float* q1, const float* logp1,
+                            const float* g1, const float* p, float* p1_work, float* v_work,
+                            float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                            float* acceptance_rate_out, uint8_t* is_accepted_out,
+                            uint8_t* is_divergent_out, float* energy_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
+                    p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
+                    is_accepted_out && is_divergent_out && energy_out,
+                "bjx_hmc_finish_dense_pc: bad arguments");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  PcArgs pa{N, D, imm, p, g1, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+  if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;  // p1 = p + (eps/2) g1 ; v1 = imm p1
+  hipLaunchKernelGGL(k_hmc_finish_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
+                     Key{key0, key1}, chain_offset, step_fold, N, D, divergence_threshold, q0, logp0,
+                     g0, ke0, q1, logp1, g1, p1_work, v_work, p_end_out, q_out, logp_out, g_out,
+                     acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
+  return bjx_check_launch("bjx_hmc_finish_dense_pc");
+}
+
+int bjx_welford_update_dense(void* stream, int64_t N, int64_t D, int64_t sample_size_new,
+                             const float* value, const float* mean_in, const float* m2_in,
+                             float* mean_out, float* m2_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size_new >= 1 && value && mean_in && m2_in && mean_out &&
+                    m2_out,
+                "bjx_welford_update_dense: bad arguments");
+  if (N == 0) return 0;
+  const size_t lds = (size_t)kWavesPerBlock * 2 * D * sizeof(float);
+  BJX_CHECK_ARG(lds <= 64 * 1024, "bjx_welford_update_dense: D too large for the LDS staging buffer");
+  hipLaunchKernelGGL(k_welford_update_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), lds,
+                     (hipStream_t)stream, N, D, (float)sample_size_new, value, mean_in, m2_in,
+                     mean_out, m2_out);
+  return bjx_check_launch("bjx_welford_update_dense");
+}
+
+int bjx_welford_final_dense(void* stream, int64_t N, int64_t D, int64_t sample_size,
+                            float imm_shrinkage_to_previous, const float* m2, const float* imm_prev,
+                            int imm_prev_per_chain, float* imm_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size >= 0 && m2 && imm_prev && imm_out,
+                "bjx_welford_final_dense: bad arguments");
+  if (N == 0) return 0;
+  const float denom = (float)(sample_size + 5) + imm_shrinkage_to_previous;
+  const float beta_data = (float)sample_size / denom;
+  const float beta_prev = imm_shrinkage_to_previous / denom;
+  const float reg = (5.0f / denom) * 1e-3f;
+  const int64_t total = N * D * D;
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_welford_final_dense, dim3((unsigned)blocks), dim3(kBlock), 0,
+                     (hipStream_t)stream, total, D, (float)(sample_size - 1), beta_data, beta_prev,
+                     reg, m2, imm_prev, (int64_t)imm_prev_per_chain, imm_out);
+  return bjx_check_launch("bjx_welford_final_dense");
 }
 
 }  // extern "C"

@@ -1,4 +1,9 @@
-"""Launch helpers for the dense Gaussian-Euclidean metric (``bjx_dense.hip``)."""
+"""Launch helpers for the dense Gaussian-Euclidean metric (``bjx_dense.hip``).
+
+``metric.kind == "dense"``: one (D, D) matrix shared by all chains -> fp32 MFMA GEMMs.
+``metric.kind == "dense_pc"``: one (D, D) matrix per chain, (N, D, D) -> batched fp64-accumulated
+matrix-vector kernels.
+"""
 from __future__ import annotations
 
 import torch
@@ -6,19 +11,24 @@ import torch
 from . import _lib
 
 
+def _sfx(metric) -> str:
+    return "_pc" if metric.kind == "dense_pc" else ""
+
+
 def momentum(stream, metric, k0, k1, off, fold, n, d, p0, ke0):
     z = torch.empty_like(p0)
     v = torch.empty_like(p0)
-    _lib.call("bjx_hmc_momentum_dense", stream, k0, k1, off, fold, n, d,
+    _lib.call("bjx_hmc_momentum_dense" + _sfx(metric), stream, k0, k1, off, fold, n, d,
               metric.mass_sqrt_t.data_ptr(), metric.imm.data_ptr(), z.data_ptr(), v.data_ptr(),
               p0.data_ptr(), ke0.data_ptr())
 
 
 def leapfrog(stream, metric, n, d, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
-    """Returns the tensor that holds the new momentum (the GEMM cannot update p in place)."""
-    if p_out.data_ptr() == p_in.data_ptr():
+    """Returns the tensor that holds the new momentum (the shared-matrix GEMM cannot update p in
+    place: its column blocks re-read the un-kicked momentum)."""
+    if metric.kind == "dense" and p_out.data_ptr() == p_in.data_ptr():
         p_out = torch.empty_like(p_in)
-    _lib.call("bjx_leapfrog_dense", stream, n, d, n_kicks, eps, _lib.ptr(eps_pc),
+    _lib.call("bjx_leapfrog_dense" + _sfx(metric), stream, n, d, n_kicks, eps, _lib.ptr(eps_pc),
               metric.imm.data_ptr(), q_in.data_ptr(), p_in.data_ptr(), g.data_ptr(),
               q_out.data_ptr(), p_out.data_ptr())
     return p_out
@@ -28,9 +38,9 @@ def finish(stream, metric, k0, k1, off, fold, n, d, eps, eps_pc, thr, q0, logp0,
            p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div, energy):
     p1 = torch.empty_like(p)
     v = torch.empty_like(p)
-    _lib.call("bjx_hmc_finish_dense", stream, k0, k1, off, fold, n, d, eps, _lib.ptr(eps_pc),
-              metric.imm.data_ptr(), thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(),
-              ke0.data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(),
-              p1.data_ptr(), v.data_ptr(), p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(),
-              g_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(),
-              energy.data_ptr())
+    _lib.call("bjx_hmc_finish_dense" + _sfx(metric), stream, k0, k1, off, fold, n, d, eps,
+              _lib.ptr(eps_pc), metric.imm.data_ptr(), thr, q0.data_ptr(), logp0.data_ptr(),
+              g0.data_ptr(), ke0.data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(),
+              p.data_ptr(), p1.data_ptr(), v.data_ptr(), p_end.data_ptr(), q_new.data_ptr(),
+              logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(),
+              is_div.data_ptr(), energy.data_ptr())

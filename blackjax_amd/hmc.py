@@ -195,7 +195,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             s, e = b * blk, min(N, (b + 1) * blk)
             n = e - s
             sl = slice(s, e)
-            m = metric if metric.imm_stride == 0 else metric._replace(imm=metric.imm[sl])
+            if metric.kind == "dense_pc":  # per-chain matrices travel with their chains
+                m = metric._replace(imm=metric.imm[sl], mass_sqrt_t=metric.mass_sqrt_t[sl])
+            else:
+                m = metric if metric.imm_stride == 0 else metric._replace(imm=metric.imm[sl])
             eb = None if eps_pc is None else eps_pc[sl]
             boff = off + s
             if m.kind == "diag":

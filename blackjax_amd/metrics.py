@@ -49,6 +49,13 @@ def default_metric(inverse_mass_matrix, n_chains: int, dim: int, device) -> Metr
         if imm.shape[0] != dim:
             raise ValueError(f"inverse_mass_matrix is {tuple(imm.shape)}, position has {dim} dims")
         return _dense_metric(imm.contiguous())
+    if imm.ndim == 3 and imm.shape[1] == imm.shape[2]:
+        # one dense matrix per chain (a vmapped dense warmup's output)
+        if imm.shape[0] != n_chains or imm.shape[1] != dim:
+            raise ValueError(
+                f"per-chain dense inverse_mass_matrix must be ({n_chains}, {dim}, {dim}), "
+                f"got {tuple(imm.shape)}")
+        return _dense_metric(imm.contiguous())
     raise ValueError(
         "The mass matrix has the wrong number of dimensions:"
         f" expected 1 or 2, got {imm.ndim}."
@@ -71,9 +78,12 @@ def _dense_metric(imm: torch.Tensor) -> Metric:
     if hit is not None:
         return hit
     L = torch.linalg.cholesky(imm.double())
-    eye = torch.eye(imm.shape[0], dtype=torch.float64, device=imm.device)
+    eye = torch.eye(imm.shape[-1], dtype=torch.float64, device=imm.device)
+    if imm.ndim == 3:
+        eye = eye.expand(imm.shape).contiguous()
     Linv = torch.linalg.solve_triangular(L, eye, upper=False)  # L^{-1} = (L^{-T})^T
-    m = Metric("dense", imm, 0, Linv.float().contiguous())
+    # "dense": one matrix shared by all chains (MFMA GEMMs); "dense_pc": one matrix per chain
+    m = Metric("dense" if imm.ndim == 2 else "dense_pc", imm, 0, Linv.float().contiguous())
     if len(_DENSE_CACHE) > 8:
         _DENSE_CACHE.clear()
     _DENSE_CACHE[key] = m

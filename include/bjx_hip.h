@@ -129,6 +129,42 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
                          float* logp_out, float* g_out, float* acceptance_rate_out,
                          uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out);
 
+/* ---- PER-CHAIN dense metric: one (D, D) inverse mass matrix per chain, (N, D, D) row-major ----
+ * This is what a vmapped `window_adaptation(..., is_mass_matrix_diagonal=False).run` produces in
+ * the reference.  Batched matrix-vector products with fp64 accumulation (bound by reading D^2
+ * words per chain, not by MFMA).  Same contracts as the shared-matrix entry points above.
+ *
+ * y[c][i] = sum_j M[c][j][i] * x[c][j]   (M^T x per chain; the building block). */
+int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, const float* x, float* y);
+int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
+                              const float* imm, float* z_work, float* v_work, float* p_out,
+                              float* ke_out);
+/* p_out may alias p_in here (each element is read and written by the same lane). */
+int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                          const float* eps_per_chain, const float* imm, const float* q_in,
+                          const float* p_in, const float* g, float* q_out, float* p_out);
+int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                            int64_t step_fold, int64_t N, int64_t D, float eps,
+                            const float* eps_per_chain, const float* imm,
+                            float divergence_threshold, const float* q0, const float* logp0,
+                            const float* g0, const float* ke0, const float* q1, const float* logp1,
+                            const float* g1, const float* p, float* p1_work, float* v_work,
+                            float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                            float* acceptance_rate_out, uint8_t* is_accepted_out,
+                            uint8_t* is_divergent_out, float* energy_out);
+
+/* Welford with a dense second-moment matrix per chain: m2 (N, D, D) += outer(value - mean_new,
+ * value - mean_old).  Replaces: blackjax/adaptation/mass_matrix.py:424-435 (dense branch). */
+int bjx_welford_update_dense(void* stream, int64_t N, int64_t D, int64_t sample_size_new,
+                             const float* value, const float* mean_in, const float* m2_in,
+                             float* mean_out, float* m2_out);
+/* Window end (dense): imm = (n/(n+5+k)) m2/(n-1) + (k/(n+5+k)) imm_prev + (5/(n+5+k)) 1e-3 I.
+ * imm_prev is (D, D) [imm_prev_per_chain = 0] or (N, D, D) [= 1].  Replaces: mass_matrix.py:335-357. */
+int bjx_welford_final_dense(void* stream, int64_t N, int64_t D, int64_t sample_size,
+                            float imm_shrinkage_to_previous, const float* m2, const float* imm_prev,
+                            int imm_prev_per_chain, float* imm_out);
+
 /* ---- window adaptation (per-chain state; every array is (N,) unless noted) ------------------
  *
  * Dual averaging init (from_log_avg = 0: x = x_in) or window-end re-init (from_log_avg = 1:

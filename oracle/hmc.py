@@ -82,6 +82,12 @@ def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False) -> 
         L = np.linalg.cholesky(imm.astype(f64))
         mass_sqrt = np.linalg.solve(L.T, np.eye(L.shape[0]))  # L^{-T}
         return Metric(imm, mass_sqrt.astype(f32), True)
+    if imm.ndim == 3 and imm.shape[1] == imm.shape[2]:
+        # one dense matrix PER CHAIN (what a vmapped dense window_adaptation produces)
+        L = np.linalg.cholesky(imm.astype(f64))
+        eye = np.broadcast_to(np.eye(imm.shape[1]), imm.shape)
+        mass_sqrt = np.linalg.solve(np.swapaxes(L, 1, 2), eye)  # L^{-T} per chain
+        return Metric(imm, mass_sqrt.astype(f32), True)
     raise ValueError(
         "The mass matrix has the wrong number of dimensions:"
         f" expected 1 or 2, got {imm.ndim}."
@@ -93,6 +99,8 @@ def linear_map(metric: Metric, mat, x):
     (fp64 accumulate, rounded once)."""
     if not metric.is_dense:
         return (mat * x).astype(f32)
+    if mat.ndim == 3:  # per-chain matrices
+        return np.einsum("nij,nj->ni", mat.astype(f64), x.astype(f64)).astype(f32)
     return (x.astype(f64) @ mat.astype(f64).T).astype(f32)
 
 

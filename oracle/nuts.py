@@ -65,6 +65,8 @@ def is_iterative_turning(metric, r_ckpts, r_sum_ckpts, idx_min, idx_max, r_sum, 
 
 
 def _chain_metric(metric: ohmc.Metric, i: int) -> ohmc.Metric:
+    if metric.is_dense and metric.inverse_mass_matrix.ndim == 3:
+        return ohmc.Metric(metric.inverse_mass_matrix[i], metric.mass_matrix_sqrt[i], True)
     if metric.is_dense or metric.inverse_mass_matrix.ndim == 1:
         return metric
     return ohmc.Metric(metric.inverse_mass_matrix[i:i + 1], metric.mass_matrix_sqrt[i:i + 1], False)

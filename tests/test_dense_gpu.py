@@ -112,3 +112,102 @@ def test_dense_hmc_statistics(dev):
     emp = (x.T @ x) / N
     assert float((emp - cov.double()).abs().max()) < 0.15
     assert np.mean(accs) > 0.7
+
+
+# ------------------------------------------------------------------ per-chain dense metric
+def _random_spd(rng, N, D):
+    a = rng.standard_normal((N, D, D))
+    return (a @ np.swapaxes(a, 1, 2) / D + 0.5 * np.eye(D)).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,D", [(9, 7), (130, 64), (3, 200)])
+def test_pc_matvec_t(dev, N, D):
+    rng = np.random.default_rng(N + D)
+    M = rng.standard_normal((N, D, D)).astype(np.float32)
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    y = torch.empty(N, D, device=dev)
+    Mt, xt = dev_t(M, dev), dev_t(x, dev)
+    _lib.call("bjx_pc_matvec_t", _lib.current_stream(), N, D, Mt.data_ptr(), xt.data_ptr(), y.data_ptr())
+    ref = np.einsum("nji,nj->ni", M.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(t2n(y), ref)  # fp64 accumulation on both sides: bit-identical
+
+
+def test_welford_dense_kernels_bit_exact(dev):
+    from blackjax_amd import adaptation as bad
+    from oracle import adaptation as oad
+
+    N, D = 11, 13
+    rng = np.random.default_rng(5)
+    wc_o = oad.welford_init(N, D, is_diag=False)
+    wc = bad.WelfordAlgorithmState(torch.zeros(N, D, device=dev), torch.zeros(N, D, D, device=dev), 0)
+    for _ in range(12):
+        x = (rng.standard_normal((N, D)) * 2 + 1).astype(np.float32)
+        wc_o = oad.welford_update(wc_o, x, is_diag=False)
+        wc = bad._welford_update(wc, dev_t(x, dev))
+    assert np.array_equal(t2n(wc.mean), wc_o.mean) and np.array_equal(t2n(wc.m2), wc_o.m2)
+    for prev in (np.eye(D, dtype=np.float32), _random_spd(rng, N, D)):
+        for shrink in (0.0, 2.0):
+            prev_o = np.broadcast_to(prev, (N, D, D)) if prev.ndim == 2 else prev
+            mm_o = oad.mm_final(oad.MassMatrixState(prev_o, wc_o), False, shrink)
+            mm = bad._mm_final(bad.MassMatrixAdaptationState(dev_t(prev, dev), wc), shrink)
+            assert np.array_equal(t2n(mm.inverse_mass_matrix), mm_o.inverse_mass_matrix)
+
+
+def test_dense_pc_hmc_vs_oracle(dev):
+    """One dense inverse mass matrix PER CHAIN (vmapped dense warmup output), per-chain step size,
+    chain blocking.  fp64-accumulated matrix-vector products on both sides: the only non-bit-exact
+    input is the fp64 Cholesky factor (LAPACK vs rocSOLVER), hence a 1e-6 tolerance."""
+    N, D, L = 20, 12, 6
+    rng = np.random.default_rng(3)
+    imm = _random_spd(rng, N, D)
+    eps = rng.uniform(0.1, 0.4, N).astype(np.float32)
+    inv_var = rng.uniform(0.5, 2.0, D).astype(np.float32)
+    fn_o = otargets.diag_gaussian(inv_var)
+    q0 = prng.normal(prng.key(1), (N, D)).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    alg = bjx.hmc(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), dev_t(eps, dev), dev_t(imm, dev), L,
+                  chain_block=8)
+    st_g = alg.init(dev_t(q0, dev))
+    for kk in prng.split(prng.key(0), 4):
+        st_o, info_o = ohmc.kernel(kk, st_o, fn_o, eps, imm, L)
+        st_g, info_g = alg.step(kk, st_g)
+        assert np.array_equal(t2n(info_g.is_accepted), info_o.is_accepted)
+        np.testing.assert_allclose(t2n(info_g.momentum), info_o.momentum, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-4, atol=1e-6)
+
+
+def test_dense_window_adaptation_vs_oracle(dev):
+    """window_adaptation(hmc, is_mass_matrix_diagonal=False): dense Welford per chain
+    (reference tests/mcmc/test_sampling.py:317-379 runs the same combination)."""
+    from oracle import adaptation as oad
+
+    N, D, L, T = 6, 5, 5, 60
+    rho = 0.6
+    fn_o = otargets.ar1_gaussian(rho, D)
+    q0 = prng.normal(prng.key(4), (N, D)).astype(np.float32)
+    st_o, par_o, hist_o = oad.window_adaptation_run(prng.key(7), q0, fn_o, T, L,
+                                                    is_mass_matrix_diagonal=False)
+    warm = bjx.window_adaptation(bjx.hmc, bjx.targets.AR1Gaussian(rho, D), is_mass_matrix_diagonal=False,
+                                 num_integration_steps=L)
+    (st_g, par_g), info = warm.run(prng.key(7), dev_t(q0, dev), T)
+    assert par_g["inverse_mass_matrix"].shape == (N, D, D)
+    eps_g = t2n(info.adaptation_state.step_size)
+    sched = oad.build_schedule(T)
+    t_end = [t for t, (_, e) in enumerate(sched) if e][0]  # first (only) window end
+    for t in range(T):
+        # bit-identical up to and including the window end (identity metric, dense Welford, blend);
+        # afterwards the per-chain Cholesky factors come from different fp64 LAPACK back ends
+        # (1e-16 relative), which the ill-conditioned 44-sample covariance and the freshly
+        # re-initialised dual averaging amplify -- hence the looser bound on the last steps
+        if t <= t_end:
+            assert np.array_equal(eps_g[t], hist_o[t][1]), t
+        else:
+            np.testing.assert_allclose(eps_g[t], hist_o[t][1], rtol=2e-2)
+    np.testing.assert_allclose(t2n(par_g["step_size"]), par_o["step_size"], rtol=2e-2)
+    np.testing.assert_allclose(t2n(par_g["inverse_mass_matrix"]), par_o["inverse_mass_matrix"],
+                               rtol=1e-5, atol=1e-6)
+    # sampling with the adapted per-chain dense matrices runs
+    alg = bjx.hmc(bjx.targets.AR1Gaussian(rho, D), par_g["step_size"], par_g["inverse_mass_matrix"], L)
+    st, inf = alg.step(bjx.random.key(1), st_g)
+    assert torch.isfinite(st.position).all() and inf.acceptance_rate.mean() > 0.3
