@@ -39,13 +39,13 @@ SIGNATURES = {
                              _f32p, _f32p, c_float,
                              _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                              _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
-    "bjx_pc_matvec_t": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
+    "bjx_pc_matvec_t": [c_void_p, c_int64, c_int64, _f32p, c_int64, _f32p, _f32p],
     "bjx_hmc_momentum_dense_pc": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
-                                  _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
-    "bjx_leapfrog_dense_pc": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, _f32p, _f32p,
-                              _f32p, _f32p, _f32p],
+                                  _f32p, _f32p, c_int64, _f32p, _f32p, _f32p, _f32p],
+    "bjx_leapfrog_dense_pc": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, c_int64, _f32p,
+                              _f32p, _f32p, _f32p, _f32p],
     "bjx_hmc_finish_dense_pc": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
-                                c_float, _f32p, _f32p, c_float,
+                                c_float, _f32p, _f32p, c_int64, c_float,
                                 _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                 _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
     "bjx_welford_update_dense": [c_void_p, c_int64, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p,
@@ -82,6 +82,8 @@ class NutsDesc(ctypes.Structure):
         ("Pq", c_void_p), ("Pg", c_void_p), ("Sq", c_void_p), ("Sg", c_void_p),
         ("ckpt_r", c_void_p), ("ckpt_rs", c_void_p),
         ("fs", c_void_p), ("is_", c_void_p),
+        ("Mdense", c_void_p), ("Mdense_stride", c_int64), ("v0", c_void_p),
+        ("Lv", c_void_p), ("Rv", c_void_p), ("ckpt_v", c_void_p),
     ]
 
 

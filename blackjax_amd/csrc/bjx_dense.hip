@@ -318,7 +318,8 @@ k_hmc_finish_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, flo
 // The fp64 accumulation makes this path bit-compatible with the oracle's reductions.
 struct PcArgs {
   int64_t N, D;
-  const float* M;       // (N, D, D)
+  const float* M;       // (N, D, D), or one shared (D, D) matrix when m_stride == 0
+  int64_t m_stride;     // D*D or 0
   const float* X;       // (N, D)
   const float* G;       // gradient for the kick prologue or nullptr
   int n_kicks;
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(kBlock) k_pc_gemv(PcArgs a) {
     }
     __syncthreads();
     if (ok) {
-      const float* m = a.M + c * a.D * a.D;
+      const float* m = a.M + c * a.m_stride;
       for (int64_t i = lane; i < a.D; i += 64) {
         double acc = 0.0;
         for (int64_t j = 0; j < a.D; ++j) acc += (double)m[j * a.D + i] * (double)xs[j];
@@ -515,18 +516,21 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
 }
 
 // ------------------------------------------------------------------ per-chain dense metric
-int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, const float* x, float* y) {
-  BJX_CHECK_ARG(N >= 0 && D > 0 && M && x && y, "bjx_pc_matvec_t: bad arguments");
+int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, int64_t matrix_stride,
+                    const float* x, float* y) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && M && x && y && (matrix_stride == 0 || matrix_stride == D * D),
+                "bjx_pc_matvec_t: bad arguments");
   if (N == 0) return 0;
-  PcArgs pa{N, D, M, x, nullptr, 0, 0.0f, nullptr, nullptr, y, nullptr, nullptr};
+  PcArgs pa{N, D, M, matrix_stride, x, nullptr, 0, 0.0f, nullptr, nullptr, y, nullptr, nullptr};
   return launch_pc((hipStream_t)stream, EPI_STORE, pa);
 }
 
 int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                               int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
-                              const float* imm, float* z_work, float* v_work, float* p_out,
-                              float* ke_out) {
-  BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out,
+                              const float* imm, int64_t matrix_stride, float* z_work, float* v_work,
+                              float* p_out, float* ke_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out &&
+                    (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_hmc_momentum_dense_pc: bad arguments");
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -534,28 +538,30 @@ int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_
   hipLaunchKernelGGL(k_dense_z, rgrid, rblock, 0, s, Key{key0, key1}, chain_offset, step_fold, N, D,
                      z_work);
   if (int rc = bjx_check_launch("bjx_hmc_momentum_dense_pc(z)")) return rc;
-  PcArgs p1{N, D, mass_sqrt_t, z_work, nullptr, 0, 0.0f, nullptr, nullptr, p_out, nullptr, nullptr};
+  PcArgs p1{N, D, mass_sqrt_t, matrix_stride, z_work, nullptr, 0, 0.0f, nullptr, nullptr, p_out, nullptr, nullptr};
   if (int rc = launch_pc(s, EPI_STORE, p1)) return rc;  // p = L^{-T} z
-  PcArgs p2{N, D, imm, p_out, nullptr, 0, 0.0f, nullptr, nullptr, v_work, nullptr, nullptr};
+  PcArgs p2{N, D, imm, matrix_stride, p_out, nullptr, 0, 0.0f, nullptr, nullptr, v_work, nullptr, nullptr};
   if (int rc = launch_pc(s, EPI_STORE, p2)) return rc;  // v = imm p
   hipLaunchKernelGGL(k_rowdot_half, rgrid, rblock, 0, s, N, D, v_work, p_out, ke_out);
   return bjx_check_launch("bjx_hmc_momentum_dense_pc(ke)");
 }
 
 int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
-                          const float* eps_per_chain, const float* imm, const float* q_in,
-                          const float* p_in, const float* g, float* q_out, float* p_out) {
-  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
+                          const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                          const float* q_in, const float* p_in, const float* g, float* q_out,
+                          float* p_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out &&
+                    (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_leapfrog_dense_pc: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense_pc: n_kicks must be 1 or 2");
   if (N == 0) return 0;
-  PcArgs pa{N, D, imm, p_in, g, n_kicks, eps, eps_per_chain, p_out, nullptr, q_in, q_out};
+  PcArgs pa{N, D, imm, matrix_stride, p_in, g, n_kicks, eps, eps_per_chain, p_out, nullptr, q_in, q_out};
   return launch_pc((hipStream_t)stream, EPI_DRIFT, pa);
 }
 
 int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                             int64_t step_fold, int64_t N, int64_t D, float eps,
-                            const float* eps_per_chain, const float* imm,
+                            const float* eps_per_chain, const float* imm, int64_t matrix_stride,
                             float divergence_threshold, const float* q0, const float* logp0,
                             const float* g0, const float* ke0, const float* q1, const float* logp1,
                             const float* g1, const float* p, float* p1_work, float* v_work,
@@ -564,11 +570,12 @@ int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t 
                             uint8_t* is_divergent_out, float* energy_out) {
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
                     p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
-                    is_accepted_out && is_divergent_out && energy_out,
+                    is_accepted_out && is_divergent_out && energy_out &&
+                    (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_hmc_finish_dense_pc: bad arguments");
   if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  PcArgs pa{N, D, imm, p, g1, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+  PcArgs pa{N, D, imm, matrix_stride, p, g1, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
   if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;  // p1 = p + (eps/2) g1 ; v1 = imm p1
   hipLaunchKernelGGL(k_hmc_finish_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
                      Key{key0, key1}, chain_offset, step_fold, N, D, divergence_threshold, q0, logp0,

@@ -79,6 +79,60 @@ __device__ __forceinline__ float chain_eps(const bjx_nuts_t& nt, int64_t c) {
   return nt.eps_per_chain ? nt.eps_per_chain[c] : nt.eps;
 }
 
+// Dense metric: y_i = sum_j M[j][i] x_j for THIS lane's output index i (M symmetric, so this is
+// (M x)_i with coalesced row reads), fp64 accumulate.  x is supplied lane-wise by xf(j) and
+// broadcast with wave shuffles, so the vector never round-trips memory.  Must be called by all
+// 64 lanes (uniform loops); lanes with i >= D just take part in the shuffles.
+template <class XF>
+__device__ __forceinline__ double matvec_t_lane(const float* __restrict__ M, int64_t D, int64_t i,
+                                                XF xf) {
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (int64_t jc = 0; jc < D; jc += 64) {
+    const int64_t jl = jc + lane;
+    const float xr = jl < D ? xf(jl) : 0.0f;
+    const int lim = (int)((D - jc) < 64 ? (D - jc) : 64);
+    for (int t = 0; t < lim; ++t) {
+      const float xj = __shfl(xr, t, BJX_WAVE);
+      if (i < D) acc += (double)M[(jc + t) * D + i] * (double)xj;
+    }
+  }
+  return acc;
+}
+
+// Opening half of a leapfrog on the trajectory end `dir` of chain c (integrators.py:104-150 with
+// step dir*eps): p += h g ; q += deps * (M^{-1} p) ; new position also to the compact row qo.
+// gsrc = gradient at the current end state.
+__device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, int dir, float deps,
+                                               float h, const float* gsrc, float* qo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t base = c * nt.D;
+  float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+  float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+  if (nt.Mdense) {
+    const float* M = nt.Mdense + c * nt.Mdense_stride;
+    for (int64_t ic = 0; ic < nt.D; ic += 64) {
+      const int64_t i = ic + lane;
+      const double acc = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gsrc[j], fp[j]); });
+      if (i < nt.D) {
+        const float qn = fmaf(deps, (float)acc, fq[i]);
+        fq[i] = qn;
+        qo[i] = qn;
+      }
+    }
+    for (int64_t j = lane; j < nt.D; j += 64) fp[j] = fmaf(h, gsrc[j], fp[j]);
+  } else {
+    const float* im = nt.imm + c * nt.imm_stride;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float pn = fmaf(h, gsrc[j], fp[j]);
+      const float qn = fmaf(deps, im[j] * pn, fq[j]);
+      fp[j] = pn;
+      fq[j] = qn;
+      qo[j] = qn;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ init
 __global__ void __launch_bounds__(kBlock)
 k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restrict__ ke0) {
@@ -90,6 +144,10 @@ k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restr
       nt.Lq[base + j] = q; nt.Rq[base + j] = q; nt.Pq[base + j] = q;
       nt.Lp[base + j] = p; nt.Rp[base + j] = p; nt.msum[base + j] = p;
       nt.Lg[base + j] = g; nt.Rg[base + j] = g; nt.Pg[base + j] = g;
+      if (nt.Mdense) {
+        const float v = nt.v0[base + j];
+        nt.Lv[base + j] = v; nt.Rv[base + j] = v;
+      }
     }
     if (lane == 0) {
       const float lp = logp0[c];
@@ -149,19 +207,8 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     }
     const float deps = (float)dir * chain_eps(nt, c);  // direction * step_size (trajectory.py:323)
     const float h = deps * 0.5f;
-    const int64_t base = c * nt.D;
-    float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
-    float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
-    const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
-    const float* im = nt.imm + c * nt.imm_stride;
-    float* qo = qf + b * nt.D;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float pn = fmaf(h, fg[j], fp[j]);
-      const float qn = fmaf(deps, im[j] * pn, fq[j]);
-      fp[j] = pn;
-      fq[j] = qn;
-      qo[j] = qn;
-    }
+    const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
+    nuts_open_half(nt, c, dir, deps, h, fg, qf + b * nt.D);
   }
 }
 
@@ -189,12 +236,32 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 
     // pass 1: closing half kick, store the new end state, kinetic energy
     double acc = 0.0;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float g = gn[j];
-      const float p = fmaf(h, g, fp[j]);
-      fp[j] = p;
-      fg[j] = g;
-      acc += (double)(im[j] * p) * (double)p;
+    float* fv = nullptr;  // dense metric: velocity M^{-1} p of the new end state
+    if (nt.Mdense) {
+      const float* M = nt.Mdense + c * nt.Mdense_stride;
+      fv = (dir > 0 ? nt.Rv : nt.Lv) + base;
+      for (int64_t ic = 0; ic < nt.D; ic += 64) {
+        const int64_t i = ic + lane;
+        const double av = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gn[j], fp[j]); });
+        if (i < nt.D) {
+          const float p = fmaf(h, gn[i], fp[i]);
+          const float v = (float)av;
+          fv[i] = v;
+          acc += (double)v * (double)p;
+        }
+      }
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        fp[j] = fmaf(h, gn[j], fp[j]);
+        fg[j] = gn[j];
+      }
+    } else {
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float g = gn[j];
+        const float p = fmaf(h, g, fp[j]);
+        fp[j] = p;
+        fg[j] = g;
+        acc += (double)(im[j] * p) * (double)p;
+      }
     }
     acc = wave_sum(acc);
     const float ke = 0.5f * (float)acc;
@@ -242,6 +309,7 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
       if (even) {
         ckr[j] = p;
         ckrs[j] = m;
+        if (fv) nt.ckpt_v[(c * nt.max_depth + idx_max) * nt.D + j] = fv[j];
       }
       if (take) {
         sq[j] = qn[j];
@@ -254,13 +322,16 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     for (int i = idx_max; i >= idx_min && !turning; --i) {
       const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
       const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
+      const float* v_ck = fv ? nt.ckpt_v + (c * nt.max_depth + i) * nt.D : nullptr;
       double a_left = 0.0, a_right = 0.0;
       for (int64_t j = lane; j < nt.D; j += 64) {
         const float p = fp[j], rl = r_ck[j];
         const float ssum = (sm[j] - rs_ck[j]) + rl;
         const float rho = ssum - (p + rl) * 0.5f;      // metrics.py:300
-        a_left += (double)(im[j] * rl) * (double)rho;
-        a_right += (double)(im[j] * p) * (double)rho;
+        const float vl = fv ? v_ck[j] : im[j] * rl;    // velocity_left / velocity_right
+        const float vr = fv ? fv[j] : im[j] * p;
+        a_left += (double)vl * (double)rho;
+        a_right += (double)vr * (double)rho;
       }
       a_left = wave_sum(a_left);
       a_right = wave_sum(a_right);
@@ -283,16 +354,7 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 
     // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
     // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
-    if (fuse_next && !(sdiv || turning)) {
-      float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        const float pn = fmaf(h, gn[j], fp[j]);
-        const float qv = fmaf(deps, im[j] * pn, fq[j]);
-        fp[j] = pn;
-        fq[j] = qv;
-        qn[j] = qv;
-      }
-    }
+    if (fuse_next && !(sdiv || turning)) nuts_open_half(nt, c, dir, deps, h, gn, qn);
   }
 }
 
@@ -326,8 +388,10 @@ k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __rest
       nt.msum[base + j] = m;
       const float pl = nt.Lp[base + j], pr = nt.Rp[base + j];
       const float rho = m - (pr + pl) * 0.5f;
-      a_left += (double)(im[j] * pl) * (double)rho;
-      a_right += (double)(im[j] * pr) * (double)rho;
+      const float vl = nt.Mdense ? nt.Lv[base + j] : im[j] * pl;
+      const float vr = nt.Mdense ? nt.Rv[base + j] : im[j] * pr;
+      a_left += (double)vl * (double)rho;
+      a_right += (double)vr * (double)rho;
       if (take) {
         nt.Pq[base + j] = nt.Sq[base + j];
         nt.Pg[base + j] = nt.Sg[base + j];
@@ -404,11 +468,14 @@ k_nuts_compact(bjx_nuts_t nt, int flag_slot, int64_t n_in_arg, const int32_t* id
 
 int check_nuts(const bjx_nuts_t* nt, const char* what) {
   if (!nt) { bjx_set_error("%s: null descriptor", what); return 1; }
-  const bool ok = nt->N >= 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30 && nt->imm &&
-                  (nt->imm_stride == 0 || nt->imm_stride == nt->D) && nt->q0 && nt->g0 && nt->p0 &&
-                  nt->Lq && nt->Lp && nt->Lg && nt->Rq && nt->Rp && nt->Rg && nt->msum && nt->Smsum &&
-                  nt->Pq && nt->Pg && nt->Sq && nt->Sg && nt->fs && nt->is &&
-                  (nt->max_depth == 0 || (nt->ckpt_r && nt->ckpt_rs));
+  const bool dense_ok =
+      !nt->Mdense || ((nt->Mdense_stride == 0 || nt->Mdense_stride == nt->D * nt->D) && nt->v0 &&
+                      nt->Lv && nt->Rv && (nt->max_depth == 0 || nt->ckpt_v));
+  const bool ok = nt->N >= 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30 &&
+                  (nt->Mdense || nt->imm) && (nt->imm_stride == 0 || nt->imm_stride == nt->D) &&
+                  nt->q0 && nt->g0 && nt->p0 && nt->Lq && nt->Lp && nt->Lg && nt->Rq && nt->Rp &&
+                  nt->Rg && nt->msum && nt->Smsum && nt->Pq && nt->Pg && nt->Sq && nt->Sg && nt->fs &&
+                  nt->is && (nt->max_depth == 0 || (nt->ckpt_r && nt->ckpt_rs)) && dense_ok;
   if (!ok) { bjx_set_error("%s: bad descriptor", what); return 1; }
   return 0;
 }

@@ -2,7 +2,7 @@
 
 ``metric.kind == "dense"``: one (D, D) matrix shared by all chains -> fp32 MFMA GEMMs.
 ``metric.kind == "dense_pc"``: one (D, D) matrix per chain, (N, D, D) -> batched fp64-accumulated
-matrix-vector kernels.
+matrix-vector kernels (``*_dense_pc`` entry points with ``matrix_stride = D*D``).
 """
 from __future__ import annotations
 
@@ -11,24 +11,33 @@ import torch
 from . import _lib
 
 
-def _sfx(metric) -> str:
-    return "_pc" if metric.kind == "dense_pc" else ""
-
-
-def momentum(stream, metric, k0, k1, off, fold, n, d, p0, ke0):
+def momentum(stream, metric, k0, k1, off, fold, n, d, p0, ke0, force_pc: bool = False):
+    """``force_pc``: route a shared matrix through the fp64-accumulated kernels too (NUTS)."""
     z = torch.empty_like(p0)
     v = torch.empty_like(p0)
-    _lib.call("bjx_hmc_momentum_dense" + _sfx(metric), stream, k0, k1, off, fold, n, d,
-              metric.mass_sqrt_t.data_ptr(), metric.imm.data_ptr(), z.data_ptr(), v.data_ptr(),
-              p0.data_ptr(), ke0.data_ptr())
+    if metric.kind == "dense_pc" or force_pc:
+        stride = d * d if metric.kind == "dense_pc" else 0
+        _lib.call("bjx_hmc_momentum_dense_pc", stream, k0, k1, off, fold, n, d,
+                  metric.mass_sqrt_t.data_ptr(), metric.imm.data_ptr(), stride, z.data_ptr(),
+                  v.data_ptr(), p0.data_ptr(), ke0.data_ptr())
+    else:
+        _lib.call("bjx_hmc_momentum_dense", stream, k0, k1, off, fold, n, d,
+                  metric.mass_sqrt_t.data_ptr(), metric.imm.data_ptr(), z.data_ptr(), v.data_ptr(),
+                  p0.data_ptr(), ke0.data_ptr())
+    return v  # imm @ p0 (velocity of the initial state)
 
 
 def leapfrog(stream, metric, n, d, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
     """Returns the tensor that holds the new momentum (the shared-matrix GEMM cannot update p in
     place: its column blocks re-read the un-kicked momentum)."""
-    if metric.kind == "dense" and p_out.data_ptr() == p_in.data_ptr():
+    if metric.kind == "dense_pc":
+        _lib.call("bjx_leapfrog_dense_pc", stream, n, d, n_kicks, eps, _lib.ptr(eps_pc),
+                  metric.imm.data_ptr(), d * d, q_in.data_ptr(), p_in.data_ptr(), g.data_ptr(),
+                  q_out.data_ptr(), p_out.data_ptr())
+        return p_out
+    if p_out.data_ptr() == p_in.data_ptr():
         p_out = torch.empty_like(p_in)
-    _lib.call("bjx_leapfrog_dense" + _sfx(metric), stream, n, d, n_kicks, eps, _lib.ptr(eps_pc),
+    _lib.call("bjx_leapfrog_dense", stream, n, d, n_kicks, eps, _lib.ptr(eps_pc),
               metric.imm.data_ptr(), q_in.data_ptr(), p_in.data_ptr(), g.data_ptr(),
               q_out.data_ptr(), p_out.data_ptr())
     return p_out
@@ -38,9 +47,12 @@ def finish(stream, metric, k0, k1, off, fold, n, d, eps, eps_pc, thr, q0, logp0,
            p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div, energy):
     p1 = torch.empty_like(p)
     v = torch.empty_like(p)
-    _lib.call("bjx_hmc_finish_dense" + _sfx(metric), stream, k0, k1, off, fold, n, d, eps,
-              _lib.ptr(eps_pc), metric.imm.data_ptr(), thr, q0.data_ptr(), logp0.data_ptr(),
-              g0.data_ptr(), ke0.data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(),
-              p.data_ptr(), p1.data_ptr(), v.data_ptr(), p_end.data_ptr(), q_new.data_ptr(),
-              logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(),
-              is_div.data_ptr(), energy.data_ptr())
+    head = [stream, k0, k1, off, fold, n, d, eps, _lib.ptr(eps_pc), metric.imm.data_ptr()]
+    tail = [thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(), q.data_ptr(),
+            logp.data_ptr(), g.data_ptr(), p.data_ptr(), p1.data_ptr(), v.data_ptr(),
+            p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
+            acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr()]
+    if metric.kind == "dense_pc":
+        _lib.call("bjx_hmc_finish_dense_pc", *head, d * d, *tail)
+    else:
+        _lib.call("bjx_hmc_finish_dense", *head, *tail)

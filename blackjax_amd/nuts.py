@@ -69,13 +69,26 @@ def _make_info(p0, bufs, fs, is_, clone: bool):
     return HMCState(c(bufs["Pq"]), c(fs[F["PLOGP"]]), c(bufs["Pg"])), info
 
 
+def _dense_fields(kind, imm, N, D, max_depth, device):
+    """Extra descriptor fields + buffers for a dense metric (``bjx_nuts_t.Mdense`` ...): the
+    velocities M^{-1} p of the two trajectory ends and of the checkpointed momenta."""
+    if kind == "diag":
+        return {"fields": dict(Mdense=0, Mdense_stride=0, v0=0, Lv=0, Rv=0, ckpt_v=0), "keep": ()}
+    f32 = dict(dtype=torch.float32, device=device)
+    lv, rv = torch.empty((N, D), **f32), torch.empty((N, D), **f32)
+    ck_v = torch.empty((N, max(max_depth, 1), D), **f32)
+    return {"fields": dict(Mdense=imm.data_ptr(), Mdense_stride=D * D if kind == "dense_pc" else 0,
+                           v0=0, Lv=lv.data_ptr(), Rv=rv.data_ptr(), ckpt_v=ck_v.data_ptr()),
+            "keep": (lv, rv, ck_v)}
+
+
 class _GraphWorkspace:
     """Static device buffers + captured chunk graphs for the ``use_graph`` driver."""
 
     MAX_CHUNK = 16
     MIN_BUCKET = 256
 
-    def __init__(self, N, D, max_depth, vg, imm_per_chain, thr, device):
+    def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device):
         self.N, self.D, self.max_depth, self.vg = N, D, max_depth, vg
         f32 = dict(dtype=torch.float32, device=device)
         self.bufs = {n: torch.empty((N, D), **f32) for n in _BUFS}
@@ -84,17 +97,19 @@ class _GraphWorkspace:
         self.fs = torch.empty((_lib.NUTS_NF, N), **f32)
         self.is_ = torch.empty((_lib.NUTS_NI, N), dtype=torch.int32, device=device)
         self.eps = torch.ones(N, **f32)
-        self.imm = torch.ones((N, D) if imm_per_chain else (D,), **f32)
+        self.imm = torch.ones(imm_shape, **f32)  # static copy of the (diag or dense) metric
         self.idx = torch.arange(N, dtype=torch.int32, device=device)
         self.qf = torch.zeros((N, D), **f32)
         self.ctl = torch.zeros(8, dtype=torch.int64, device=device)
+        self.dense = _dense_fields(kind, self.imm, N, D, max_depth, device)
         self.desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=self.imm.data_ptr(),
-            imm_stride=D if imm_per_chain else 0, eps_per_chain=self.eps.data_ptr(), eps=0.0,
+            imm_stride=D if (kind == "diag" and len(imm_shape) == 2) else 0,
+            eps_per_chain=self.eps.data_ptr(), eps=0.0,
             divergence_threshold=thr, key0=0, key1=0, chain_offset=0, step_fold=-1,
             q0=0, g0=0, p0=0, ckpt_r=self.ck_r.data_ptr(), ckpt_rs=self.ck_rs.data_ptr(),
             fs=self.fs.data_ptr(), is_=self.is_.data_ptr(),
-            **{n: b.data_ptr() for n, b in self.bufs.items()})
+            **{n: b.data_ptr() for n, b in self.bufs.items()}, **self.dense["fields"])
         self.graphs: dict = {}
 
     def bucket(self, n_rows: int) -> int:
@@ -161,20 +176,27 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         k0, k1, fold = key_spec(rng_key)
         vg = value_and_grad(logdensity_fn)
         metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
-        if metric.kind != "diag":
-            raise NotImplementedError("NUTS with a dense mass matrix is not implemented yet")
         eps, eps_pc = step_size_args(step_size, N, q0.device)
         stream = _lib.current_stream()
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, int(chain_offset), fold, N, D,
-                  metric.imm.data_ptr(), metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
-        return q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0
+        v0 = None
+        if metric.kind == "diag":
+            _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, int(chain_offset), fold, N, D,
+                      metric.imm.data_ptr(), metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
+        else:
+            # dense metric (shared or per chain): fp64-accumulated matrix-vector kernels throughout,
+            # so tree decisions stay bit-compatible with the oracle
+            from . import dense
+
+            v0 = dense.momentum(stream, metric, k0, k1, int(chain_offset), fold, N, D, p0, ke0,
+                                force_pc=True)
+        return q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0, v0
 
     def kernel_eager(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                      inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
-        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0,
-         ke0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
+        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0,
+         v0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
         dev = q0.device
         max_depth = int(max_num_doublings)
         bufs = {n: torch.empty_like(q0) for n in _BUFS}
@@ -182,13 +204,16 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         ck_rs = torch.empty_like(ck_r)
         fs = torch.empty((_lib.NUTS_NF, N), dtype=torch.float32, device=dev)
         is_ = torch.empty((_lib.NUTS_NI, N), dtype=torch.int32, device=dev)
+        dense_f = _dense_fields(metric.kind, metric.imm, N, D, max_depth, dev)
+        if v0 is not None:
+            dense_f["fields"]["v0"] = v0.data_ptr()
         desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=metric.imm.data_ptr(),
             imm_stride=metric.imm_stride, eps_per_chain=_lib.ptr(eps_pc), eps=eps,
             divergence_threshold=thr, key0=k0, key1=k1, chain_offset=int(chain_offset),
             step_fold=fold, q0=q0.data_ptr(), g0=g0.data_ptr(), p0=p0.data_ptr(),
             ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(), is_=is_.data_ptr(),
-            **{n: b.data_ptr() for n, b in bufs.items()})
+            **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"])
         dref = ctypes.byref(desc)
         _lib.call("bjx_nuts_init", stream, dref, logp0.data_ptr(), ke0.data_ptr())
 
@@ -233,15 +258,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
 
     def kernel_graph(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                      inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
-        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0,
-         ke0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
+        (q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0,
+         v0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
         max_depth = int(max_num_doublings)
         off = int(chain_offset)
-        wkey = (N, D, max_depth, id(vg), metric.imm_stride != 0, q0.device.index)
+        wkey = (N, D, max_depth, id(vg), metric.kind, tuple(metric.imm.shape), q0.device.index)
         ws = workspaces.get(wkey)
         if ws is None:
-            ws = workspaces[wkey] = _GraphWorkspace(N, D, max_depth, vg, metric.imm_stride != 0, thr,
-                                                    q0.device)
+            ws = workspaces[wkey] = _GraphWorkspace(N, D, max_depth, vg, tuple(metric.imm.shape),
+                                                    metric.kind, thr, q0.device)
         if eps_pc is None:
             ws.eps.fill_(eps)
         else:
@@ -250,6 +275,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         d = ws.desc
         d.key0, d.key1, d.chain_offset, d.step_fold = k0, k1, off, fold
         d.q0, d.g0, d.p0 = q0.data_ptr(), g0.data_ptr(), p0.data_ptr()
+        d.v0 = v0.data_ptr() if v0 is not None else 0
         dref = ctypes.byref(d)
         _lib.call("bjx_nuts_init", stream, dref, logp0.data_ptr(), ke0.data_ptr())
         chunk_max = ws.MAX_CHUNK

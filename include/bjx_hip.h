@@ -135,18 +135,23 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
  * words per chain, not by MFMA).  Same contracts as the shared-matrix entry points above.
  *
  * y[c][i] = sum_j M[c][j][i] * x[c][j]   (M^T x per chain; the building block). */
-int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, const float* x, float* y);
+int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, int64_t matrix_stride,
+                    const float* x, float* y);
+/* matrix_stride = D*D for (N, D, D) per-chain matrices, 0 to apply ONE (D, D) matrix to every chain
+ * through the same fp64-accumulated kernels (used by NUTS with a shared dense metric, where
+ * bit-compatibility with the oracle matters more than MFMA throughput). */
 int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                               int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
-                              const float* imm, float* z_work, float* v_work, float* p_out,
-                              float* ke_out);
+                              const float* imm, int64_t matrix_stride, float* z_work, float* v_work,
+                              float* p_out, float* ke_out);
 /* p_out may alias p_in here (each element is read and written by the same lane). */
 int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
-                          const float* eps_per_chain, const float* imm, const float* q_in,
-                          const float* p_in, const float* g, float* q_out, float* p_out);
+                          const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                          const float* q_in, const float* p_in, const float* g, float* q_out,
+                          float* p_out);
 int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                             int64_t step_fold, int64_t N, int64_t D, float eps,
-                            const float* eps_per_chain, const float* imm,
+                            const float* eps_per_chain, const float* imm, int64_t matrix_stride,
                             float divergence_threshold, const float* q0, const float* logp0,
                             const float* g0, const float* ke0, const float* q1, const float* logp1,
                             const float* g1, const float* p, float* p1_work, float* v_work,

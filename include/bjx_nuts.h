@@ -79,6 +79,15 @@ typedef struct {
   float *ckpt_r, *ckpt_rs;    /* (N, max_depth, D) U-turn checkpoints (termination.py:46-54) */
   float* fs;                  /* (BJX_NUTS_NF, N) */
   int32_t* is;                /* (BJX_NUTS_NI, N) */
+  /* Dense metric (Mdense != NULL; `imm` is then ignored): velocities M^{-1} p are fp64-accumulated
+   * matrix-vector products (metrics.py:263-304 with util.py:58-61); the velocities of the two
+   * trajectory ends and of every checkpointed momentum are kept so U-turn checks need no extra
+   * products. */
+  const float* Mdense;        /* (D, D) shared [stride 0] or (N, D, D) per chain [stride D*D] */
+  int64_t Mdense_stride;
+  const float* v0;            /* (N, D) M^{-1} p0 from the momentum draw */
+  float *Lv, *Rv;             /* (N, D) velocities of the leftmost / rightmost state */
+  float* ckpt_v;              /* (N, max_depth, D) velocities of the checkpointed momenta */
 } bjx_nuts_t;
 
 /* Start of a transition: trajectory = (z0, z0, momentum_sum = p0, num_states = 0), proposal =

@@ -127,9 +127,15 @@ def test_pc_matvec_t(dev, N, D):
     x = rng.standard_normal((N, D)).astype(np.float32)
     y = torch.empty(N, D, device=dev)
     Mt, xt = dev_t(M, dev), dev_t(x, dev)
-    _lib.call("bjx_pc_matvec_t", _lib.current_stream(), N, D, Mt.data_ptr(), xt.data_ptr(), y.data_ptr())
+    _lib.call("bjx_pc_matvec_t", _lib.current_stream(), N, D, Mt.data_ptr(), D * D, xt.data_ptr(),
+              y.data_ptr())
     ref = np.einsum("nji,nj->ni", M.astype(np.float64), x.astype(np.float64)).astype(np.float32)
     assert np.array_equal(t2n(y), ref)  # fp64 accumulation on both sides: bit-identical
+    # one shared matrix applied to every chain (matrix_stride = 0)
+    _lib.call("bjx_pc_matvec_t", _lib.current_stream(), N, D, Mt.data_ptr(), 0, xt.data_ptr(),
+              y.data_ptr())
+    ref0 = (x.astype(np.float64) @ M[0].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(t2n(y), ref0)
 
 
 def test_welford_dense_kernels_bit_exact(dev):

@@ -118,3 +118,33 @@ def test_nuts_max_depth_zero_and_one(dev):
     alg1 = bjx.nuts(fn, 0.1, torch.ones(D, device=dev), max_num_doublings=1)
     st3, info1 = alg1.step(bjx.random.key(0), st)
     assert torch.all(info1.num_integration_steps == 1) and torch.all(info1.num_trajectory_expansions == 1)
+
+
+@pytest.mark.parametrize("per_chain,use_graph", [(False, False), (True, False), (False, True)])
+def test_nuts_dense_metric_parity(dev, per_chain, use_graph):
+    """NUTS with a dense inverse mass matrix (shared (D, D) or one per chain (N, D, D)): velocities are
+    fp64-accumulated matrix-vector products on both sides, U-turn checks use the stored velocities
+    (metrics.py:272-304).  reference tests/mcmc/test_sampling.py:317-379 runs nuts x dense."""
+    N, D, T = 14, 9, 3
+    rho = 0.7
+    fn_o = otargets.ar1_gaussian(rho, D)
+    rng = np.random.default_rng(1)
+    if per_chain:
+        a = rng.standard_normal((N, D, D))
+        imm = (a @ np.swapaxes(a, 1, 2) / D + 0.5 * np.eye(D)).astype(np.float32)
+    else:
+        imm = otargets.ar1_covariance(rho, D)
+    q0 = prng.normal(prng.key(6), (N, D)).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    alg = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.35, dev_t(imm, dev), max_num_doublings=6,
+                   use_graph=use_graph)
+    st_g = alg.init(dev_t(q0, dev))
+    for k in prng.split(prng.key(8), T):
+        st_o, info_o = onuts.kernel(k, st_o, fn_o, np.float32(0.35), imm, 6)
+        st_g, info_g = alg.step(k, st_g)
+        assert np.array_equal(t2n(info_g.num_integration_steps), info_o.num_integration_steps)
+        assert np.array_equal(t2n(info_g.num_trajectory_expansions), info_o.num_trajectory_expansions)
+        assert np.array_equal(t2n(info_g.is_turning), info_o.is_turning)
+        np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(t2n(info_g.momentum), info_o.momentum, rtol=1e-5, atol=1e-6)
