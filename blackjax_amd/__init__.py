@@ -7,6 +7,8 @@ kernels (``libbjxhip.so``, C ABI in ``include/bjx_hip.h``).  There is no CPU fal
 """
 from __future__ import annotations
 
+import functools as _functools
+
 from . import hmc as _hmc
 from . import nuts as _nuts
 from . import adaptation, diagnostics, distributed, integrators, metrics, random, targets, util
@@ -30,5 +32,12 @@ class GenerateSamplingAPI:
 
 hmc = GenerateSamplingAPI(_hmc.as_top_level_api, _hmc.init, _hmc.build_kernel)
 nuts = GenerateSamplingAPI(_nuts.as_top_level_api, _nuts.init, _nuts.build_kernel)
+# blackjax/__init__.py:145-151: multinomial HMC shares HMCState / init with hmc
+mhmc = GenerateSamplingAPI(
+    _functools.partial(_hmc.as_top_level_api, build_proposal=_hmc.multinomial_hmc_proposal),
+    _hmc.init,
+    _functools.partial(_hmc.build_kernel, build_proposal=_hmc.multinomial_hmc_proposal),
+)
+multinomial_hmc = mhmc
 
-__all__ = ["hmc", "nuts", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
+__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc","window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]

@@ -193,6 +193,136 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, floa
   }
 }
 
+// ------------------------------------------------------------------------------ multinomial HMC
+// One step of static_progressive_integration (trajectory.py:214-225) fused with the opening half of
+// the next leapfrog.  Input: p = momentum after the OPENING half kick of step i, g = gradient at the
+// new position q.  Pass 1: closing half kick + kinetic energy -> proposal weight, divergence,
+// progressive uniform sampling with key fold_in(key_integrator, i) (proposal.py:118-143).
+// Pass 2: reservoir update on accept; if do_next, opening half kick + drift of step i+1 in place.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64_t step, int do_next,
+                 float eps_s, const float* __restrict__ eps_pc, const float* __restrict__ imm,
+                 int64_t imm_stride, float thr, const float* __restrict__ logp0,
+                 const float* __restrict__ ke0, float* q, float* p, const float* __restrict__ g,
+                 const float* __restrict__ logp_new, float* __restrict__ W, float* __restrict__ S,
+                 uint8_t* __restrict__ any_div, uint8_t* __restrict__ ever, float* __restrict__ Rq,
+                 float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
+                 float* __restrict__ Renergy) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const float eps = eps_pc ? eps_pc[r] : eps_s;
+    const float h = eps * 0.5f;
+    const int64_t base = r * D;
+    const float* im = imm + r * imm_stride;
+    double acc = 0.0;
+    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
+      if constexpr (VEC == 4) {
+        const F4 pp = ld4(p + base + j), gg = ld4(g + base + j), mm = ld4(im + j);
+        const float a = fmaf(h, gg.x, pp.x), b = fmaf(h, gg.y, pp.y);
+        const float c = fmaf(h, gg.z, pp.z), d = fmaf(h, gg.w, pp.w);
+        acc += (double)(mm.x * a) * (double)a + (double)(mm.y * b) * (double)b;
+        acc += (double)(mm.z * c) * (double)c + (double)(mm.w * d) * (double)d;
+      } else {
+        const float a = fmaf(h, g[base + j], p[base + j]);
+        acc += (double)(im[j] * a) * (double)a;
+      }
+    }
+    acc = wave_sum(acc);
+    const float ke = 0.5f * (float)acc;
+    const float lp = logp_new[r];
+    const float H0 = -logp0[r] + ke0[r];
+    const float e_new = -lp + ke;
+    float w = H0 - e_new;
+    if (w != w) w = -__builtin_inff();
+    const float s_new = fminf(w, 0.0f);
+    const bool is_div = (-w) > thr;
+    const float Wc = W[r];
+    const Key ki = key_child(chain_key(key, (uint64_t)(r + off), fold), 1);
+    const float u = key_uniform(key_child(ki, (uint64_t)step));
+    const float pa = (float)(1.0 / (1.0 + exp(-(double)(w - Wc))));  // expit
+    const bool take = u < pa;
+    // logaddexp in fp64, rounded once (same formula as np.logaddexp)
+    auto lae = [](float a, float b) {
+      const double x = (double)a, y = (double)b;
+      if (x == y) return (float)(x + 0.6931471805599453);
+      const double t = x - y;
+      if (t > 0) return (float)(x + log1p(exp(-t)));
+      if (t <= 0) return (float)(y + log1p(exp(t)));
+      return (float)t;
+    };
+    const float Wn = lae(Wc, w), Sn = lae(S[r], s_new);
+    if (lane == 0) {
+      W[r] = Wn;
+      S[r] = Sn;
+      if (is_div) any_div[r] = 1;
+      if (take) {
+        ever[r] = 1;
+        Rlogp[r] = lp;
+        Renergy[r] = e_new;
+      }
+    }
+    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
+      if constexpr (VEC == 4) {
+        const F4 pp = ld4(p + base + j), gg = ld4(g + base + j), qq = ld4(q + base + j);
+        F4 pf{fmaf(h, gg.x, pp.x), fmaf(h, gg.y, pp.y), fmaf(h, gg.z, pp.z), fmaf(h, gg.w, pp.w)};
+        if (take) {
+          st4(Rq + base + j, qq);
+          st4(Rp + base + j, pf);
+          st4(Rg + base + j, gg);
+        }
+        if (do_next) {
+          const F4 mm = ld4(im + j);
+          F4 pn{fmaf(h, gg.x, pf.x), fmaf(h, gg.y, pf.y), fmaf(h, gg.z, pf.z), fmaf(h, gg.w, pf.w)};
+          F4 qn{fmaf(eps, mm.x * pn.x, qq.x), fmaf(eps, mm.y * pn.y, qq.y),
+                fmaf(eps, mm.z * pn.z, qq.z), fmaf(eps, mm.w * pn.w, qq.w)};
+          st4(p + base + j, pn);
+          st4(q + base + j, qn);
+        }
+      } else {
+        const float gg = g[base + j], qq = q[base + j];
+        const float pf = fmaf(h, gg, p[base + j]);
+        if (take) {
+          Rq[base + j] = qq;
+          Rp[base + j] = pf;
+          Rg[base + j] = gg;
+        }
+        if (do_next) {
+          const float pn = fmaf(h, gg, pf);
+          p[base + j] = pn;
+          q[base + j] = fmaf(eps, im[j] * pn, qq);
+        }
+      }
+    }
+  }
+}
+
+// Chains that never replaced the initial proposal keep z0 (trajectory.py:212); acceptance_rate =
+// exp(sum_log_p_accept) / L (hmc.py:234).
+__global__ void __launch_bounds__(kBlock)
+k_mhmc_finish(int64_t N, int64_t D, float n_steps, const float* __restrict__ q0,
+              const float* __restrict__ p0, const float* __restrict__ g0,
+              const float* __restrict__ logp0, const float* __restrict__ ke0,
+              const uint8_t* __restrict__ ever, const float* __restrict__ S, float* __restrict__ Rq,
+              float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
+              float* __restrict__ Renergy, float* __restrict__ acc_rate) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    if (lane == 0) acc_rate[r] = exp_cr(S[r]) / n_steps;
+    if (ever[r]) continue;
+    const int64_t base = r * D;
+    for (int64_t j = lane; j < D; j += 64) {
+      Rq[base + j] = q0[base + j];
+      Rp[base + j] = p0[base + j];
+      Rg[base + j] = g0[base + j];
+    }
+    if (lane == 0) {
+      Rlogp[r] = logp0[r];
+      Renergy[r] = -logp0[r] + ke0[r];
+    }
+  }
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -283,6 +413,51 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
   else BJX_FIN(1);
 #undef BJX_FIN
   return bjx_check_launch("bjx_hmc_finish_diag");
+}
+
+int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                       int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                       const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                       float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                       float* p, const float* g, const float* logp_new, float* weight,
+                       float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                       float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                       float* prop_energy) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
+                    weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q && prop_p &&
+                    prop_g && prop_logp && prop_energy,
+                "bjx_mhmc_step_diag: bad arguments");
+  BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_mhmc_step_diag: imm_stride must be 0 or D");
+  if (N == 0) return 0;
+  const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
+  const Key key{key0, key1};
+  hipStream_t s = (hipStream_t)stream;
+#define BJX_MH(V)                                                                               \
+  hipLaunchKernelGGL(k_mhmc_step_diag<V>, grid, block, 0, s, key, chain_offset, step_fold, N, D, \
+                     step, do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold,  \
+                     logp0, ke0, q, p, g, logp_new, weight, sum_log_p_accept, any_divergent,    \
+                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy)
+  if (bjx_vec4_ok(D, imm, q, p, g, prop_q, prop_p, prop_g)) BJX_MH(4);
+  else BJX_MH(1);
+#undef BJX_MH
+  return bjx_check_launch("bjx_mhmc_step_diag");
+}
+
+int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_steps,
+                    const float* q0, const float* p0, const float* g0, const float* logp0,
+                    const float* ke0, const uint8_t* ever_accepted, const float* sum_log_p_accept,
+                    float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
+                    float* acceptance_rate_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0 && q0 && p0 && g0 && logp0 && ke0 && ever_accepted &&
+                    sum_log_p_accept && prop_q && prop_p && prop_g && prop_logp && prop_energy &&
+                    acceptance_rate_out,
+                "bjx_mhmc_finish: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_mhmc_finish, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, N, D, (float)num_integration_steps, q0, p0, g0, logp0, ke0,
+                     ever_accepted, sum_log_p_accept, prop_q, prop_p, prop_g, prop_logp, prop_energy,
+                     acceptance_rate_out);
+  return bjx_check_launch("bjx_mhmc_finish");
 }
 
 }  // extern "C"

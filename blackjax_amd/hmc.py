@@ -73,6 +73,79 @@ def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, 
     return dense.leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out)
 
 
+class _ProposalKind:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return self.name
+
+
+#: selectors for ``build_kernel(build_proposal=...)`` (blackjax/mcmc/hmc.py:115-178, 181-248)
+hmc_proposal = _ProposalKind("hmc_proposal")
+multinomial_hmc_proposal = _ProposalKind("multinomial_hmc_proposal")
+
+
+def _build_mhmc_kernel(thr: float):
+    """blackjax.mhmc: ``build_kernel(build_proposal=multinomial_hmc_proposal)`` (hmc.py:181-248 with
+    trajectory.static_progressive_integration 170-232).  Instead of the trajectory end point, one
+    state of the whole trajectory is drawn proportionally to exp(-H) by progressive (reservoir)
+    sampling; there is no Metropolis rejection (``is_accepted`` is always True)."""
+
+    def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+               inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
+        q0 = check_batch(state.position, "state.position")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        N, D = q0.shape
+        L = int(num_integration_steps)
+        if L < 0:
+            raise ValueError("num_integration_steps must be >= 0")
+        k0, k1, fold = key_spec(rng_key)
+        vg = value_and_grad(logdensity_fn)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
+        if metric.kind != "diag":
+            raise NotImplementedError("multinomial HMC is implemented for diagonal metrics only")
+        eps, eps_pc = step_size_args(step_size, N, q0.device)
+        stream = _lib.current_stream()
+        off = int(chain_offset)
+        dev = q0.device
+        imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+
+        p0 = torch.empty_like(q0)
+        ke0 = torch.empty_like(logp0)
+        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
+                  p0.data_ptr(), ke0.data_ptr())
+        weight = torch.zeros_like(logp0)
+        slpa = torch.full_like(logp0, float("-inf"))
+        any_div = torch.zeros(N, dtype=torch.bool, device=dev)
+        ever = torch.zeros(N, dtype=torch.bool, device=dev)
+        pq, pp, pg = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
+        plogp, penergy = torch.empty_like(logp0), torch.empty_like(logp0)
+        acc_rate = torch.empty_like(logp0)
+        if L > 0:
+            q, p = torch.empty_like(q0), torch.empty_like(q0)
+            _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                      q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
+            for i in range(L):
+                logp, g = eval_logdensity(vg, q)
+                _lib.call("bjx_mhmc_step_diag", stream, k0, k1, off, fold, N, D, i,
+                          1 if i + 1 < L else 0, eps, _lib.ptr(eps_pc), imm_p, imm_s, thr,
+                          logp0.data_ptr(), ke0.data_ptr(), q.data_ptr(), p.data_ptr(), g.data_ptr(),
+                          logp.data_ptr(), weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(),
+                          ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
+                          plogp.data_ptr(), penergy.data_ptr())
+        _lib.call("bjx_mhmc_finish", stream, N, D, L, q0.data_ptr(), p0.data_ptr(), g0.data_ptr(),
+                  logp0.data_ptr(), ke0.data_ptr(), ever.data_ptr(), slpa.data_ptr(), pq.data_ptr(),
+                  pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr(),
+                  acc_rate.data_ptr())
+        info = HMCInfo(p0, acc_rate, torch.ones(N, dtype=torch.bool, device=dev), any_div, penergy,
+                       IntegratorState(pq, pp, plogp, pg), L)
+        return HMCState(pq, plogp, pg), info
+
+    return kernel
+
+
 def _default_chain_block():
     import os
 
@@ -142,9 +215,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     graph (diagonal metric; the callable must be capturable: static shapes, no host sync).
     """
     integrators.check_supported(integrator)
-    if build_proposal is not None:
-        raise NotImplementedError("only the default hmc_proposal is implemented")
     thr = float(divergence_threshold)
+    if build_proposal is multinomial_hmc_proposal:
+        return _build_mhmc_kernel(thr)
+    if build_proposal not in (None, hmc_proposal):
+        raise NotImplementedError(
+            "build_proposal must be hmc_proposal (default) or multinomial_hmc_proposal")
     if chain_block is None:
         chain_block = _default_chain_block()
     graphs: dict = {}

@@ -96,6 +96,35 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                         float* acceptance_rate_out, uint8_t* is_accepted_out,
                         uint8_t* is_divergent_out, float* energy_out);
 
+/* ---- multinomial HMC (blackjax.mhmc) ----------------------------
+ * One step of static_progressive_integration fused with the opening half of the next leapfrog.
+ * On entry p holds the momentum after the OPENING half kick of leapfrog `step` and (q, g,
+ * logp_new) the new position and the callable's outputs there.  The kernel applies the closing
+ * half kick, forms the proposal weight w = H0 - H (NaN -> -inf), any_divergent |= -w > threshold,
+ * draws u = uniform(fold_in(key_integrator, step)), accepts the new state into the reservoir
+ * (prop_*) with probability expit(w - weight), updates weight and sum_log_p_accept by logaddexp,
+ * and, if do_next, performs the opening half kick + drift of leapfrog step+1 in place on (q, p).
+ * weight / sum_log_p_accept: (N,) initialised to 0 / -inf; ever_accepted / any_divergent: (N,)
+ * uint8 initialised to 0.  H0 = -logp0 + ke0.
+ * Replaces: blackjax/mcmc/hmc.py:181-248 ; trajectory.py:170-232 ; proposal.py:51-105,118-143. */
+int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                       int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                       const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                       float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                       float* p, const float* g, const float* logp_new, float* weight,
+                       float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                       float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                       float* prop_energy);
+
+/* End of a multinomial-HMC transition: chains whose reservoir never replaced the initial state get
+ * (q0, p0, g0, logp0, H0) copied into prop_*; acceptance_rate = exp(sum_log_p_accept) / L
+ * (hmc.py:234).  prop_(q, logp, g) is the new chain state. */
+int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_steps,
+                    const float* q0, const float* p0, const float* g0, const float* logp0,
+                    const float* ke0, const uint8_t* ever_accepted, const float* sum_log_p_accept,
+                    float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
+                    float* acceptance_rate_out);
+
 /* ---- dense Gaussian-Euclidean metric (one (D, D) inverse mass matrix shared by all chains) ----
  * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32, exact fp32 fma chains: "precision=highest",
  * blackjax/util.py:23-61).  All matrices row-major.

@@ -192,6 +192,51 @@ def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matr
     return new_state, info
 
 
+def mhmc_kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
+                num_integration_steps: int, divergence_threshold: float = 1000.0,
+                chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False):
+    """blackjax.mhmc: hmc.build_kernel(build_proposal=multinomial_hmc_proposal)
+    (hmc.py:181-248, 279-312) with static_progressive_integration (trajectory.py:170-232) and
+    progressive_uniform_sampling (proposal.py:118-143), batched over chains."""
+    from .fp import expit_cr, logaddexp_cr
+
+    N, D = state.position.shape
+    L = int(num_integration_steps)
+    metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
+    keys = chain_keys(rng_key, N, chain_offset) if chain_keys_override is None else chain_keys_override
+    kk = prng.split(keys, 2)  # hmc.py:299
+    key_momentum, key_integrator = kk[:, 0], kk[:, 1]
+    p0 = sample_momentum(metric, key_momentum, D)
+    z0 = IntegratorState(state.position, p0, state.logdensity, state.logdensity_grad)
+    e0 = hmc_energy(metric, z0)  # trajectory.py:211
+    prop = [z0.position.copy(), z0.momentum.copy(), z0.logdensity.copy(), z0.logdensity_grad.copy()]
+    prop_energy = e0.copy()
+    W = np.zeros(N, f32)  # Proposal(initial_state, initial_energy, 0.0, -inf)  trajectory.py:212
+    S = np.full(N, -np.inf, f32)
+    any_div = np.zeros(N, bool)
+    z = z0
+    for i in range(L):  # trajectory.py:214-225
+        step_keys = prng.fold_in(key_integrator, np.uint32(i))
+        z = velocity_verlet(z, step_size, logdensity_fn, metric)
+        e_new = hmc_energy(metric, z)
+        w = safe_energy_diff(e0, e_new)  # proposal.py:91-95
+        s_new = np.minimum(w, f32(0.0))
+        any_div |= (-w) > f32(divergence_threshold)
+        with np.errstate(invalid="ignore"):
+            pa = expit_cr((w - W).astype(f32))  # progressive_uniform_sampling
+        acc = prng.uniform(step_keys, ()) < pa
+        W = logaddexp_cr(W, w)
+        S = logaddexp_cr(S, s_new)
+        for a, b in zip(prop, (z.position, z.momentum, z.logdensity, z.logdensity_grad)):
+            a[acc] = b[acc]
+        prop_energy = np.where(acc, e_new, prop_energy).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        acceptance_rate = (exp_cr(S) / f32(L)).astype(f32)  # hmc.py:234
+    proposal = IntegratorState(*prop)
+    info = HMCInfo(p0, acceptance_rate, np.ones(N, bool), any_div, prop_energy, proposal, L)
+    return HMCState(proposal.position, proposal.logdensity, proposal.logdensity_grad), info
+
+
 def run(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
         num_integration_steps, num_steps, divergence_threshold=1000.0, chain_offset=0):
     """util.py:150-213 run_inference_algorithm, step-major keys:

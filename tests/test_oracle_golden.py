@@ -100,3 +100,24 @@ def test_hmc_kernel_statistics_normal():
     d = np.concatenate(draws)
     np.testing.assert_allclose(d.mean(), 1.0, atol=0.1)
     np.testing.assert_allclose(d.var(), 4.0, rtol=0.1)
+
+
+def test_mhmc_oracle_statistics_normal():
+    """Multinomial HMC restatement (hmc.py:181-248): N(1, 2^2) target, mean/var within 0.1/10 %."""
+    from oracle import prng
+
+    def fn(q):
+        g = -(q - f32(1.0)) / f32(4.0)
+        return (0.5 * np.sum((q - f32(1.0)).astype(f64) * g, -1)).astype(f32), g.astype(f32)
+
+    N = 256
+    st = ohmc.init(np.ones((N, 1), f32), fn)
+    draws = []
+    for t, kk in enumerate(prng.split(prng.key(12), 60)):
+        st, info = ohmc.mhmc_kernel(kk, st, fn, f32(0.8), np.ones(1, f32) * 4, 6)
+        assert info.is_accepted.all()
+        if t >= 20:
+            draws.append(st.position.copy())
+    d = np.concatenate(draws)
+    np.testing.assert_allclose(d.mean(), 1.0, atol=0.1)
+    np.testing.assert_allclose(d.var(), 4.0, rtol=0.1)
