@@ -11,6 +11,10 @@ using namespace bjx;
 
 namespace {
 
+#ifndef BJX_REVERSE_ROWS
+#define BJX_REVERSE_ROWS 1
+#endif
+
 constexpr int kBlock = 256;                 // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
 
@@ -80,7 +84,13 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
                 const float* __restrict__ imm, int64_t imm_stride, const float* q_in,
                 const float* p_in, const float* __restrict__ g, float* q_out, float* p_out) {
   const int lane = threadIdx.x & 63;
-  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+  // Rows are swept LAST-TO-FIRST (workgroup 0 takes the last rows).  The user's callable, which
+  // runs between two leapfrog launches, sweeps first-to-last and leaves the tail of q / g in the
+  // 256 MiB Infinity Cache; starting there turns that part of this kernel's g/q reads into cache
+  // hits, and this kernel in turn finishes at row 0, which is where the next callable starts
+  // reading q.  Pure traversal order: results are unchanged.
+  for (int64_t rr = wave_row0(); rr < N; rr += wave_row_stride()) {
+    const int64_t r = BJX_REVERSE_ROWS ? N - 1 - rr : rr;
     const float eps = eps_pc ? eps_pc[r] : eps_s;
     const float h = eps * 0.5f;
     const int64_t base = r * D;

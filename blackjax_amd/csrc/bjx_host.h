@@ -24,8 +24,8 @@ static inline int bjx_check_launch(const char* what) {
   return 0;
 }
 
-// Row-per-wave kernels: enough workgroups to cover every CU several times over
-// several times over; grid-stride only beyond 65536 workgroups (BJX_MAX_BLOCKS overrides).
+// Row-per-wave kernels: one row per wave (>> 256 CUs worth of workgroups); grid-stride only
+// beyond 65536 workgroups (BJX_MAX_BLOCKS overrides).
 unsigned bjx_row_grid(int64_t n_rows, int waves_per_block);
 
 // 16-byte vector path is legal when D % 4 == 0 and every non-null pointer is 16-B aligned.
