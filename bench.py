@@ -125,8 +125,21 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for t in range(args.warmup):
-        state, info = alg.step(keys[t], state)
+    # Warm-up runs EXACTLY the timed loop's body (including the bookkeeping torch ops and the
+    # launch-timer events): on a fresh box the first use of any kernel pages its code object in from
+    # disk (tens of ms per torch op), which must not land in the timed region.
+    n_sub = min(1024, N)
+    warm_timer = None if args.no_launch_timing else _lib.LaunchTimer(["bjx_leapfrog_diag"])
+    _lib.set_timer(warm_timer)
+    warm_acc = torch.zeros((), device=dev)
+    prime_key = bjx.random.key(12345)
+    for t in range(-1, args.warmup):  # one extra priming pass (t = -1) in addition to the W warm-ups
+        state, info = alg.step(prime_key if t < 0 else keys[t], state)
+        warm_acc += info.acceptance_rate.mean()
+        _ = state.position[:n_sub].clone()
+    _lib.set_timer(None)
+    if warm_timer is not None:
+        warm_timer.durations_ms("bjx_leapfrog_diag")  # first elapsed_time() call warms that path too
     torch.cuda.synchronize()
 
     timer = None
@@ -134,7 +147,6 @@ def main():
         timer = _lib.LaunchTimer(["bjx_leapfrog_diag"])
         _lib.set_timer(timer)
     acc_sum = torch.zeros((), device=dev)
-    n_sub = min(1024, N)
     draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
     barrier()
     torch.cuda.synchronize()
