@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import functools as _functools
 
+from . import dynamic_hmc as _dynamic_hmc
 from . import hmc as _hmc
 from . import nuts as _nuts
 from . import adaptation, diagnostics, distributed, integrators, metrics, random, targets, util
@@ -39,5 +40,11 @@ mhmc = GenerateSamplingAPI(
     _functools.partial(_hmc.build_kernel, build_proposal=_hmc.multinomial_hmc_proposal),
 )
 multinomial_hmc = mhmc
+dynamic_hmc = GenerateSamplingAPI(_dynamic_hmc.as_top_level_api, _dynamic_hmc.init,
+                                  _dynamic_hmc.build_kernel)
+# batched counterparts of the reference's default callables (dynamic_hmc.py:69-70) + key seeding
+dynamic_hmc.next_key_fn = _dynamic_hmc.next_key_fn
+dynamic_hmc.randint_steps_fn = _dynamic_hmc.randint_steps_fn
+dynamic_hmc.chain_keys = _dynamic_hmc.chain_keys
 
-__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc","window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
+__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]

@@ -82,7 +82,8 @@ template <int VEC, int KICKS>
 __global__ void __launch_bounds__(kBlock)
 k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps_pc,
                 const float* __restrict__ imm, int64_t imm_stride, const float* q_in,
-                const float* p_in, const float* __restrict__ g, float* q_out, float* p_out) {
+                const float* p_in, const float* __restrict__ g, float* q_out, float* p_out,
+                const int32_t* __restrict__ n_steps, int32_t step_idx) {
   const int lane = threadIdx.x & 63;
   // Rows are swept LAST-TO-FIRST (workgroup 0 takes the last rows).  The user's callable, which
   // runs between two leapfrog launches, sweeps first-to-last and leaves the tail of q / g in the
@@ -91,9 +92,19 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
   // reading q.  Pure traversal order: results are unchanged.
   for (int64_t rr = wave_row0(); rr < N; rr += wave_row_stride()) {
     const int64_t r = BJX_REVERSE_ROWS ? N - 1 - rr : rr;
+    const int64_t base = r * D;
+    if (n_steps && step_idx >= n_steps[r]) {
+      // dynamic HMC: this chain's trajectory is already complete -- leave its state untouched
+      // (copy it through when the launch is out of place)
+      if (q_out != q_in)
+        for (int64_t j = lane; j < D; j += 64) {
+          q_out[base + j] = q_in[base + j];
+          p_out[base + j] = p_in[base + j];
+        }
+      continue;
+    }
     const float eps = eps_pc ? eps_pc[r] : eps_s;
     const float h = eps * 0.5f;
-    const int64_t base = r * D;
     const float* im = imm + r * imm_stride;
     if constexpr (VEC == 4) {
 #pragma unroll 4
@@ -373,10 +384,10 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   return bjx_check_launch("bjx_hmc_momentum_diag");
 }
 
-int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
-                      const float* eps_per_chain, const float* imm, int64_t imm_stride,
-                      const float* q_in, const float* p_in, const float* g, float* q_out,
-                      float* p_out) {
+int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                             const float* q_in, const float* p_in, const float* g, float* q_out,
+                             float* p_out, const int32_t* n_steps, int32_t step_idx) {
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
                 "bjx_leapfrog_diag: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_diag: n_kicks must be 1 or 2");
@@ -386,7 +397,7 @@ int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps
   hipStream_t s = (hipStream_t)stream;
 #define BJX_LF(V, K)                                                                          \
   hipLaunchKernelGGL((k_leapfrog_diag<V, K>), grid, block, 0, s, N, D, eps, eps_per_chain, imm, \
-                     imm_stride, q_in, p_in, g, q_out, p_out)
+                     imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx)
   if (bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     if (n_kicks == 1) BJX_LF(4, 1); else BJX_LF(4, 2);
   } else {
@@ -394,6 +405,61 @@ int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps
   }
 #undef BJX_LF
   return bjx_check_launch("bjx_leapfrog_diag");
+}
+
+int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                      const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                      const float* q_in, const float* p_in, const float* g, float* q_out,
+                      float* p_out) {
+  return bjx_leapfrog_diag_masked(stream, N, D, n_kicks, eps, eps_per_chain, imm, imm_stride, q_in,
+                                  p_in, g, q_out, p_out, nullptr, 0);
+}
+
+namespace {
+// split(key, 2)[child] per chain: keys_out[i] = threefry(keys_in[i], (0, child))
+__global__ void k_keys_child(int64_t N, const uint32_t* __restrict__ kin, uint32_t child,
+                             uint32_t* __restrict__ kout) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Key k = key_child(Key{kin[2 * i], kin[2 * i + 1]}, child);
+  kout[2 * i] = k.k0;
+  kout[2 * i + 1] = k.k1;
+}
+
+// jax.random.randint(key, (), minval, maxval, int32) per chain (jax/_src/random.py::_randint)
+__global__ void k_keys_randint(int64_t N, const uint32_t* __restrict__ kin, int32_t minval,
+                               int32_t maxval, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Key key{kin[2 * i], kin[2 * i + 1]};
+  const uint32_t hi = key_bits32(key_child(key, 0), 0);  // random_bits(split(key)[0], 32, ())
+  const uint32_t lo = key_bits32(key_child(key, 1), 0);
+  uint32_t span = (uint32_t)(maxval - minval);
+  if (maxval <= minval) span = 1u;
+  uint32_t mult = (1u << 16) % span;  // 2^32 % span computed as ((2^16 % span)^2) % span
+  mult = (mult * mult) % span;
+  uint32_t off = (hi % span) * mult + (lo % span);
+  off %= span;
+  out[i] = minval + (int32_t)off;
+}
+}  // namespace
+
+int bjx_keys_child(void* stream, int64_t N, const uint32_t* keys_in, uint32_t child,
+                   uint32_t* keys_out) {
+  BJX_CHECK_ARG(N >= 0 && keys_in && keys_out, "bjx_keys_child: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_keys_child, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, N, keys_in, child, keys_out);
+  return bjx_check_launch("bjx_keys_child");
+}
+
+int bjx_keys_randint(void* stream, int64_t N, const uint32_t* keys, int32_t minval, int32_t maxval,
+                     int32_t* out) {
+  BJX_CHECK_ARG(N >= 0 && keys && out, "bjx_keys_randint: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_keys_randint, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, N, keys, minval, maxval, out);
+  return bjx_check_launch("bjx_keys_randint");
 }
 
 int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

@@ -1,0 +1,163 @@
+"""Batched dynamic HMC (random trajectory length per chain and transition) behind the
+``blackjax.dynamic_hmc`` API surface (blackjax/mcmc/dynamic_hmc.py).
+
+Mirrors ``DynamicHMCState`` (39-52), ``init`` (55-61), ``build_kernel`` (65-126) and
+``as_top_level_api`` (129-223).  Every chain carries its own ``random_generator_arg`` (one threefry
+key per chain, ``(N, 2)`` uint32 stored as int32 bit patterns on the device), draws its own number
+of integration steps from it and advances it, exactly as the vmapped reference does.
+
+The transition itself is ``blackjax_amd.hmc``'s with a per-chain trajectory length: the leapfrog
+kernel takes the ``(N,)`` step counts and leaves finished chains untouched
+(``bjx_leapfrog_diag_masked``); the host loops to the longest trajectory of the batch.
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple
+
+import numpy as np
+import torch
+
+from . import _lib, integrators, metrics
+from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
+from .base import SamplingAlgorithm
+from .hmc import HMCInfo, IntegratorState
+from .random import key_spec
+
+__all__ = ["DynamicHMCState", "init", "build_kernel", "as_top_level_api", "chain_keys",
+           "next_key_fn", "randint_steps_fn"]
+
+
+class DynamicHMCState(NamedTuple):
+    """blackjax/mcmc/dynamic_hmc.py:39-52, batched."""
+
+    position: torch.Tensor
+    logdensity: torch.Tensor
+    logdensity_grad: torch.Tensor
+    random_generator_arg: torch.Tensor  # (N, 2) int32: per-chain threefry key words (bit patterns)
+
+
+def chain_keys(rng_key, n_chains: int, device, chain_offset: int = 0) -> torch.Tensor:
+    """``jax.random.split(rng_key, N)`` as a device tensor: the usual way to seed
+    ``random_generator_arg`` for N chains."""
+    from . import random as bjx_random
+
+    k = bjx_random.split(rng_key, n_chains, offset=chain_offset).view(np.int32)
+    return torch.as_tensor(k, device=device).contiguous()
+
+
+def next_key_fn(keys: torch.Tensor) -> torch.Tensor:
+    """Default ``next_random_arg_fn``: ``lambda key: jax.random.split(key)[1]`` per chain
+    (dynamic_hmc.py:69)."""
+    out = torch.empty_like(keys)
+    _lib.call("bjx_keys_child", _lib.current_stream(), keys.shape[0], keys.data_ptr(), 1,
+              out.data_ptr())
+    return out
+
+
+def randint_steps_fn(keys: torch.Tensor, minval: int = 1, maxval: int = 10) -> torch.Tensor:
+    """Default ``integration_steps_fn``: ``lambda key: jax.random.randint(key, (), 1, 10)`` per chain
+    (dynamic_hmc.py:70); extra ``integration_steps_params`` replace the bounds."""
+    out = torch.empty(keys.shape[0], dtype=torch.int32, device=keys.device)
+    _lib.call("bjx_keys_randint", _lib.current_stream(), keys.shape[0], keys.data_ptr(), int(minval),
+              int(maxval), out.data_ptr())
+    return out
+
+
+def init(position: torch.Tensor, logdensity_fn: Callable, random_generator_arg: torch.Tensor):
+    """blackjax/mcmc/dynamic_hmc.py:55-61."""
+    position = check_batch(position, "position")
+    logp, grad = eval_logdensity(value_and_grad(logdensity_fn), position)
+    rga = random_generator_arg
+    if rga.shape != (position.shape[0], 2) or rga.dtype != torch.int32 or not rga.is_cuda:
+        raise ValueError("random_generator_arg must be a device (n_chains, 2) int32 tensor of key words "
+                         "(see dynamic_hmc.chain_keys)")
+    return DynamicHMCState(position, logp, grad, rga.contiguous())
+
+
+def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: float = 1000,
+                 next_random_arg_fn: Callable = next_key_fn,
+                 integration_steps_fn: Callable = randint_steps_fn, build_proposal=None):
+    """blackjax/mcmc/dynamic_hmc.py:65-126.  ``integration_steps_fn(random_generator_arg, *params)``
+    returns an ``(N,)`` int32 device tensor of trajectory lengths (>= 1)."""
+    integrators.check_supported(integrator)
+    if build_proposal is not None:
+        raise NotImplementedError("dynamic_hmc is implemented for the default hmc_proposal only")
+    thr = float(divergence_threshold)
+
+    def kernel(rng_key, state: DynamicHMCState, logdensity_fn: Callable, step_size,
+               inverse_mass_matrix, integration_steps_params: tuple = (), *, chain_offset: int = 0):
+        q0 = check_batch(state.position, "state.position")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        N, D = q0.shape
+        dev = q0.device
+        k0, k1, fold = key_spec(rng_key)
+        vg = value_and_grad(logdensity_fn)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+        if metric.kind != "diag":
+            raise NotImplementedError("dynamic_hmc is implemented for diagonal metrics only")
+        eps, eps_pc = step_size_args(step_size, N, dev)
+        stream = _lib.current_stream()
+        off = int(chain_offset)
+        imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+
+        n_steps = integration_steps_fn(state.random_generator_arg, *integration_steps_params)
+        n_steps = n_steps.to(device=dev, dtype=torch.int32).contiguous()
+        lo, hi = int(n_steps.min()), int(n_steps.max())  # one host sync per transition
+        if lo < 1:
+            raise ValueError("integration_steps_fn must return at least 1 step for every chain")
+
+        p0 = torch.empty_like(q0)
+        ke0 = torch.empty_like(logp0)
+        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
+                  p0.data_ptr(), ke0.data_ptr())
+        q, p = torch.empty_like(q0), torch.empty_like(q0)
+        ns = n_steps.data_ptr()
+        _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                  q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), ns, 0)
+        logp, g = eval_logdensity(vg, q)
+        for l in range(1, hi):
+            # chains with n_steps <= l are skipped; their q is unchanged so the callable keeps
+            # returning the same (logp, g) for them
+            _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                      q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr(), ns, l)
+            logp, g = eval_logdensity(vg, q)
+
+        p_end, q_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
+        logp_new, acc_rate, energy = (torch.empty_like(logp0) for _ in range(3))
+        is_acc = torch.empty(N, dtype=torch.bool, device=dev)
+        is_div = torch.empty(N, dtype=torch.bool, device=dev)
+        _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, fold, N, D, eps, _lib.ptr(eps_pc), imm_p,
+                  imm_s, thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
+                  q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(), p_end.data_ptr(),
+                  q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(),
+                  is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        info = HMCInfo(p0, acc_rate, is_acc, is_div, energy, IntegratorState(q, p_end, logp, g),
+                       n_steps)
+        new_arg = next_random_arg_fn(state.random_generator_arg)
+        return DynamicHMCState(q_new, logp_new, g_new, new_arg), info
+
+    return kernel
+
+
+def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
+                     divergence_threshold: int = 1000, integrator=integrators.velocity_verlet,
+                     next_random_arg_fn: Callable = next_key_fn,
+                     integration_steps_fn: Callable = randint_steps_fn,
+                     integration_steps_params: tuple = (), build_proposal=None,
+                     chain_offset: int = 0) -> SamplingAlgorithm:
+    """blackjax/mcmc/dynamic_hmc.py:129-223."""
+    kernel = build_kernel(integrator, divergence_threshold, next_random_arg_fn, integration_steps_fn,
+                          build_proposal)
+
+    def init_fn(position, rng_key):
+        # build_sampling_algorithm forwards `rng_key` as the random_generator_arg seed
+        # (dynamic_hmc.py:215-222): one key per chain = split(rng_key, N)
+        return init(position, logdensity_fn, chain_keys(rng_key, position.shape[0], position.device,
+                                                        chain_offset))
+
+    def step_fn(rng_key, state):
+        return kernel(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
+                      integration_steps_params, chain_offset=chain_offset)
+
+    return SamplingAlgorithm(init_fn, step_fn)

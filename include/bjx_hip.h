@@ -78,6 +78,27 @@ int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps
                       const float* q_in, const float* p_in, const float* g, float* q_out,
                       float* p_out);
 
+/* Same as bjx_leapfrog_diag with a per-chain trajectory length (dynamic HMC, SURVEY.md section 8f
+ * row 2): chain i is advanced only while step_idx < n_steps[i] (n_steps: device (N,) int32);
+ * otherwise its (q, p) is left untouched (copied through when the launch is out of place).
+ * Replaces: the per-chain `num_integration_steps` of blackjax/mcmc/dynamic_hmc.py:85-118 under vmap. */
+int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                             const float* q_in, const float* p_in, const float* g, float* q_out,
+                             float* p_out, const int32_t* n_steps, int32_t step_idx);
+
+/* Per-chain key utilities on the device (keys: (N, 2) uint32 jax.random key data).
+ *   bjx_keys_child:   keys_out[i] = split(keys_in[i], .)[child]   (default next_random_arg_fn of
+ *                     dynamic_hmc.py:69: `lambda key: jax.random.split(key)[1]`)
+ *   bjx_keys_randint: out[i] = jax.random.randint(keys[i], (), minval, maxval) as int32 (default
+ *                     integration_steps_fn of dynamic_hmc.py:70: randint(key, (), 1, 10)).
+ * jax.random.randint is restated from jax/_src/random.py::_randint (two 32-bit draws from
+ * split(key, 2), offset = ((hi % span) * (2^32 % span) + lo % span) % span). */
+int bjx_keys_child(void* stream, int64_t N, const uint32_t* keys_in, uint32_t child,
+                   uint32_t* keys_out);
+int bjx_keys_randint(void* stream, int64_t N, const uint32_t* keys, int32_t minval, int32_t maxval,
+                     int32_t* out);
+
 /* Closing half kick + flip + energies + Metropolis accept + state select (diag metric).
  *   p1 = p + (eps/2) g1 ; p_end = -p1 ; ke1 = 0.5 dot(imm*p1, p1)
  *   H0 = -logp0 + ke0 ; H1 = -logp1 + ke1 ; delta = H0 - H1 (NaN -> -inf)

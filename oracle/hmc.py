@@ -249,3 +249,41 @@ def run(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
         positions.append(state.position)
         infos.append(info)
     return state, np.stack(positions, axis=0), infos
+
+
+# ----------------------------------------------------------------------------- dynamic HMC
+class DynamicHMCState(NamedTuple):  # blackjax/mcmc/dynamic_hmc.py:39-52
+    position: np.ndarray
+    logdensity: np.ndarray
+    logdensity_grad: np.ndarray
+    random_generator_arg: np.ndarray  # (N, 2) uint32: one key per chain
+
+
+def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size,
+                       inverse_mass_matrix, divergence_threshold: float = 1000.0,
+                       chain_offset: int = 0, steps_bounds=(1, 10)):
+    """blackjax/mcmc/dynamic_hmc.py:65-126 with the default callables
+    ``integration_steps_fn = lambda key: randint(key, (), 1, 10)`` and
+    ``next_random_arg_fn = lambda key: split(key)[1]``: every chain draws its own trajectory
+    length from its own ``random_generator_arg``.  Restated chain by chain (small cases)."""
+    N, D = state.position.shape
+    n_steps = prng.randint(state.random_generator_arg, *steps_bounds)
+    keys = chain_keys(rng_key, N, chain_offset)
+    eps = np.broadcast_to(np.asarray(step_size, f32), (N,))
+    imm = np.asarray(inverse_mass_matrix, f32)
+    outs = []
+    for i in range(N):
+        st_i = HMCState(state.position[i:i + 1], state.logdensity[i:i + 1], state.logdensity_grad[i:i + 1])
+        imm_i = imm if imm.ndim == 1 else imm[i]
+        outs.append(kernel(None, st_i, logdensity_fn, eps[i], imm_i, int(n_steps[i]),
+                           divergence_threshold, chain_keys_override=keys[i:i + 1]))
+    cat = lambda f: np.concatenate([f(o) for o in outs], 0)
+    new = DynamicHMCState(cat(lambda o: o[0].position), cat(lambda o: o[0].logdensity),
+                          cat(lambda o: o[0].logdensity_grad),
+                          prng.split(state.random_generator_arg, 2)[:, 1])
+    info = HMCInfo(cat(lambda o: o[1].momentum), cat(lambda o: o[1].acceptance_rate),
+                   cat(lambda o: o[1].is_accepted), cat(lambda o: o[1].is_divergent),
+                   cat(lambda o: o[1].energy),
+                   IntegratorState(*[cat(lambda o, k=k: o[1].proposal[k]) for k in range(4)]),
+                   n_steps)
+    return new, info

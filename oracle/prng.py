@@ -167,3 +167,20 @@ def normal(k, shape=()) -> np.ndarray:
     """jax.random.normal(key, shape, float32)."""
     u = uniform(k, shape, minval=_NORMAL_LO, maxval=f32(1.0))
     return (_SQRT2 * erf_inv(u)).astype(f32)
+
+
+def randint(k, minval: int, maxval: int) -> np.ndarray:
+    """jax.random.randint(key, (), minval, maxval, int32) for one key or a batch (..., 2) of keys.
+    Restated from jax/_src/random.py::_randint: two 32-bit draws from split(key, 2); with
+    span = maxval - minval (1 if maxval <= minval) and multiplier = 2^32 % span (computed as
+    ((2^16 % span)^2) % span): offset = ((hi % span) * multiplier + lo % span) % span."""
+    k = as_key(k)
+    kk = split(k, 2)
+    hi = random_bits(kk[..., 0, :], ())
+    lo = random_bits(kk[..., 1, :], ())
+    span = np.uint32(maxval - minval) if maxval > minval else np.uint32(1)
+    mult = np.uint32(1 << 16) % span
+    mult = (mult * mult) % span
+    with np.errstate(over="ignore"):
+        off = ((hi % span) * mult + (lo % span)) % span
+    return (np.int32(minval) + off.astype(np.int32)).astype(np.int32)
