@@ -11,7 +11,10 @@ import math
 
 import torch
 
-__all__ = ["effective_sample_size"]
+from ._diag_rhat import potential_scale_reduction  # noqa: E402,F401
+
+rhat = potential_scale_reduction
+__all__ = ["effective_sample_size", "potential_scale_reduction", "rhat"]
 
 
 def _next_fast_len(n: int) -> int:

@@ -314,10 +314,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
-                     recompact_every: int = 16, use_graph: bool = False) -> SamplingAlgorithm:
+                     recompact_every: int = 16, use_graph: bool = False,
+                     graph_sync_every: int = 4) -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220."""
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
-                          use_graph=use_graph)
+                          use_graph=use_graph, graph_sync_every=graph_sync_every)
 
     def init_fn(position, rng_key=None):
         del rng_key
