@@ -32,6 +32,13 @@ SIGNATURES = {
                             _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
     "bjx_leapfrog_diag_masked": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, c_int64,
                                  _f32p, _f32p, _f32p, _f32p, _f32p, c_void_p, ctypes.c_int32],
+    "bjx_leapfrog_diag_coef": [c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_float, c_float,
+                               _f32p, _f32p, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, c_void_p,
+                               ctypes.c_int32],
+    "bjx_hmc_finish_diag_coef": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
+                                 c_float, c_float, _f32p, _f32p, c_int64, c_float,
+                                 _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                 _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
     "bjx_keys_child": [c_void_p, c_int64, c_void_p, c_uint32, c_void_p],
     "bjx_keys_randint": [c_void_p, c_int64, c_void_p, ctypes.c_int32, ctypes.c_int32, c_void_p],
     "bjx_mhmc_step_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,

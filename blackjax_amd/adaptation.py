@@ -211,8 +211,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
     if imm_shrinkage_to_previous < 0.0:
         raise ValueError(
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
-    integrators.check_supported(integrator)
-    mcmc_kernel = algorithm.build_kernel(integrator)
+    mcmc_kernel = algorithm.build_kernel(integrator)  # the sampler validates the integrator
 
     def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0):
         """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains)."""

@@ -83,7 +83,11 @@ __global__ void __launch_bounds__(kBlock)
 k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps_pc,
                 const float* __restrict__ imm, int64_t imm_stride, const float* q_in,
                 const float* p_in, const float* __restrict__ g, float* q_out, float* p_out,
-                const int32_t* __restrict__ n_steps, int32_t step_idx) {
+                const int32_t* __restrict__ n_steps, int32_t step_idx, float kick_a, float kick_b,
+                float drift) {
+  // General palindromic-integrator stage (integrators.py:104-150): kick coefficients kick_a
+  // [, kick_b] and drift coefficient `drift` multiply the step size exactly as the reference's
+  // `step_size * coef` (fp32 product); velocity Verlet is (0.5, 0.5, 1.0).
   const int lane = threadIdx.x & 63;
   // Rows are swept LAST-TO-FIRST (workgroup 0 takes the last rows).  The user's callable, which
   // runs between two leapfrog launches, sweeps first-to-last and leaves the tail of q / g in the
@@ -104,7 +108,9 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
       continue;
     }
     const float eps = eps_pc ? eps_pc[r] : eps_s;
-    const float h = eps * 0.5f;
+    const float h = eps * kick_a;   // step_size * coef (integrators.py:236)
+    const float h2 = eps * kick_b;
+    const float ed = eps * drift;   // step_size * coef (integrators.py:200)
     const float* im = imm + r * imm_stride;
     if constexpr (VEC == 4) {
 #pragma unroll 4
@@ -117,19 +123,19 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
         pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
         pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
         if constexpr (KICKS == 2) {
-          pn.x = fmaf(h, gg.x, pn.x); pn.y = fmaf(h, gg.y, pn.y);
-          pn.z = fmaf(h, gg.z, pn.z); pn.w = fmaf(h, gg.w, pn.w);
+          pn.x = fmaf(h2, gg.x, pn.x); pn.y = fmaf(h2, gg.y, pn.y);
+          pn.z = fmaf(h2, gg.z, pn.z); pn.w = fmaf(h2, gg.w, pn.w);
         }
-        qn.x = fmaf(eps, mm.x * pn.x, qq.x); qn.y = fmaf(eps, mm.y * pn.y, qq.y);
-        qn.z = fmaf(eps, mm.z * pn.z, qq.z); qn.w = fmaf(eps, mm.w * pn.w, qq.w);
+        qn.x = fmaf(ed, mm.x * pn.x, qq.x); qn.y = fmaf(ed, mm.y * pn.y, qq.y);
+        qn.z = fmaf(ed, mm.z * pn.z, qq.z); qn.w = fmaf(ed, mm.w * pn.w, qq.w);
         st4(p_out + base + j, pn);
         st4(q_out + base + j, qn);
       }
     } else {
       for (int64_t j = lane; j < D; j += 64) {
         float pn = fmaf(h, g[base + j], p_in[base + j]);
-        if constexpr (KICKS == 2) pn = fmaf(h, g[base + j], pn);
-        const float qn = fmaf(eps, im[j] * pn, q_in[base + j]);
+        if constexpr (KICKS == 2) pn = fmaf(h2, g[base + j], pn);
+        const float qn = fmaf(ed, im[j] * pn, q_in[base + j]);
         p_out[base + j] = pn;
         q_out[base + j] = qn;
       }
@@ -149,11 +155,11 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, floa
                   float* p_end, float* __restrict__ q_out, float* __restrict__ logp_out,
                   float* __restrict__ g_out, float* __restrict__ acc_rate_out,
                   uint8_t* __restrict__ is_acc_out, uint8_t* __restrict__ is_div_out,
-                  float* __restrict__ energy_out) {
+                  float* __restrict__ energy_out, float kick_coef) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const float eps = eps_pc ? eps_pc[r] : eps_s;
-    const float h = eps * 0.5f;
+    const float h = eps * kick_coef;  // last coefficient of the palindromic integrator (0.5 for VV)
     const int64_t base = r * D;
     const float* im = imm + r * imm_stride;
     double acc = 0.0;
@@ -384,10 +390,11 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   return bjx_check_launch("bjx_hmc_momentum_diag");
 }
 
-int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
-                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
-                             const float* q_in, const float* p_in, const float* g, float* q_out,
-                             float* p_out, const int32_t* n_steps, int32_t step_idx) {
+int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, float kick_a,
+                           float kick_b, float drift, float eps, const float* eps_per_chain,
+                           const float* imm, int64_t imm_stride, const float* q_in,
+                           const float* p_in, const float* g, float* q_out, float* p_out,
+                           const int32_t* n_steps, int32_t step_idx) {
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
                 "bjx_leapfrog_diag: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_diag: n_kicks must be 1 or 2");
@@ -397,7 +404,8 @@ int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, fl
   hipStream_t s = (hipStream_t)stream;
 #define BJX_LF(V, K)                                                                          \
   hipLaunchKernelGGL((k_leapfrog_diag<V, K>), grid, block, 0, s, N, D, eps, eps_per_chain, imm, \
-                     imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx)
+                     imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b,  \
+                     drift)
   if (bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     if (n_kicks == 1) BJX_LF(4, 1); else BJX_LF(4, 2);
   } else {
@@ -407,12 +415,21 @@ int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, fl
   return bjx_check_launch("bjx_leapfrog_diag");
 }
 
+// velocity Verlet: coefficients [0.5, 1.0, 0.5] (integrators.py:321-322)
+int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                             const float* q_in, const float* p_in, const float* g, float* q_out,
+                             float* p_out, const int32_t* n_steps, int32_t step_idx) {
+  return bjx_leapfrog_diag_coef(stream, N, D, n_kicks, 0.5f, 0.5f, 1.0f, eps, eps_per_chain, imm,
+                                imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx);
+}
+
 int bjx_leapfrog_diag(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
                       const float* eps_per_chain, const float* imm, int64_t imm_stride,
                       const float* q_in, const float* p_in, const float* g, float* q_out,
                       float* p_out) {
-  return bjx_leapfrog_diag_masked(stream, N, D, n_kicks, eps, eps_per_chain, imm, imm_stride, q_in,
-                                  p_in, g, q_out, p_out, nullptr, 0);
+  return bjx_leapfrog_diag_coef(stream, N, D, n_kicks, 0.5f, 0.5f, 1.0f, eps, eps_per_chain, imm,
+                                imm_stride, q_in, p_in, g, q_out, p_out, nullptr, 0);
 }
 
 namespace {
@@ -462,9 +479,10 @@ int bjx_keys_randint(void* stream, int64_t N, const uint32_t* keys, int32_t minv
   return bjx_check_launch("bjx_keys_randint");
 }
 
-int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                        int64_t step_fold, int64_t N, int64_t D, float eps, const float* eps_per_chain,
-                        const float* imm, int64_t imm_stride, float divergence_threshold,
+int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                             int64_t step_fold, int64_t N, int64_t D, float kick_coef, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                             float divergence_threshold,
                         const float* q0, const float* logp0, const float* g0, const float* ke0,
                         const float* q1, const float* logp1, const float* g1, const float* p,
                         float* p_end_out, float* q_out, float* logp_out, float* g_out,
@@ -484,11 +502,25 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                      eps,                                                                       \
                      eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0,  \
                      q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out, acceptance_rate_out,  \
-                     is_accepted_out, is_divergent_out, energy_out)
+                     is_accepted_out, is_divergent_out, energy_out, kick_coef)
   if (bjx_vec4_ok(D, imm, q0, g0, q1, g1, p, p_end_out, q_out, g_out)) BJX_FIN(4);
   else BJX_FIN(1);
 #undef BJX_FIN
   return bjx_check_launch("bjx_hmc_finish_diag");
+}
+
+int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                        int64_t step_fold, int64_t N, int64_t D, float eps, const float* eps_per_chain,
+                        const float* imm, int64_t imm_stride, float divergence_threshold,
+                        const float* q0, const float* logp0, const float* g0, const float* ke0,
+                        const float* q1, const float* logp1, const float* g1, const float* p,
+                        float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                        float* acceptance_rate_out, uint8_t* is_accepted_out,
+                        uint8_t* is_divergent_out, float* energy_out) {
+  return bjx_hmc_finish_diag_coef(stream, key0, key1, chain_offset, step_fold, N, D, 0.5f, eps,
+                                  eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0,
+                                  ke0, q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out,
+                                  acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
 }
 
 int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

@@ -214,13 +214,19 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     ``use_graph``: capture the per-block inner loop (the user's callable included) in a HIP
     graph (diagonal metric; the callable must be capturable: static shapes, no host sync).
     """
-    integrators.check_supported(integrator)
     thr = float(divergence_threshold)
     if build_proposal is multinomial_hmc_proposal:
+        integrators.check_supported(integrator)
         return _build_mhmc_kernel(thr)
     if build_proposal not in (None, hmc_proposal):
         raise NotImplementedError(
             "build_proposal must be hmc_proposal (default) or multinomial_hmc_proposal")
+    # any palindromic coefficient list [b1, a1, ..., b1] (integrators.py:62-152); the higher-order
+    # ones (mclachlan / yoshida / omelyan) run through the general-coefficient kernels (diag metric)
+    integrators.check_supported(integrator, allow_general=True)
+    general = integrator is not integrators.velocity_verlet
+    kick_c = integrator.coefficients[0::2]   # b1 .. b1
+    drift_c = integrator.coefficients[1::2]  # a1 ..
     if chain_block is None:
         chain_block = _default_chain_block()
     graphs: dict = {}
@@ -242,7 +248,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         stream = _lib.current_stream()
         off = int(chain_offset)
         dev = q0.device
-        graphed = bool(use_graph) and L >= 1 and metric.kind == "diag"
+        graphed = bool(use_graph) and L >= 1 and metric.kind == "diag" and not general
+        if general and metric.kind != "diag":
+            raise NotImplementedError(
+                f"{integrator!r} is implemented for diagonal metrics only (velocity_verlet for dense)")
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
@@ -303,6 +312,29 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 ctx.graph.replay()
                 q, p, logp, g = ctx.Wq, ctx.Wp, ctx.logp, ctx.g
                 eps_fin, eps_pc_fin = eps, eb
+            elif general:
+                # generalized_two_stage_integrator (integrators.py:104-150): one launch per position
+                # update; the closing kick b_K of a step merges with the opening kick b_1 of the next
+                q, p = q_end[sl], p_work[sl]
+                args = (_lib.ptr(eb), m.imm.data_ptr(), m.imm_stride)
+                first = True
+                for _ in range(L):
+                    for si, a_c in enumerate(drift_c):
+                        if first:
+                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 1, kick_c[0], 0.0, a_c,
+                                      eps, *args, q0[sl].data_ptr(), p0[sl].data_ptr(),
+                                      g0[sl].data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)
+                            first = False
+                        elif si == 0:
+                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 2, kick_c[-1], kick_c[0],
+                                      a_c, eps, *args, q.data_ptr(), p.data_ptr(), g.data_ptr(),
+                                      q.data_ptr(), p.data_ptr(), None, 0)
+                        else:
+                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 1, kick_c[si], 0.0, a_c,
+                                      eps, *args, q.data_ptr(), p.data_ptr(), g.data_ptr(),
+                                      q.data_ptr(), p.data_ptr(), None, 0)
+                        logp, g = eval_logdensity(vg, q)
+                eps_fin, eps_pc_fin = eps, eb
             else:
                 q, p = q_end[sl], p_work[sl]
                 p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
@@ -312,7 +344,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                     logp, g = eval_logdensity(vg, q)
                 eps_fin, eps_pc_fin = eps, eb
 
-            if m.kind == "diag":
+            if m.kind == "diag" and general:
+                _lib.call("bjx_hmc_finish_diag_coef", stream, k0, k1, boff, fold, n, D, kick_c[-1],
+                          eps_fin, _lib.ptr(eps_pc_fin), m.imm.data_ptr(), m.imm_stride, thr,
+                          q0[sl].data_ptr(), logp0[sl].data_ptr(), g0[sl].data_ptr(),
+                          ke0[sl].data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(),
+                          p.data_ptr(), p_end[sl].data_ptr(), q_new[sl].data_ptr(),
+                          logp_new[sl].data_ptr(), g_new[sl].data_ptr(), acc_rate[sl].data_ptr(),
+                          is_acc[sl].data_ptr(), is_div[sl].data_ptr(), energy[sl].data_ptr())
+            elif m.kind == "diag":
                 _lib.call("bjx_hmc_finish_diag", stream, k0, k1, boff, fold, n, D, eps_fin,
                           _lib.ptr(eps_pc_fin), m.imm.data_ptr(), m.imm_stride, thr,
                           q0[sl].data_ptr(), logp0[sl].data_ptr(), g0[sl].data_ptr(),

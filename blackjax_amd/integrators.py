@@ -1,20 +1,50 @@
-"""Integrator selectors.  Only velocity Verlet (coefficients [0.5, 1.0, 0.5],
-blackjax/mcmc/integrators.py:321-322) has a HIP implementation; the other
-palindromic integrators of the reference are out of scope."""
+"""Palindromic symplectic integrators (blackjax/mcmc/integrators.py:270-369).
+
+An integrator is its coefficient list ``[b1, a1, b2, a2, ..., b1]`` (momentum / position updates
+alternating, ``generalized_two_stage_integrator`` 62-152).  ``velocity_verlet`` is implemented for
+every sampler and metric; ``mclachlan``, ``yoshida`` and ``omelyan`` are implemented for
+``blackjax_amd.hmc`` with a diagonal metric through the general-coefficient kernels
+(``bjx_leapfrog_diag_coef`` / ``bjx_hmc_finish_diag_coef``); the non-Euclidean integrators of the
+reference (isokinetic, maruyama, implicit midpoint) are out of scope.
+"""
+from __future__ import annotations
 
 
-class _VelocityVerlet:
-    coefficients = (0.5, 1.0, 0.5)
+class Integrator:
+    def __init__(self, name, coefficients):
+        self.name = name
+        self.coefficients = tuple(float(c) for c in coefficients)
+        assert len(self.coefficients) % 2 == 1 and self.coefficients == self.coefficients[::-1]
+
+    @property
+    def num_gradients_per_step(self) -> int:
+        return (len(self.coefficients) - 1) // 2
 
     def __repr__(self):
-        return "velocity_verlet"
+        return self.name
 
 
-velocity_verlet = _VelocityVerlet()
+velocity_verlet = Integrator("velocity_verlet", [0.5, 1.0, 0.5])  # integrators.py:321-322
+
+_b1 = 0.1931833275037836  # integrators.py:335-340
+mclachlan = Integrator("mclachlan", [_b1, 0.5, 1 - 2 * _b1, 0.5, _b1])
+
+_b1, _a1 = 0.11888010966548, 0.29619504261126  # integrators.py:350-356
+yoshida = Integrator("yoshida", [_b1, _a1, 0.5 - _b1, 1 - 2 * _a1, 0.5 - _b1, _a1, _b1])
+
+_b1, _a1, _b2, _a2 = (0.08398315262876693, 0.2539785108410595, 0.6822365335719091,
+                      -0.03230286765269967)  # integrators.py:362-369
+_b3, _a3 = 0.5 - _b1 - _b2, 1 - 2 * (_a1 + _a2)
+omelyan = Integrator("omelyan", [_b1, _a1, _b2, _a2, _b3, _a3, _b3, _a2, _b2, _a1, _b1])
 
 
-def check_supported(integrator):
-    if integrator is not velocity_verlet:
-        raise NotImplementedError(
-            "blackjax_amd implements the velocity_verlet integrator only; got %r" % (integrator,)
-        )
+def check_supported(integrator, allow_general: bool = False):
+    """``allow_general``: the caller implements arbitrary palindromic coefficients."""
+    if integrator is velocity_verlet:
+        return
+    if allow_general and isinstance(integrator, Integrator):
+        return
+    raise NotImplementedError(
+        "this sampler/metric implements the velocity_verlet integrator only; got %r "
+        "(mclachlan / yoshida / omelyan are available for blackjax_amd.hmc with a diagonal metric)"
+        % (integrator,))

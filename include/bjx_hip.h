@@ -87,6 +87,31 @@ int bjx_leapfrog_diag_masked(void* stream, int64_t N, int64_t D, int n_kicks, fl
                              const float* q_in, const float* p_in, const float* g, float* q_out,
                              float* p_out, const int32_t* n_steps, int32_t step_idx);
 
+/* General palindromic integrators: coefficients
+ * [b1, a1, b2, a2, ..., b1] of generalized_two_stage_integrator (blackjax/mcmc/integrators.py:
+ * 104-150; mclachlan / yoshida / omelyan 335-369).  One launch per position update:
+ *   p = p + (eps*kick_a) g  [ ; p = p + (eps*kick_b) g  if n_kicks == 2 ]
+ *   q = q + (eps*drift) * (imm * p)
+ * `eps*coef` is an fp32 product like the reference's `step_size * coef`.  Velocity Verlet is
+ * (kick_a, kick_b, drift) = (0.5, 0.5, 1.0), i.e. bjx_leapfrog_diag.  n_steps/step_idx as in
+ * bjx_leapfrog_diag_masked (NULL = every chain advances). */
+int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, float kick_a,
+                           float kick_b, float drift, float eps, const float* eps_per_chain,
+                           const float* imm, int64_t imm_stride, const float* q_in,
+                           const float* p_in, const float* g, float* q_out, float* p_out,
+                           const int32_t* n_steps, int32_t step_idx);
+
+/* bjx_hmc_finish_diag with the closing kick p1 = p + (eps*kick_coef) g1, kick_coef = last
+ * coefficient of the palindromic integrator (0.5 for velocity Verlet). */
+int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                             int64_t step_fold, int64_t N, int64_t D, float kick_coef, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                             float divergence_threshold, const float* q0, const float* logp0,
+                             const float* g0, const float* ke0, const float* q1, const float* logp1,
+                             const float* g1, const float* p, float* p_end_out, float* q_out,
+                             float* logp_out, float* g_out, float* acceptance_rate_out,
+                             uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out);
+
 /* Per-chain key utilities on the device (keys: (N, 2) uint32 jax.random key data).
  *   bjx_keys_child:   keys_out[i] = split(keys_in[i], .)[child]   (default next_random_arg_fn of
  *                     dynamic_hmc.py:69: `lambda key: jax.random.split(key)[1]`)
