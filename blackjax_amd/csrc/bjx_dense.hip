@@ -41,10 +41,15 @@ struct GemmArgs {
   float* Q_out;
 };
 
-template <int EPI, bool ALIGNED>
+// FULL: M % BM == 0 and D % BN == 0 (hence D % BK == 0): every tile is complete, no bounds checks.
+template <int EPI, bool ALIGNED, bool FULL>
 __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
-  __shared__ float As[2][BK * LDA];
-  __shared__ float Bs[2][BK * LDB];
+  // one LDS block: [2 x A tile][2 x B tile]; re-used as the epilogue's transpose staging area
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
+  float (*As)[BK * LDA] = reinterpret_cast<float (*)[BK * LDA]>(smem);
+  float (*Bs)[BK * LDB] = reinterpret_cast<float (*)[BK * LDB]>(smem + 2 * BK * LDA);
+  static_assert(2 * BK * LDA + 2 * BK * LDB >= 4 * 32 * 64, "epilogue staging needs 32 KiB");
+  static_assert((2 * BK * LDA) % 4 == 0, "B tiles must stay 16-byte aligned");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   const int a_row = tid >> 1, a_k = (tid & 1) * EPT;              // A tile: 128 rows x BK, EPT k per thread
   const int b_k = tid / (BN / EPT), b_n = (tid % (BN / EPT)) * EPT;  // B tile: BK x 128, EPT n per thread
   const int64_t g_row = row0 + a_row;
-  const bool row_ok = g_row < a.M;
+  const bool row_ok = FULL || g_row < a.M;
   float h = 0.0f;
   if (a.n_kicks > 0 && row_ok) h = (a.eps_pc ? a.eps_pc[g_row] : a.eps) * 0.5f;
 
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
     if (row_ok) {
       const int64_t kk = cur_kk;
       const float* ap = a.A + g_row * D + kk;
-      if (ALIGNED && kk + EPT <= D) {
+      if (ALIGNED && (FULL || kk + EPT <= D)) {
 #pragma unroll
         for (int v = 0; v < EPT / 4; ++v) {
           const F4 x = ld4(ap + 4 * v);
@@ -116,9 +121,9 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
       }
     }
     const int64_t bk = k0 + b_k, bn = col0 + b_n;
-    if (bk < D) {
+    if (FULL || bk < D) {
       const float* bp = a.B + bk * D + bn;
-      if (ALIGNED && bn + EPT <= D) {
+      if (ALIGNED && (FULL || bn + EPT <= D)) {
 #pragma unroll
         for (int v = 0; v < EPT / 4; ++v) {
           const F4 x = ld4(bp + 4 * v);
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
       if (a.A_out && col_blk == 0) {
         const int64_t kk = cur_kk;
         float* op = a.A_out + g_row * D + kk;
-        if (ALIGNED && kk + EPT <= D) {
+        if (ALIGNED && (FULL || kk + EPT <= D)) {
 #pragma unroll
           for (int v = 0; v < EPT / 4; ++v)
             st4(op + 4 * v, F4{ra[4 * v], ra[4 * v + 1], ra[4 * v + 2], ra[4 * v + 3]});
@@ -207,6 +212,48 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   }
 
   // epilogue: acc[i][j][4*bq + r] <-> row = 8*bq + 4*(lane/32) + r, col = lane%32 of the 32x32 tile
+  if constexpr (ALIGNED) {
+    // Transpose through LDS so that global accesses are 16-byte row segments (4 rows x 256 B per
+    // wave instruction) instead of 4-byte scalars in 128-B pieces.  Each wave stages 32 rows x 64
+    // columns (8 KiB) of its 64 x 64 tile at a time in its private slice of the (now idle) tile
+    // buffers; the loop above ended with a workgroup barrier, so nobody still reads them.
+    float* stage = smem + wave * (32 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stage[(bq * 8 + lk * 4 + r) * 64 + j * 32 + lm] = acc[i][j][bq * 4 + r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int c4 = (lane & 15) * 4;
+      const int64_t col = col0 + wn * 64 + c4;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rl = (lane >> 4) + 4 * it;
+        const int64_t row = row0 + wm * 64 + i * 32 + rl;
+        const F4 c = *reinterpret_cast<const F4*>(stage + rl * 64 + c4);
+        if (FULL || (row < a.M && col < D)) {
+          if constexpr (EPI == EPI_STORE) {
+            st4(a.C + row * D + col, c);
+          } else {
+            const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
+            const F4 q = ld4(a.Q_in + row * D + col);
+            st4(a.Q_out + row * D + col,
+                F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -436,13 +483,16 @@ int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
 
 int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
-  const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B);
+  const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B, ga.C, ga.Q_in, ga.Q_out);
+  const bool full = (ga.M % BM == 0) && (ga.D % BN == 0);
   if (epi == EPI_STORE) {
-    if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true>), grid, dim3(kThreads), 0, s, ga);
-    else hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, false>), grid, dim3(kThreads), 0, s, ga);
+    if (aligned && full) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true, true>), grid, dim3(kThreads), 0, s, ga);
+    else if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true, false>), grid, dim3(kThreads), 0, s, ga);
+    else hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, false, false>), grid, dim3(kThreads), 0, s, ga);
   } else {
-    if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, true>), grid, dim3(kThreads), 0, s, ga);
-    else hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, false>), grid, dim3(kThreads), 0, s, ga);
+    if (aligned && full) hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, true, true>), grid, dim3(kThreads), 0, s, ga);
+    else if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, true, false>), grid, dim3(kThreads), 0, s, ga);
+    else hipLaunchKernelGGL((k_dense_gemm<EPI_DRIFT, false, false>), grid, dim3(kThreads), 0, s, ga);
   }
   return bjx_check_launch("bjx_dense gemm");
 }
