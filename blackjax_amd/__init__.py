@@ -12,8 +12,9 @@ import functools as _functools
 from . import dynamic_hmc as _dynamic_hmc
 from . import hmc as _hmc
 from . import nuts as _nuts
-from . import adaptation, diagnostics, distributed, integrators, metrics, random, targets, util
+from . import adaptation, chees, diagnostics, distributed, integrators, metrics, optim, random, targets, util
 from .adaptation import window_adaptation
+from .chees import chees_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
 
 __version__ = "0.1.0"
@@ -46,5 +47,8 @@ dynamic_hmc = GenerateSamplingAPI(_dynamic_hmc.as_top_level_api, _dynamic_hmc.in
 dynamic_hmc.next_key_fn = _dynamic_hmc.next_key_fn
 dynamic_hmc.randint_steps_fn = _dynamic_hmc.randint_steps_fn
 dynamic_hmc.chain_keys = _dynamic_hmc.chain_keys
+dynamic_hmc.halton_sequence = _dynamic_hmc.halton_sequence
+dynamic_hmc.halton_steps_fn = _dynamic_hmc.halton_steps_fn
+dhmc = dynamic_hmc  # blackjax/__init__.py alias used by the ChEES examples
 
-__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "window_adaptation", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]
+__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "window_adaptation", "chees_adaptation", "chees", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm"]

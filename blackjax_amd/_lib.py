@@ -126,6 +126,25 @@ SIGNATURES.update({
     "bjx_nuts_merge": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p],
 })
 
+# include/bjx_pool.h (pooled cross-chain statistics; bjx_pool_workspace_bytes returns int64, see load())
+_f64p = c_void_p
+SIGNATURES.update({
+    "bjx_chees_weights": [c_void_p, c_int64, c_int64, _f32p, _f32p, _u8p, _f32p],
+    "bjx_chees_colstats": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, c_void_p, _f64p],
+    "bjx_chees_means": [c_void_p, c_int64, _f64p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_chees_criterion": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                            _f32p],
+    "bjx_chees_scalars": [c_void_p, c_int64, _f32p, _u8p, _f32p, c_float, _f64p],
+    "bjx_pool_colsum": [c_void_p, c_int64, c_int64, _f32p, _f32p, c_void_p, _f64p],
+    "bjx_pool_mean": [c_void_p, c_int64, _f64p, ctypes.c_double, _f32p],
+    "bjx_pool_merge_diag": [c_void_p, c_int64, c_float, c_float, _f32p, _f64p, _f32p, _f32p],
+    "bjx_pool_final_diag": [c_void_p, c_int64, c_float, _f32p, _f32p],
+    "bjx_pool_center": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
+    "bjx_halton_steps": [c_void_p, c_int64, c_void_p, ctypes.c_int32, c_float, c_float, c_float,
+                         c_void_p],
+})
+INT64_FUNCTIONS = {"bjx_pool_workspace_bytes": [c_int64, c_int64]}
+
 _lib = None
 
 
@@ -150,6 +169,10 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = c_int
+        fn.argtypes = argtypes
+    for name, argtypes in INT64_FUNCTIONS.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int64
         fn.argtypes = argtypes
     _lib = lib
     return lib

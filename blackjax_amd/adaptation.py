@@ -182,8 +182,9 @@ def _stack_history(history):
             return torch.stack(items)
         if isinstance(first, tuple) and hasattr(first, "_fields"):
             return type(first)(*[stack([it[i] for it in items]) for i in range(len(first))])
-        if isinstance(first, (int, float, bool)):
-            return torch.tensor(items)
+        if isinstance(first, (int, float, bool)) or (hasattr(first, "dtype") and hasattr(first, "item")
+                                                     and getattr(first, "ndim", 1) == 0):
+            return torch.tensor([it.item() if hasattr(it, "item") else it for it in items])
         return items
 
     return stack(history)

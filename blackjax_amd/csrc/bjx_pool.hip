@@ -1,0 +1,513 @@
+// Pooled (cross-chain) statistics for many-chain warmup: ChEES-HMC criterion, ensemble moment
+// blocks, Halton trajectory jitter.  C ABI in include/bjx_pool.h; reference lines cited there.
+//
+// Two reduction shapes over an (N, D) batch:
+//   * over chains (columns survive): thread (ty, tx) owns VEC consecutive columns and walks the rows
+//     of its slab in fp64 registers; a row segment of tpr*VEC floats is one coalesced burst; the
+//     slab partials are combined in a fixed order (LDS across ty, then a second kernel across
+//     slabs), so results are reproducible run to run.  HBM-bound: one read of each input.
+//   * over dimensions (rows survive): one wavefront per chain, 16 B per lane, fp64 wave reduction
+//     (same shape as the leapfrog kernels).
+#include <math.h>
+
+#include <type_traits>
+
+#include "../../include/bjx_pool.h"
+#include "bjx_device.h"
+#include "bjx_host.h"
+
+using namespace bjx;
+
+namespace {
+
+// ------------------------------------------------------------------------------ column reductions
+struct ColGeom {
+  int tpr_log2;  // threads per row segment = 1 << tpr_log2 (<= 256)
+  int64_t ncb;   // column blocks (grid.y)
+  int64_t nslab; // row slabs (grid.x)
+  int64_t rows_per_slab;
+};
+
+ColGeom col_geom(int64_t N, int64_t D, int vec) {
+  ColGeom g;
+  const int64_t groups = (D + vec - 1) / vec;
+  g.tpr_log2 = 0;
+  while ((1 << g.tpr_log2) < groups && g.tpr_log2 < 8) ++g.tpr_log2;
+  const int64_t tpr = 1 << g.tpr_log2, rp = 256 >> g.tpr_log2;
+  g.ncb = (groups + tpr - 1) / tpr;
+  if (g.ncb < 1) g.ncb = 1;
+  int64_t want = 1024 / g.ncb;  // >= 4 workgroups per CU when the batch is large enough
+  if (want < 1) want = 1;
+  int64_t max_slabs = (N + rp - 1) / rp;
+  if (max_slabs < 1) max_slabs = 1;
+  g.nslab = want < max_slabs ? want : max_slabs;
+  g.rows_per_slab = (N + g.nslab - 1) / g.nslab;
+  if (g.rows_per_slab < 1) g.rows_per_slab = 1;
+  g.nslab = (N + g.rows_per_slab - 1) / g.rows_per_slab;
+  if (g.nslab < 1) g.nslab = 1;
+  return g;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld_vec(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    F4 t = ld4(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = p[0];
+  }
+}
+
+struct OpChees {  // chees_adaptation.py:241-246, 384-386
+  static constexpr int K = 4;
+  const float* qp;
+  const float* w;
+  const float* qi;
+  template <int VEC>
+  __device__ __forceinline__ void row(int64_t r, int64_t off, double (&a)[K][VEC]) const {
+    const double wr = (double)w[r];
+    float x[VEC], y[VEC];
+    ld_vec<VEC>(qp + off, x);
+    ld_vec<VEC>(qi + off, y);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float xs = isfinite(x[v]) ? x[v] : 0.0f;
+      a[0][v] += wr * (double)xs;
+      const bool ok = !(y[v] != y[v]);
+      a[1][v] += ok ? (double)y[v] : 0.0;
+      a[2][v] += ok ? 1.0 : 0.0;
+      a[3][v] += wr;
+    }
+  }
+};
+
+struct OpSum {  // metric_buffers.py:429
+  static constexpr int K = 1;
+  const float* x;
+  template <int VEC>
+  __device__ __forceinline__ void row(int64_t, int64_t off, double (&a)[K][VEC]) const {
+    float t[VEC];
+    ld_vec<VEC>(x + off, t);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[0][v] += (double)t[v];
+  }
+};
+
+struct OpCenteredSq {  // metric_buffers.py:430-433
+  static constexpr int K = 1;
+  const float* x;
+  const float* center;
+  template <int VEC>
+  __device__ __forceinline__ void row(int64_t, int64_t off, double (&a)[K][VEC], const float (&c)[VEC]) const {
+    float t[VEC];
+    ld_vec<VEC>(x + off, t);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float d = t[v] - c[v];
+      a[0][v] += (double)d * (double)d;
+    }
+  }
+};
+
+template <int VEC, class Op>
+__global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr_log2,
+                                                   int64_t rows_per_slab, Op op, double* partial) {
+  constexpr int K = Op::K;
+  __shared__ double sm[256 * K * VEC];
+  const int tpr = 1 << tpr_log2, rp = 256 >> tpr_log2;
+  const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x >> tpr_log2;
+  const int64_t c0 = ((int64_t)blockIdx.y * tpr + tx) * VEC;
+  const int64_t r_lo = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t r_hi = r_lo + rows_per_slab < N ? r_lo + rows_per_slab : N;
+  double a[K][VEC];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[k][v] = 0.0;
+  if (c0 < D) {
+    if constexpr (std::is_same<Op, OpCenteredSq>::value) {
+      float c[VEC];
+      ld_vec<VEC>(op.center + c0, c);
+      for (int64_t r = r_lo + ty; r < r_hi; r += rp) op.template row<VEC>(r, r * D + c0, a, c);
+    } else {
+      for (int64_t r = r_lo + ty; r < r_hi; r += rp) op.template row<VEC>(r, r * D + c0, a);
+    }
+  }
+  double* mine = sm + (size_t)threadIdx.x * K * VEC;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) mine[k * VEC + v] = a[k][v];
+  __syncthreads();
+  if (ty == 0 && c0 < D) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        double s = 0.0;
+        for (int j = 0; j < rp; ++j) s += sm[((size_t)(j * tpr + tx)) * K * VEC + k * VEC + v];
+        partial[((int64_t)blockIdx.x * K + k) * D + c0 + v] = s;
+      }
+  }
+}
+
+__global__ void k_colfinal(int64_t nslab, int64_t KD, const double* partial, double* out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= KD) return;
+  double s = 0.0;
+  for (int64_t t = 0; t < nslab; ++t) s += partial[t * KD + j];
+  out[j] = s;
+}
+
+template <class Op>
+int run_colreduce(hipStream_t stream, int64_t N, int64_t D, bool vec4, Op op, void* workspace,
+                  double* out, const char* what) {
+  constexpr int K = Op::K;
+  if (D == 0) return 0;
+  if (N == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * K * D, stream);
+    if (e != hipSuccess) {
+      bjx_set_error("%s: memset failed: %s", what, hipGetErrorString(e));
+      return 2;
+    }
+    return 0;
+  }
+  const ColGeom g = col_geom(N, D, vec4 ? 4 : 1);
+  dim3 grid((unsigned)g.nslab, (unsigned)g.ncb);
+  double* partial = (double*)workspace;
+  if (vec4)
+    hipLaunchKernelGGL((k_colreduce<4, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2,
+                       g.rows_per_slab, op, partial);
+  else
+    hipLaunchKernelGGL((k_colreduce<1, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2,
+                       g.rows_per_slab, op, partial);
+  const int64_t KD = (int64_t)K * D;
+  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, stream, g.nslab, KD,
+                     partial, out);
+  return bjx_check_launch(what);
+}
+
+// ------------------------------------------------------------------------------ row kernels
+template <int VEC>
+__global__ __launch_bounds__(256) void k_chees_weights(int64_t N, int64_t D, const float* __restrict__ qp,
+                                                       const float* __restrict__ acc,
+                                                       const uint8_t* __restrict__ is_div,
+                                                       float* __restrict__ w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const float* row = qp + n * D;
+    bool bad = false;
+    for (int64_t c = (int64_t)lane * VEC; c < D; c += 64 * VEC) {
+      float x[VEC];
+      ld_vec<VEC>(row + c, x);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) bad |= !isfinite(x[v]);
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) w[n] = (is_div[n] || any_bad) ? 0.0f : acc[n];
+  }
+}
+
+template <int VEC, bool WHITEN>
+__global__ __launch_bounds__(256) void k_chees_criterion(
+    int64_t N, int64_t D, const float* __restrict__ qp, const float* __restrict__ pp,
+    const float* __restrict__ qi, const float* __restrict__ pm, const float* __restrict__ im,
+    const float* __restrict__ imm, const float* __restrict__ isq, float* __restrict__ crit) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const int64_t base = n * D;
+    double s_pp = 0.0, s_ii = 0.0, s_pv = 0.0;
+    for (int64_t c = (int64_t)lane * VEC; c < D; c += 64 * VEC) {
+      float a[VEC], b[VEC], m[VEC], ma[VEC], mb[VEC];
+      ld_vec<VEC>(qp + base + c, a);
+      ld_vec<VEC>(qi + base + c, b);
+      ld_vec<VEC>(pp + base + c, m);
+      ld_vec<VEC>(pm + c, ma);
+      ld_vec<VEC>(im + c, mb);
+      float sg[VEC], sq[VEC];
+      if constexpr (WHITEN) {
+        ld_vec<VEC>(imm + c, sg);
+        ld_vec<VEC>(isq + c, sq);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float pc = a[v] - ma[v];
+        float ic = b[v] - mb[v];
+        float vel = m[v];
+        if constexpr (WHITEN) {
+          pc = pc * sq[v];
+          ic = ic * sq[v];
+          vel = (vel * sg[v]) * sq[v];
+        }
+        s_pp += (double)pc * (double)pc;
+        s_ii += (double)ic * (double)ic;
+        s_pv += (double)pc * (double)vel;
+      }
+    }
+    s_pp = wave_sum(s_pp);
+    s_ii = wave_sum(s_ii);
+    s_pv = wave_sum(s_pv);
+    if (lane == 0) {
+      const float diff = (float)s_pp - (float)s_ii;
+      crit[n] = diff * (float)s_pv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_chees_scalars(int64_t N, const float* __restrict__ acc,
+                                                        const uint8_t* __restrict__ is_div,
+                                                        const float* __restrict__ crit, float scale,
+                                                        double* __restrict__ out) {
+  __shared__ double sm[4][16];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t n = threadIdx.x; n < N; n += 1024) {
+    if (is_div[n]) continue;
+    const float a = acc[n];
+    s[0] += (double)(1.0f / a);
+    s[1] += 1.0;
+    if (crit != nullptr) {
+      const float tg = scale * crit[n];
+      s[2] += (double)a * (double)tg;
+    }
+    s[3] += (double)(a + 1e-20f);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double t = wave_sum(s[k]);
+    if (lane == 0) sm[k][wv] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int j = 0; j < 16; ++j) t += sm[threadIdx.x][j];
+    out[threadIdx.x] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------ D-sized glue
+__global__ void k_chees_means(int64_t D, const double* __restrict__ stats, const float* __restrict__ imm,
+                              float* __restrict__ pm, float* __restrict__ im, float* __restrict__ isq) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  pm[d] = (float)stats[d] / ((float)stats[3 * D + d] + 1e-20f);
+  im[d] = (float)stats[D + d] / (float)stats[2 * D + d];
+  if (imm != nullptr && isq != nullptr) isq[d] = 1.0f / sqrtf(imm[d]);
+}
+
+__global__ void k_pool_mean(int64_t D, const double* __restrict__ sum, double count, float* __restrict__ mean) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < D) mean[d] = (float)(sum[d] / count);
+}
+
+__global__ void k_pool_merge_diag(int64_t D, float n_a, float n_b, const float* __restrict__ mean_b,
+                                  const double* __restrict__ m2_b_sum, float* __restrict__ mean,
+                                  float* __restrict__ m2) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const float n_ab = n_a + n_b;
+  const float delta = mean_b[d] - mean[d];
+  const float mean_ab = mean[d] + delta * (n_b / n_ab);
+  const float coef = (n_a * n_b) / n_ab;
+  const float cross = (delta * delta) * coef;
+  m2[d] = (m2[d] + (float)m2_b_sum[d]) + cross;
+  mean[d] = mean_ab;
+}
+
+__global__ void k_pool_final_diag(int64_t D, float count, const float* __restrict__ m2, float* __restrict__ imm) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const float v = m2[d] / (count - 1.0f);
+  imm[d] = (v != v) ? v : fmaxf(v, 1e-20f);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool_center(int64_t N, int64_t D, const float* __restrict__ x,
+                                                     const float* __restrict__ center,
+                                                     float* __restrict__ out) {
+  const int64_t per_row = D / VEC;
+  const int64_t total = N * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row, c = (i - r * per_row) * VEC;
+    float t[VEC], m[VEC];
+    ld_vec<VEC>(x + r * D + c, t);
+    ld_vec<VEC>(center + c, m);
+    if constexpr (VEC == 4) {
+      st4(out + r * D + c, F4{t[0] - m[0], t[1] - m[1], t[2] - m[2], t[3] - m[3]});
+    } else {
+      out[r * D + c] = t[0] - m[0];
+    }
+  }
+}
+
+__global__ void k_halton_steps(int64_t N, const int32_t* __restrict__ arg, int max_bits, float ja, float jb,
+                               float num_leapfrog, int32_t* __restrict__ steps) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint32_t i = (uint32_t)arg[n] + 1u;
+  float h = 0.0f;
+  for (int k = 0; k < max_bits; ++k)
+    if ((i >> k) & 1u) h += ldexpf(0.5f, -k);  // exact: distinct powers of two, max_bits <= 24
+  const float jitter = h * ja + jb;
+  steps[n] = (int32_t)ceilf(jitter * num_leapfrog);
+}
+
+inline unsigned flat_grid(int64_t n, int block) {
+  int64_t b = (n + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > 65536) b = 65536;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bjx_pool_workspace_bytes(int64_t N, int64_t D) {
+  if (N <= 0 || D <= 0) return 0;
+  const ColGeom g4 = col_geom(N, D, 4), g1 = col_geom(N, D, 1);
+  const int64_t slabs = g4.nslab > g1.nslab ? g4.nslab : g1.nslab;
+  return slabs * 4 * D * (int64_t)sizeof(double);
+}
+
+int bjx_chees_weights(hipStream_t stream, int64_t N, int64_t D, const float* q_prop, const float* acc,
+                      const uint8_t* is_divergent, float* w) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_chees_weights: negative size");
+  if (N == 0) return 0;
+  BJX_CHECK_ARG((q_prop || D == 0) && acc && is_divergent && w, "bjx_chees_weights: null pointer");
+  const unsigned grid = bjx_row_grid(N, 4);
+  if (bjx_vec4_ok(D, q_prop))
+    hipLaunchKernelGGL(k_chees_weights<4>, dim3(grid), dim3(256), 0, stream, N, D, q_prop, acc,
+                       is_divergent, w);
+  else
+    hipLaunchKernelGGL(k_chees_weights<1>, dim3(grid), dim3(256), 0, stream, N, D, q_prop, acc,
+                       is_divergent, w);
+  return bjx_check_launch("bjx_chees_weights");
+}
+
+int bjx_chees_colstats(hipStream_t stream, int64_t N, int64_t D, const float* q_prop, const float* w,
+                       const float* q_init, void* workspace, double* stats) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_chees_colstats: negative size");
+  BJX_CHECK_ARG(stats || D == 0, "bjx_chees_colstats: null stats");
+  BJX_CHECK_ARG(N == 0 || D == 0 || (q_prop && w && q_init && workspace), "bjx_chees_colstats: null pointer");
+  OpChees op{q_prop, w, q_init};
+  return run_colreduce(stream, N, D, bjx_vec4_ok(D, q_prop, q_init), op, workspace, stats,
+                       "bjx_chees_colstats");
+}
+
+int bjx_chees_means(hipStream_t stream, int64_t D, const double* stats, const float* imm,
+                    float* proposals_mean, float* initials_mean, float* inv_sqrt_imm) {
+  BJX_CHECK_ARG(D >= 0, "bjx_chees_means: negative size");
+  if (D == 0) return 0;
+  BJX_CHECK_ARG(stats && proposals_mean && initials_mean, "bjx_chees_means: null pointer");
+  hipLaunchKernelGGL(k_chees_means, dim3(flat_grid(D, 256)), dim3(256), 0, stream, D, stats, imm,
+                     proposals_mean, initials_mean, inv_sqrt_imm);
+  return bjx_check_launch("bjx_chees_means");
+}
+
+int bjx_chees_criterion(hipStream_t stream, int64_t N, int64_t D, const float* q_prop,
+                        const float* p_prop, const float* q_init, const float* proposals_mean,
+                        const float* initials_mean, const float* imm, const float* inv_sqrt_imm,
+                        float* crit) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_chees_criterion: negative size");
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(crit && (D == 0 || (q_prop && p_prop && q_init && proposals_mean && initials_mean)),
+                "bjx_chees_criterion: null pointer");
+  BJX_CHECK_ARG((imm == nullptr) == (inv_sqrt_imm == nullptr),
+                "bjx_chees_criterion: imm and inv_sqrt_imm must both be given or both be NULL");
+  const unsigned grid = bjx_row_grid(N, 4);
+  const bool v4 = bjx_vec4_ok(D, q_prop, p_prop, q_init, proposals_mean, initials_mean, imm, inv_sqrt_imm);
+#define BJX_LAUNCH_CRIT(V, W)                                                                         \
+  hipLaunchKernelGGL((k_chees_criterion<V, W>), dim3(grid), dim3(256), 0, stream, N, D, q_prop,       \
+                     p_prop, q_init, proposals_mean, initials_mean, imm, inv_sqrt_imm, crit)
+  if (imm != nullptr) {
+    if (v4) BJX_LAUNCH_CRIT(4, true); else BJX_LAUNCH_CRIT(1, true);
+  } else {
+    if (v4) BJX_LAUNCH_CRIT(4, false); else BJX_LAUNCH_CRIT(1, false);
+  }
+#undef BJX_LAUNCH_CRIT
+  return bjx_check_launch("bjx_chees_criterion");
+}
+
+int bjx_chees_scalars(hipStream_t stream, int64_t N, const float* acc, const uint8_t* is_divergent,
+                      const float* crit, float scale, double* out) {
+  BJX_CHECK_ARG(N >= 0 && out, "bjx_chees_scalars: bad arguments");
+  BJX_CHECK_ARG(N == 0 || (acc && is_divergent), "bjx_chees_scalars: null pointer");
+  hipLaunchKernelGGL(k_chees_scalars, dim3(1), dim3(1024), 0, stream, N, acc, is_divergent, crit, scale,
+                     out);
+  return bjx_check_launch("bjx_chees_scalars");
+}
+
+int bjx_pool_colsum(hipStream_t stream, int64_t N, int64_t D, const float* x, const float* center,
+                    void* workspace, double* out) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_pool_colsum: negative size");
+  BJX_CHECK_ARG(out || D == 0, "bjx_pool_colsum: null out");
+  BJX_CHECK_ARG(N == 0 || D == 0 || (x && workspace), "bjx_pool_colsum: null pointer");
+  if (center != nullptr) {
+    OpCenteredSq op{x, center};
+    return run_colreduce(stream, N, D, bjx_vec4_ok(D, x, center), op, workspace, out, "bjx_pool_colsum");
+  }
+  OpSum op{x};
+  return run_colreduce(stream, N, D, bjx_vec4_ok(D, x), op, workspace, out, "bjx_pool_colsum");
+}
+
+int bjx_pool_mean(hipStream_t stream, int64_t D, const double* sum, double count, float* mean) {
+  BJX_CHECK_ARG(D >= 0, "bjx_pool_mean: negative size");
+  if (D == 0) return 0;
+  BJX_CHECK_ARG(sum && mean, "bjx_pool_mean: null pointer");
+  hipLaunchKernelGGL(k_pool_mean, dim3(flat_grid(D, 256)), dim3(256), 0, stream, D, sum, count, mean);
+  return bjx_check_launch("bjx_pool_mean");
+}
+
+int bjx_pool_merge_diag(hipStream_t stream, int64_t D, float n_a, float n_b, const float* mean_b,
+                        const double* m2_b_sum, float* mean, float* m2) {
+  BJX_CHECK_ARG(D >= 0, "bjx_pool_merge_diag: negative size");
+  if (D == 0) return 0;
+  BJX_CHECK_ARG(mean_b && m2_b_sum && mean && m2, "bjx_pool_merge_diag: null pointer");
+  BJX_CHECK_ARG(n_a + n_b > 0.0f, "bjx_pool_merge_diag: empty merge");
+  hipLaunchKernelGGL(k_pool_merge_diag, dim3(flat_grid(D, 256)), dim3(256), 0, stream, D, n_a, n_b,
+                     mean_b, m2_b_sum, mean, m2);
+  return bjx_check_launch("bjx_pool_merge_diag");
+}
+
+int bjx_pool_final_diag(hipStream_t stream, int64_t D, float count, const float* m2, float* imm) {
+  BJX_CHECK_ARG(D >= 0, "bjx_pool_final_diag: negative size");
+  if (D == 0) return 0;
+  BJX_CHECK_ARG(m2 && imm, "bjx_pool_final_diag: null pointer");
+  hipLaunchKernelGGL(k_pool_final_diag, dim3(flat_grid(D, 256)), dim3(256), 0, stream, D, count, m2, imm);
+  return bjx_check_launch("bjx_pool_final_diag");
+}
+
+int bjx_pool_center(hipStream_t stream, int64_t N, int64_t D, const float* x, const float* center,
+                    float* centered) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_pool_center: negative size");
+  if (N == 0 || D == 0) return 0;
+  BJX_CHECK_ARG(x && center && centered, "bjx_pool_center: null pointer");
+  if (bjx_vec4_ok(D, x, center, centered))
+    hipLaunchKernelGGL(k_pool_center<4>, dim3(flat_grid(N * (D / 4), 256)), dim3(256), 0, stream, N, D,
+                       x, center, centered);
+  else
+    hipLaunchKernelGGL(k_pool_center<1>, dim3(flat_grid(N * D, 256)), dim3(256), 0, stream, N, D, x,
+                       center, centered);
+  return bjx_check_launch("bjx_pool_center");
+}
+
+int bjx_halton_steps(hipStream_t stream, int64_t N, const int32_t* arg, int32_t max_bits,
+                     float jitter_amount, float jitter_offset, float num_leapfrog_steps,
+                     int32_t* steps) {
+  BJX_CHECK_ARG(N >= 0, "bjx_halton_steps: negative size");
+  BJX_CHECK_ARG(max_bits >= 0 && max_bits < 32,
+                "bjx_halton_steps: max_bits must be less than bit width of dtype int32 (32)");
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(arg && steps, "bjx_halton_steps: null pointer");
+  hipLaunchKernelGGL(k_halton_steps, dim3(flat_grid(N, 256)), dim3(256), 0, stream, N, arg, (int)max_bits,
+                     jitter_amount, jitter_offset, num_leapfrog_steps, steps);
+  return bjx_check_launch("bjx_halton_steps");
+}
+
+}  // extern "C"

@@ -15,7 +15,7 @@ from typing import NamedTuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["ChainShard", "shard_chains", "all_gather_chains", "MomentBlock", "moment_block",
+__all__ = ["ChainShard", "shard_chains", "all_gather_chains", "all_reduce_sum_", "MomentBlock", "moment_block",
            "merge_moment_blocks", "all_reduce_moments"]
 
 
@@ -51,6 +51,17 @@ def all_gather_chains(local: torch.Tensor, shard: ChainShard, group=None) -> tor
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad.contiguous(), group=group)
     return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
+
+
+def all_reduce_sum_(buf: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place all-reduce(sum) of a statistics buffer over the ranks of ``group``; a no-op for a
+    single process (``group is None`` means "this process only", NOT the default group, so that
+    rank-local runs never issue a collective by accident).  This is the exchange step of the pooled
+    (cross-chain) warmup, include/bjx_pool.h."""
+    if group is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return buf
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
 
 
 class MomentBlock(NamedTuple):

@@ -24,7 +24,7 @@ from .hmc import HMCInfo, IntegratorState
 from .random import key_spec
 
 __all__ = ["DynamicHMCState", "init", "build_kernel", "as_top_level_api", "chain_keys",
-           "next_key_fn", "randint_steps_fn"]
+           "next_key_fn", "randint_steps_fn", "halton_sequence", "halton_steps_fn"]
 
 
 class DynamicHMCState(NamedTuple):
@@ -63,14 +63,51 @@ def randint_steps_fn(keys: torch.Tensor, minval: int = 1, maxval: int = 10) -> t
     return out
 
 
+def halton_sequence(i: int, max_bits: int = 10) -> np.float32:
+    """blackjax/mcmc/dynamic_hmc.py:205-215 for a host integer: the ``(i+1)``-th element of the
+    base-2 Halton sequence over ``max_bits`` bits (exact in fp32 for ``max_bits <= 24``)."""
+    max_bits = int(max_bits)
+    if max_bits >= 32:
+        raise ValueError(f"max_bits ({max_bits}) must be less than bit width of dtype int32 (32)")
+    v = np.float32(0.0)
+    for k in range(max_bits):
+        if ((int(i) + 1) >> k) & 1:
+            v = np.float32(v + np.float32(0.5 / (1 << k)))
+    return v
+
+
+def halton_steps_fn(max_bits: int, jitter_amount: float = 1.0) -> Callable:
+    """``integration_steps_fn`` of ChEES-HMC (chees_adaptation.py:762-771): per chain
+    ``ceil((halton(arg) * jitter_amount + (1 - jitter_amount)) * num_leapfrog_steps)`` from an integer
+    counter ``random_generator_arg`` of shape ``(N,)`` (int32, device)."""
+    max_bits = int(max_bits)
+    if max_bits >= 32:
+        raise ValueError(f"max_bits ({max_bits}) must be less than bit width of dtype int32 (32)")
+    ja, jb = float(np.float32(jitter_amount)), float(np.float32(1.0 - jitter_amount))
+
+    def steps_fn(random_generator_arg: torch.Tensor, num_leapfrog_steps: float) -> torch.Tensor:
+        arg = random_generator_arg
+        if arg.ndim != 1 or arg.dtype != torch.int32 or not arg.is_cuda:
+            raise ValueError("random_generator_arg must be a device (n_chains,) int32 counter tensor")
+        out = torch.empty_like(arg)
+        _lib.call("bjx_halton_steps", _lib.current_stream(), arg.shape[0], arg.contiguous().data_ptr(),
+                  max_bits, ja, jb, float(num_leapfrog_steps), out.data_ptr())
+        return out
+
+    return steps_fn
+
+
 def init(position: torch.Tensor, logdensity_fn: Callable, random_generator_arg: torch.Tensor):
-    """blackjax/mcmc/dynamic_hmc.py:55-61."""
+    """blackjax/mcmc/dynamic_hmc.py:55-61.  ``random_generator_arg`` is per chain: ``(N, 2)`` int32
+    key words (the default key-driven callables) or an ``(N,)`` int32 counter (Halton jitter)."""
     position = check_batch(position, "position")
     logp, grad = eval_logdensity(value_and_grad(logdensity_fn), position)
     rga = random_generator_arg
-    if rga.shape != (position.shape[0], 2) or rga.dtype != torch.int32 or not rga.is_cuda:
-        raise ValueError("random_generator_arg must be a device (n_chains, 2) int32 tensor of key words "
-                         "(see dynamic_hmc.chain_keys)")
+    n = position.shape[0]
+    if (not isinstance(rga, torch.Tensor) or rga.dtype != torch.int32 or not rga.is_cuda
+            or rga.shape not in ((n, 2), (n,))):
+        raise ValueError("random_generator_arg must be a device int32 tensor: (n_chains, 2) key words "
+                         "(see dynamic_hmc.chain_keys) or an (n_chains,) counter")
     return DynamicHMCState(position, logp, grad, rga.contiguous())
 
 
@@ -112,16 +149,27 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
                   p0.data_ptr(), ke0.data_ptr())
         q, p = torch.empty_like(q0), torch.empty_like(q0)
-        ns = n_steps.data_ptr()
-        _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                  q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), ns, 0)
-        logp, g = eval_logdensity(vg, q)
-        for l in range(1, hi):
-            # chains with n_steps <= l are skipped; their q is unchanged so the callable keeps
-            # returning the same (logp, g) for them
-            _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                      q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr(), ns, l)
+        if lo == hi:
+            # every chain integrates the same number of steps (e.g. a shared Halton counter after
+            # ChEES warmup): the plain, unmasked leapfrog kernel of blackjax_amd.hmc
+            _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                      q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
             logp, g = eval_logdensity(vg, q)
+            for l in range(1, hi):
+                _lib.call("bjx_leapfrog_diag", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                          q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr())
+                logp, g = eval_logdensity(vg, q)
+        else:
+            ns = n_steps.data_ptr()
+            _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                      q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), ns, 0)
+            logp, g = eval_logdensity(vg, q)
+            for l in range(1, hi):
+                # chains with n_steps <= l are skipped; their q is unchanged so the callable keeps
+                # returning the same (logp, g) for them
+                _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                          q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr(), ns, l)
+                logp, g = eval_logdensity(vg, q)
 
         p_end, q_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         logp_new, acc_rate, energy = (torch.empty_like(logp0) for _ in range(3))

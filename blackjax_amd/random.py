@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["key", "PRNGKey", "split", "fold_in", "key_words", "ChainMajorKey", "key_spec"]
+__all__ = ["key", "PRNGKey", "split", "fold_in", "uniform", "key_words", "ChainMajorKey", "key_spec"]
 
 
 def key(seed: int) -> np.ndarray:
@@ -52,6 +52,16 @@ def split(rng_key, num: int = 2, offset: int = 0) -> np.ndarray:
 def fold_in(rng_key, data: int) -> np.ndarray:
     """jax.random.fold_in(key, data) == split(key, .)[data] for threefry-partitionable keys."""
     return split(rng_key, 1, offset=int(data) & 0xFFFFFFFF)[0]
+
+
+def uniform(rng_key) -> np.float32:
+    """jax.random.uniform(key, (), float32) on the host: 23 mantissa bits of
+    ``random_bits(key, 32, ())`` = the xor of the two threefry output words at counter 0."""
+    w = split(rng_key, 1)[0]
+    bits = np.uint32(w[0] ^ w[1])
+    f = (np.array([(bits >> np.uint32(9)) | np.uint32(0x3F800000)], np.uint32).view(np.float32)[0]
+         - np.float32(1.0))
+    return np.float32(max(np.float32(0.0), f))
 
 
 class ChainMajorKey:

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "bjx_hip.h")).read()
     text += open(os.path.join(ROOT, "include", "bjx_nuts.h")).read()
+    text += open(os.path.join(ROOT, "include", "bjx_pool.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bjx_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,8 +25,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bjx_hip.h but not exported"
     # and every bound prototype is declared in the header
-    for s in _lib.SIGNATURES:
-        assert s in syms, f"{s} bound in _lib.py but not declared in include/bjx_hip.h"
+    for s in list(_lib.SIGNATURES) + list(_lib.INT64_FUNCTIONS):
+        assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
+    assert lib.bjx_pool_workspace_bytes(0, 8) == 0
+    assert lib.bjx_pool_workspace_bytes(65536, 1024) == 1024 * 4 * 1024 * 8
     assert lib.bjx_abi_version() == 1
 
 
