@@ -8,10 +8,18 @@ chain (momentum draw, L leapfrogs each followed by the log-density callable, Met
 accept).  Chains shard over GPUs with no data-path collective (weak scaling: 65 536
 chains PER GPU); per-chain keys come from the global chain index.
 
+Scheduling of a transition (``--chain-block``): chains are independent, so the engine may run a
+transition block by block over chains.  The default (-1, "auto") sizes a block so that its q, p, g
+fit the 256 MiB Infinity Cache (16 384 chains at D = 1 024) -- same kernels, same results bit for
+bit, every launch bracketed and counted as usual; 0 runs all chains in one launch (pure HBM
+streaming).  The all-at-once mode is measured too and reported beside the headline as
+``plain_mode``.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (fused kick+drift leapfrog): ALGORITHMIC bytes per launch
-                  (20 B x D x N: read p,g,q; write p,q) / mean launch duration measured with
-                  HIP events on the launch stream inside the timed region; peak 8000 GB/s.
+                  (20 B x D x chains per launch: read p,g,q; write p,q) / mean launch duration
+                  measured with HIP events on the launch stream inside the timed region (every 4th
+                  launch is bracketed when a transition has >= 100 launches); peak 8000 GB/s.
   cpu_baseline -- the oracle's C/OpenMP port of the same transition timed on the host cores on a
                   bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
 """
@@ -84,12 +92,13 @@ def main():
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--leapfrogs", type=int, default=50)
     ap.add_argument("--eps", type=float, default=0.25)
-    ap.add_argument("--chain-block", type=int, default=0,
-                    help="run each transition block-by-block over this many chains (0 = all at once)")
+    ap.add_argument("--chain-block", type=int, default=-1,
+                    help="chains per launch: -1 = auto (block sized for the Infinity Cache), "
+                         "0 = all chains at once, n = n chains")
     ap.add_argument("--use-graph", action="store_true",
                     help="capture each block's inner leapfrog/callable loop in a HIP graph")
-    ap.add_argument("--no-ic-mode", action="store_true",
-                    help="skip the extra Infinity-Cache-mode measurement (chain blocks + HIP graph)")
+    ap.add_argument("--no-plain-mode", action="store_true",
+                    help="skip the extra all-chains-at-once (HBM streaming) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     args = ap.parse_args()
@@ -109,61 +118,102 @@ def main():
 
     import blackjax_amd as bjx
     from blackjax_amd import _lib
+    from blackjax_amd.hmc import auto_chain_block
 
     N, D, L = args.chains, args.dim, args.leapfrogs
+    blk = auto_chain_block(N, D) if args.chain_block < 0 else (args.chain_block or N)
+    blk = min(blk, N)
+    n_blocks = (N + blk - 1) // blk
     sig = torch.as_tensor(sigma_ladder(D), device=dev)
     imm = (sig * sig).contiguous()
     target = bjx.targets.DiagGaussian((1.0 / imm).contiguous())
-    alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N,
-                  chain_block=args.chain_block or None, use_graph=args.use_graph)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    state = alg.init(sig * torch.randn(N, D, device=dev, generator=gen))
+    q_init = sig * torch.randn(N, D, device=dev, generator=gen)
     keys = bjx.random.split(bjx.random.key(0), args.warmup + args.steps)
+    n_sub = min(1024, N)
+    timed_kernel = "bjx_leapfrog_diag"
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # Warm-up runs EXACTLY the timed loop's body (including the bookkeeping torch ops and the
-    # launch-timer events): on a fresh box the first use of any kernel pages its code object in from
-    # disk (tens of ms per torch op), which must not land in the timed region.
-    n_sub = min(1024, N)
-    warm_timer = None if args.no_launch_timing else _lib.LaunchTimer(["bjx_leapfrog_diag"])
-    _lib.set_timer(warm_timer)
-    warm_acc = torch.zeros((), device=dev)
-    prime_key = bjx.random.key(12345)
-    for t in range(-1, args.warmup):  # one extra priming pass (t = -1) in addition to the W warm-ups
-        state, info = alg.step(prime_key if t < 0 else keys[t], state)
-        warm_acc += info.acceptance_rate.mean()
-        _ = state.position[:n_sub].clone()
-    _lib.set_timer(None)
-    if warm_timer is not None:
-        warm_timer.durations_ms("bjx_leapfrog_diag")  # first elapsed_time() call warms that path too
-    torch.cuda.synchronize()
+    def measure(chain_block, use_graph, collect_draws):
+        """W warm-up + K timed transitions in one scheduling mode.  The warm-up runs EXACTLY the
+        timed loop's body (bookkeeping torch ops and launch-timer events included) plus one priming
+        pass: on a fresh box the first use of any kernel pages its code object in from disk, which
+        must not land in the timed region."""
+        alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=chain_block,
+                      use_graph=use_graph)
+        state = alg.init(q_init)
+        launches = L * ((N + chain_block - 1) // chain_block)
+        every = 4 if launches >= 100 else 1
+        timing = not args.no_launch_timing and not use_graph  # events cannot be recorded inside a graph
+        warm_timer = _lib.LaunchTimer([timed_kernel], every) if timing else None
+        _lib.set_timer(warm_timer)
+        warm_acc = torch.zeros((), device=dev)
+        prime_key = bjx.random.key(12345)
+        for t in range(-1, args.warmup):
+            state, info = alg.step(prime_key if t < 0 else keys[t], state)
+            warm_acc += info.acceptance_rate.mean()
+            _ = state.position[:n_sub].clone()
+        _lib.set_timer(None)
+        if warm_timer is not None:
+            warm_timer.durations_ms(timed_kernel)  # first elapsed_time() call warms that path too
+        torch.cuda.synchronize()
 
-    timer = None
-    if not args.no_launch_timing and rank == 0:
-        timer = _lib.LaunchTimer(["bjx_leapfrog_diag"])
-        _lib.set_timer(timer)
-    acc_sum = torch.zeros((), device=dev)
-    draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, args.warmup + args.steps):
-        state, info = alg.step(keys[t], state)
-        acc_sum += info.acceptance_rate.mean()
-        draws.append(state.position[:n_sub].clone())
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.set_timer(None)
+        timer = None
+        if timing and rank == 0:
+            timer = _lib.LaunchTimer([timed_kernel], every)
+            _lib.set_timer(timer)
+        acc_sum = torch.zeros((), device=dev)
+        draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, args.warmup + args.steps):
+            state, info = alg.step(keys[t], state)
+            acc_sum += info.acceptance_rate.mean()
+            if collect_draws:
+                draws.append(state.position[:n_sub].clone())
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        _lib.set_timer(None)
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        roof = None
+        if timer is not None:
+            d_ms = timer.durations_ms(timed_kernel)
+            avg_s = float(np.mean(d_ms)) * 1e-3
+            alg_bytes = 20.0 * D * min(chain_block, N)  # read p,g,q ; write p,q (imm (D,) is shared and cached)
+            achieved = alg_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "k_leapfrog_diag<4,2>", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                    "chains_per_launch": min(chain_block, N), "avg_launch_us": avg_s * 1e6,
+                    "launches_timed": len(d_ms), "timed_every": every}
+        return state, dt, roof, float(acc_sum.item()) / max(args.steps, 1), draws
+
+    state, dt, roofline, mean_acc, draws = measure(blk, args.use_graph, True)
+    if roofline is not None:
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if (tj.get("chains") == N and tj.get("dim") == D
+                        and tj.get("chains_per_launch", N) == roofline["chains_per_launch"]):
+                    roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if n_blocks > 1:
+            roofline["note"] = ("chain-block scheduling: a block's q/p/g stay resident in the 256 MiB Infinity "
+                                "Cache across the L steps, so part of this kernel's traffic never reaches "
+                                "HBM; plain_mode.roofline is the same kernel streaming from HBM")
 
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         # final draws / statistics are the only thing that crosses xGMI (RCCL all-gather)
         sub = state.position[:256].contiguous()
         gathered = [torch.empty_like(sub) for _ in range(world)]
@@ -172,29 +222,13 @@ def main():
     else:
         final_draws = state.position[:256]
 
-    # Extra, separately reported region: the same workload run block-by-block (16 384 chains at a
-    # time, inner loop captured in a HIP graph) so a block's q/p/g stay in the 256 MiB Infinity
-    # Cache across the L steps.  Not the headline `value` (its kernels are not HBM streams).
-    ic_mode = None
-    if not args.no_ic_mode and not args.chain_block and not args.use_graph and N > 16384:
-        alg_ic = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=16384,
-                         use_graph=True)
-        st_ic = state
-        st_ic, _ = alg_ic.step(keys[0], st_ic)  # captures the graph
-        barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for t in range(args.warmup, args.warmup + args.steps):
-            st_ic, _ = alg_ic.step(keys[t], st_ic)
-        torch.cuda.synchronize()
-        barrier()
-        dt_ic = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dt_ic], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_ic = float(tt.item())
-        ic_mode = {"value": world * N * L * args.steps / dt_ic, "unit": "chain-leapfrog-steps/s",
-                   "chain_block": 16384, "hip_graph": True, "ms_per_step": dt_ic / args.steps * 1e3}
+    # Extra, separately reported region: the same workload with all chains in one launch (every
+    # leapfrog launch streams its 1.3 GB from HBM).
+    plain_mode = None
+    if not args.no_plain_mode and n_blocks > 1:
+        _, dt_p, roof_p, _, _ = measure(N, False, False)
+        plain_mode = {"value": world * N * L * args.steps / dt_p, "unit": "chain-leapfrog-steps/s",
+                      "ms_per_step": dt_p / args.steps * 1e3, "roofline": roof_p}
 
     # ESS/sec (second half of BASELINE.json's metric): min over dimensions of
     # effective_sample_size (blackjax/diagnostics.py:157-304) on the retained subset / wall time
@@ -204,29 +238,7 @@ def main():
         ess_min = float(ess.min().item())
 
     if rank == 0:
-        total_chain_leapfrogs = world * N * L * args.steps
-        value = total_chain_leapfrogs / dt
-        roofline = None
-        if timer is not None:
-            d_ms = timer.durations_ms("bjx_leapfrog_diag")
-            avg_s = float(np.mean(d_ms)) * 1e-3
-            alg_bytes = 20.0 * D * N  # read p,g,q ; write p,q (imm (D,) is shared and cached)
-            achieved = alg_bytes / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("chains") == N and tj.get("dim") == D:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {
-                "bound": "hbm", "kernel": "k_leapfrog_diag<4,2>", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_us": avg_s * 1e6, "launches_timed": len(d_ms),
-            }
+        value = world * N * L * args.steps / dt
         out = {
             "metric": "chain-leapfrog-steps/sec (whole node), 65 536 chains x 1 024-dim diag-mass HMC",
             "value": value,
@@ -244,10 +256,10 @@ def main():
                 "workload": f"HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
                             f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
                 "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
-                "chain_block": args.chain_block or N, "hip_graph": bool(args.use_graph),
+                "chain_block": blk, "hip_graph": bool(args.use_graph),
                 "parallelism": f"chains sharded x{world}, no data-path collective",
             },
-            "mean_acceptance": float(acc_sum.item()) / args.steps,
+            "mean_acceptance": mean_acc,
             "ess": None if ess_min is None else {
                 "min_ess_subset": ess_min, "subset_chains": n_sub, "draws_per_chain": args.steps,
                 "min_ess_per_sec_subset": ess_min / dt,
@@ -255,7 +267,7 @@ def main():
                 "note": "rank-0 subset of chains, min over the D dimensions"},
             "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
             "final_draws_gathered": list(final_draws.shape),
-            "infinity_cache_mode": ic_mode,
+            "plain_mode": plain_mode,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

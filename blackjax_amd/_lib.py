@@ -182,9 +182,13 @@ class LaunchTimer:
     """Brackets selected entry points with HIP events on the current stream so a caller
     (bench.py) can read per-launch kernel durations of the timed region afterwards."""
 
-    def __init__(self, names):
+    def __init__(self, names, every: int = 1):
+        """``every``: bracket only every k-th launch of each name (two event records cost a few
+        microseconds of host time, which matters once launches are ~50 us)."""
         self.names = set(names)
         self.events = {n: [] for n in self.names}
+        self.every = max(1, int(every))
+        self.seen = {n: 0 for n in self.names}
 
     def durations_ms(self, name):
         import torch
@@ -203,7 +207,11 @@ def set_timer(timer) -> None:
 
 def call(name: str, *args) -> None:
     lib = load()
-    if _timer is not None and name in _timer.names:
+    timed = _timer is not None and name in _timer.names
+    if timed:
+        _timer.seen[name] += 1
+        timed = _timer.seen[name] % _timer.every == 0
+    if timed:
         import torch
 
         s = torch.cuda.Event(enable_timing=True)

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bjx_log1p.h"
+
 #define BJX_WAVE 64
 
 namespace bjx {
@@ -70,10 +72,13 @@ __device__ __forceinline__ float key_uniform(Key key) {
   return fmaxf(0.0f, unit_float(key_bits32(key, 0)));
 }
 
-// XLA ErfInv32 (Giles' single-precision polynomial); log1p evaluated in fp64 and rounded once.
+// XLA ErfInv32 (Giles' single-precision polynomial); log1p evaluated in fp64 and rounded once --
+// through the fast correctly-rounded path of bjx_log1p.h, the library log1p only when that path
+// cannot decide the rounding (2^-21 of the inputs; results identical by construction).
 __device__ __forceinline__ float erfinv_f32(float x) {
   float t = -(x * x);
-  float w = -(float)log1p((double)t);
+  float w;
+  if (!bjx_neg_log1p_fast(t, &w)) w = -(float)log1p((double)t);
   const bool lt = w < 5.0f;
   float p;
   if (lt) {

@@ -64,33 +64,48 @@ struct OpChees {  // chees_adaptation.py:241-246, 384-386
   const float* w;
   const float* qi;
   template <int VEC>
-  __device__ __forceinline__ void row(int64_t r, int64_t off, double (&a)[K][VEC]) const {
-    const double wr = (double)w[r];
-    float x[VEC], y[VEC];
-    ld_vec<VEC>(qp + off, x);
-    ld_vec<VEC>(qi + off, y);
+  struct Regs {
+    float x[VEC], y[VEC], w;
+  };
+  template <int VEC>
+  __device__ __forceinline__ void load(int64_t r, int64_t off, Regs<VEC>& g) const {
+    g.w = w[r];
+    ld_vec<VEC>(qp + off, g.x);
+    ld_vec<VEC>(qi + off, g.y);
+  }
+  template <int VEC>
+  __device__ __forceinline__ void acc(const Regs<VEC>& g, double (&a)[K][VEC], const float*) const {
+    const double wr = (double)g.w;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float xs = isfinite(x[v]) ? x[v] : 0.0f;
+      const float xs = isfinite(g.x[v]) ? g.x[v] : 0.0f;
       a[0][v] += wr * (double)xs;
-      const bool ok = !(y[v] != y[v]);
-      a[1][v] += ok ? (double)y[v] : 0.0;
+      const bool ok = !(g.y[v] != g.y[v]);
+      a[1][v] += ok ? (double)g.y[v] : 0.0;
       a[2][v] += ok ? 1.0 : 0.0;
-      a[3][v] += wr;
     }
+    a[3][0] += wr;  // one accumulator per thread; broadcast over its columns when stored
   }
+  static constexpr bool kBroadcastLast = true;
 };
 
 struct OpSum {  // metric_buffers.py:429
   static constexpr int K = 1;
   const float* x;
   template <int VEC>
-  __device__ __forceinline__ void row(int64_t, int64_t off, double (&a)[K][VEC]) const {
+  struct Regs {
     float t[VEC];
-    ld_vec<VEC>(x + off, t);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) a[0][v] += (double)t[v];
+  };
+  template <int VEC>
+  __device__ __forceinline__ void load(int64_t, int64_t off, Regs<VEC>& g) const {
+    ld_vec<VEC>(x + off, g.t);
   }
+  template <int VEC>
+  __device__ __forceinline__ void acc(const Regs<VEC>& g, double (&a)[K][VEC], const float*) const {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[0][v] += (double)g.t[v];
+  }
+  static constexpr bool kBroadcastLast = false;
 };
 
 struct OpCenteredSq {  // metric_buffers.py:430-433
@@ -98,15 +113,22 @@ struct OpCenteredSq {  // metric_buffers.py:430-433
   const float* x;
   const float* center;
   template <int VEC>
-  __device__ __forceinline__ void row(int64_t, int64_t off, double (&a)[K][VEC], const float (&c)[VEC]) const {
+  struct Regs {
     float t[VEC];
-    ld_vec<VEC>(x + off, t);
+  };
+  template <int VEC>
+  __device__ __forceinline__ void load(int64_t, int64_t off, Regs<VEC>& g) const {
+    ld_vec<VEC>(x + off, g.t);
+  }
+  template <int VEC>
+  __device__ __forceinline__ void acc(const Regs<VEC>& g, double (&a)[K][VEC], const float* c) const {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float d = t[v] - c[v];
+      const float d = g.t[v] - c[v];
       a[0][v] += (double)d * (double)d;
     }
   }
+  static constexpr bool kBroadcastLast = false;
 };
 
 template <int VEC, class Op>
@@ -125,13 +147,29 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr
 #pragma unroll
     for (int v = 0; v < VEC; ++v) a[k][v] = 0.0;
   if (c0 < D) {
-    if constexpr (std::is_same<Op, OpCenteredSq>::value) {
-      float c[VEC];
-      ld_vec<VEC>(op.center + c0, c);
-      for (int64_t r = r_lo + ty; r < r_hi; r += rp) op.template row<VEC>(r, r * D + c0, a, c);
-    } else {
-      for (int64_t r = r_lo + ty; r < r_hi; r += rp) op.template row<VEC>(r, r * D + c0, a);
+    float c[VEC] = {};
+    if constexpr (std::is_same<Op, OpCenteredSq>::value) ld_vec<VEC>(op.center + c0, c);
+    // U rows are loaded before any is accumulated (memory-level parallelism: U independent 16-byte
+    // loads per input in flight per lane); accumulation order stays r ascending.
+    constexpr int U = 8;
+    using R = typename Op::template Regs<VEC>;
+    int64_t r = r_lo + ty;
+    for (; r + (int64_t)(U - 1) * rp < r_hi; r += (int64_t)U * rp) {
+      R g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) op.template load<VEC>(r + (int64_t)u * rp, (r + (int64_t)u * rp) * D + c0, g[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) op.template acc<VEC>(g[u], a, c);
     }
+    for (; r < r_hi; r += rp) {
+      R g;
+      op.template load<VEC>(r, r * D + c0, g);
+      op.template acc<VEC>(g, a, c);
+    }
+  }
+  if constexpr (Op::kBroadcastLast) {
+#pragma unroll
+    for (int v = 1; v < VEC; ++v) a[K - 1][v] = a[K - 1][0];
   }
   double* mine = sm + (size_t)threadIdx.x * K * VEC;
 #pragma unroll
@@ -151,12 +189,34 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr
   }
 }
 
-__global__ void k_colfinal(int64_t nslab, int64_t KD, const double* partial, double* out) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= KD) return;
+// Second stage: lanes over 64 consecutive outputs (coalesced), the 16 waves of a block split the
+// slabs (wave w takes slabs w, w+16, ...; 8 loads in flight), LDS combine in wave order.
+__global__ __launch_bounds__(1024) void k_colfinal(int64_t nslab, int64_t KD, const double* __restrict__ partial,
+                                                   double* __restrict__ out) {
+  __shared__ double sm[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int64_t t = 0; t < nslab; ++t) s += partial[t * KD + j];
-  out[j] = s;
+  if (j < KD) {
+    constexpr int U = 8;
+    int64_t t = wv;
+    for (; t + (int64_t)(U - 1) * 16 < nslab; t += (int64_t)U * 16) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = partial[(t + (int64_t)u * 16) * KD + j];
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += v[u];
+    }
+    for (; t < nslab; t += 16) s += partial[t * KD + j];
+  }
+  sm[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && j < KD) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += sm[w][lane];
+    out[j] = tot;
+  }
 }
 
 template <class Op>
@@ -182,7 +242,7 @@ int run_colreduce(hipStream_t stream, int64_t N, int64_t D, bool vec4, Op op, vo
     hipLaunchKernelGGL((k_colreduce<1, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2,
                        g.rows_per_slab, op, partial);
   const int64_t KD = (int64_t)K * D;
-  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, stream, g.nslab, KD,
+  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 63) / 64)), dim3(1024), 0, stream, g.nslab, KD,
                      partial, out);
   return bjx_check_launch(what);
 }
@@ -196,17 +256,41 @@ __global__ __launch_bounds__(256) void k_chees_weights(int64_t N, int64_t D, con
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t n = wave; n < N; n += nwaves) {
-    const float* row = qp + n * D;
-    bool bad = false;
-    for (int64_t c = (int64_t)lane * VEC; c < D; c += 64 * VEC) {
-      float x[VEC];
-      ld_vec<VEC>(row + c, x);
+  // RW rows per wave and iteration, all their loads issued before any is tested: a 4 KB row alone
+  // is too little work per wave to keep HBM busy
+  constexpr int RW = 4;
+  for (int64_t n0 = wave * RW; n0 < N; n0 += nwaves * RW) {
+    bool bad[RW];
+    float a_n[RW];
+    uint8_t d_n[RW];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) bad |= !isfinite(x[v]);
+    for (int r = 0; r < RW; ++r) {  // per-chain scalars requested up front, not after the row sweep
+      bad[r] = false;
+      const bool in = n0 + r < N;
+      a_n[r] = in ? acc[n0 + r] : 0.0f;
+      d_n[r] = in ? is_div[n0 + r] : (uint8_t)1;
     }
-    const bool any_bad = __any(bad);
-    if (lane == 0) w[n] = (is_div[n] || any_bad) ? 0.0f : acc[n];
+    for (int64_t c = (int64_t)lane * VEC; c < D; c += 64 * VEC) {
+      float x[RW][VEC];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (n0 + r < N) {
+          ld_vec<VEC>(qp + (n0 + r) * D + c, x[r]);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[r][v] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) bad[r] |= !isfinite(x[r][v]);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const bool any_bad = __any(bad[r]);
+      if (lane == 0 && n0 + r < N) w[n0 + r] = (d_n[r] || any_bad) ? 0.0f : a_n[r];
+    }
   }
 }
 
@@ -264,16 +348,31 @@ __global__ __launch_bounds__(1024) void k_chees_scalars(int64_t N, const float* 
                                                         double* __restrict__ out) {
   __shared__ double sm[4][16];
   double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t n = threadIdx.x; n < N; n += 1024) {
-    if (is_div[n]) continue;
-    const float a = acc[n];
-    s[0] += (double)(1.0f / a);
-    s[1] += 1.0;
-    if (crit != nullptr) {
-      const float tg = scale * crit[n];
-      s[2] += (double)a * (double)tg;
+  // one block (the result is 4 numbers); U chains per thread are loaded before any is used so the
+  // single CU keeps U x 1024 loads in flight
+  constexpr int U = 8;
+  for (int64_t n0 = threadIdx.x; n0 < N; n0 += (int64_t)1024 * U) {
+    float a[U], c[U];
+    uint8_t dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t n = n0 + (int64_t)u * 1024;
+      const bool in = n < N;
+      dv[u] = in ? is_div[n] : (uint8_t)1;
+      a[u] = in ? acc[n] : 0.0f;
+      c[u] = (in && crit != nullptr) ? crit[n] : 0.0f;
     }
-    s[3] += (double)(a + 1e-20f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (dv[u]) continue;
+      s[0] += (double)(1.0f / a[u]);
+      s[1] += 1.0;
+      if (crit != nullptr) {
+        const float tg = scale * c[u];
+        s[2] += (double)a[u] * (double)tg;
+      }
+      s[3] += (double)(a[u] + 1e-20f);
+    }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -380,7 +479,7 @@ int bjx_chees_weights(hipStream_t stream, int64_t N, int64_t D, const float* q_p
   BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_chees_weights: negative size");
   if (N == 0) return 0;
   BJX_CHECK_ARG((q_prop || D == 0) && acc && is_divergent && w, "bjx_chees_weights: null pointer");
-  const unsigned grid = bjx_row_grid(N, 4);
+  const unsigned grid = bjx_row_grid((N + 3) / 4, 4);  // 4 rows per wave, 4 waves per block
   if (bjx_vec4_ok(D, q_prop))
     hipLaunchKernelGGL(k_chees_weights<4>, dim3(grid), dim3(256), 0, stream, N, D, q_prop, acc,
                        is_divergent, w);

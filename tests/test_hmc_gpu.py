@@ -49,6 +49,19 @@ def test_rng_normal_uniform(dev, N, D):
     np.testing.assert_allclose(zz, z_ref, rtol=2e-7, atol=0)
 
 
+def test_rng_normal_large_sample_bit_exact(dev):
+    """8.4 M normals: the device's fast correctly-rounded log1p path (bjx_log1p.h) against the
+    oracle's fp64 log1p -- every draw bit-identical."""
+    N, D = 2048, 4096
+    key = prng.key(2024)
+    z = torch.empty(N, D, device=dev)
+    _lib.call("bjx_rng_normal", _lib.current_stream(), int(key[0]), int(key[1]), 0, N, D, z.data_ptr())
+    z_ref = prng.normal(prng.split(key, N), (D,))
+    zz = t2n(z)
+    assert np.array_equal(zz, z_ref), f"{np.sum(zz != z_ref)} of {zz.size} normal draws differ"
+    assert abs(float(zz.mean())) < 2e-3 and abs(float(zz.std()) - 1.0) < 2e-3
+
+
 @pytest.mark.parametrize("N,D,per_chain_imm", [(64, 1024, False), (5, 100, False), (9, 256, True), (3, 7, True)])
 def test_momentum_diag(dev, N, D, per_chain_imm):
     rng = np.random.default_rng(0)
