@@ -11,10 +11,12 @@ import math
 
 import torch
 
+from ._diag_rank import ess_bulk, ess_tail, rhat  # noqa: E402,F401
 from ._diag_rhat import potential_scale_reduction  # noqa: E402,F401
 
-rhat = potential_scale_reduction
-__all__ = ["effective_sample_size", "potential_scale_reduction", "rhat"]
+# NOTE: as in the reference, ``rhat`` is the rank-normalised split-R-hat (diagnostics.py:92-155), not
+# the classic ``potential_scale_reduction`` (39-89).
+__all__ = ["effective_sample_size", "potential_scale_reduction", "rhat", "ess_bulk", "ess_tail"]
 
 
 def _next_fast_len(n: int) -> int:

@@ -75,3 +75,66 @@ def effective_sample_size(input_array, chain_axis: int = 0, sample_axis: int = 1
     ess = ess_raw / tau
     ess = np.where(degenerate, 0.0, ess)
     return ess.reshape(event).astype(dtype)
+
+
+# ----------------------------------------------------------------------------- rank-normalised family
+def potential_scale_reduction(input_array, chain_axis: int = 0, sample_axis: int = 1):
+    """blackjax/diagnostics.py:39-89."""
+    x = np.moveaxis(np.asarray(input_array), (chain_axis, sample_axis), (0, 1))
+    assert x.shape[0] > 1
+    n = x.shape[1]
+    between = n * x.mean(1).var(0, ddof=1)
+    within = x.var(1, ddof=1).mean(0)
+    return np.sqrt((between / within + n - 1) / n)
+
+
+def split_chains(x):
+    """diagnostics.py:341-360: (M, T, ...) -> (2M, T//2, ...), an odd last draw is dropped."""
+    half = x.shape[1] // 2
+    return np.concatenate([x[:, :half], x[:, half:2 * half]], axis=0)
+
+
+def rank_normalize(x):
+    """diagnostics.py:363-401: Blom plotting position of the pooled ranks (stable double argsort)."""
+    from scipy.special import ndtri
+
+    M, T = x.shape[:2]
+    n = M * T
+    flat = x.reshape(n, *x.shape[2:])
+    ranks = np.argsort(np.argsort(flat, axis=0, kind="stable"), axis=0, kind="stable").astype(x.dtype) + 1
+    z = ndtri((ranks - x.dtype.type(3.0 / 8)) / x.dtype.type(n + 1.0 / 4)).astype(x.dtype)
+    return z.reshape(x.shape)
+
+
+def _std_axes(input_array, chain_axis, sample_axis):
+    x = np.asarray(input_array)
+    x = x.astype(x.dtype if x.dtype in (np.float32, np.float64) else np.float64)
+    return np.moveaxis(x, (chain_axis % x.ndim, sample_axis % x.ndim), (0, 1))
+
+
+def rhat(input_array, chain_axis: int = 0, sample_axis: int = 1):
+    """diagnostics.py:92-155: max of the split-R-hat of the rank-normalised draws and of the
+    rank-normalised draws folded about the pooled median."""
+    xs = split_chains(_std_axes(input_array, chain_axis, sample_axis))
+    bulk = potential_scale_reduction(rank_normalize(xs))
+    flat = xs.reshape(xs.shape[0] * xs.shape[1], *xs.shape[2:])
+    folded = np.abs(xs - np.median(flat, axis=0)).astype(xs.dtype)
+    tail = potential_scale_reduction(rank_normalize(folded))
+    return np.maximum(bulk, tail)
+
+
+def ess_bulk(input_array, chain_axis: int = 0, sample_axis: int = 1):
+    """diagnostics.py:404-443."""
+    xs = split_chains(_std_axes(input_array, chain_axis, sample_axis))
+    return effective_sample_size(rank_normalize(xs))
+
+
+def ess_tail(input_array, chain_axis: int = 0, sample_axis: int = 1, prob: float = 0.90):
+    """diagnostics.py:446-522."""
+    xs = split_chains(_std_axes(input_array, chain_axis, sample_axis))
+    flat = xs.reshape(xs.shape[0] * xs.shape[1], *xs.shape[2:])
+    q_lo = np.quantile(flat, (1.0 - prob) / 2.0, axis=0).astype(xs.dtype)
+    q_hi = np.quantile(flat, (1.0 + prob) / 2.0, axis=0).astype(xs.dtype)
+    lower = effective_sample_size((xs <= q_lo[None, None]).astype(xs.dtype))
+    upper = effective_sample_size((xs >= q_hi[None, None]).astype(xs.dtype))
+    return np.minimum(lower, upper)
