@@ -110,8 +110,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # One rank per GPU over RCCL (backend "nccl").  BJX_BENCH_BACKEND=gloo exists only so the
+        # multi-rank control flow can be exercised on a single-GPU box (ranks then share cuda:0).
+        backend = os.environ.get("BJX_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (blackjax_amd has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

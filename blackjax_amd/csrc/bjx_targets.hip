@@ -110,9 +110,9 @@ extern "C" {
 
 int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* inv_var,
                              const float* q, float* logp_out, float* g_out) {
-  BJX_CHECK_ARG(N >= 0 && D > 0 && inv_var && q && logp_out && g_out,
-                "bjx_target_diag_gaussian: bad arguments");
-  if (N == 0) return 0;
+  BJX_CHECK_ARG(N >= 0 && D > 0, "bjx_target_diag_gaussian: bad arguments");
+  if (N == 0) return 0;  // an empty batch has no buffers to check
+  BJX_CHECK_ARG(inv_var && q && logp_out && g_out, "bjx_target_diag_gaussian: bad arguments");
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   if (bjx_vec4_ok(D, inv_var, q, g_out))
     hipLaunchKernelGGL(k_diag_gaussian<4>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
@@ -125,8 +125,9 @@ int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* in
 
 int bjx_target_neal_funnel(void* stream, int64_t N, int64_t D, const float* q, float* logp_out,
                            float* g_out) {
-  BJX_CHECK_ARG(N >= 0 && D >= 2 && q && logp_out && g_out, "bjx_target_neal_funnel: bad arguments");
+  BJX_CHECK_ARG(N >= 0 && D >= 2, "bjx_target_neal_funnel: bad arguments");
   if (N == 0) return 0;
+  BJX_CHECK_ARG(q && logp_out && g_out, "bjx_target_neal_funnel: bad arguments");
   hipLaunchKernelGGL(k_neal_funnel, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, D, q, logp_out, g_out);
   return bjx_check_launch("bjx_target_neal_funnel");
@@ -134,8 +135,9 @@ int bjx_target_neal_funnel(void* stream, int64_t N, int64_t D, const float* q, f
 
 int bjx_target_ar1_gaussian(void* stream, int64_t N, int64_t D, float diag_edge, float diag_mid,
                             float off, const float* q, float* logp_out, float* g_out) {
-  BJX_CHECK_ARG(N >= 0 && D >= 2 && q && logp_out && g_out, "bjx_target_ar1_gaussian: bad arguments");
+  BJX_CHECK_ARG(N >= 0 && D >= 2, "bjx_target_ar1_gaussian: bad arguments");
   if (N == 0) return 0;
+  BJX_CHECK_ARG(q && logp_out && g_out, "bjx_target_ar1_gaussian: bad arguments");
   hipLaunchKernelGGL(k_ar1_gaussian, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, D, diag_edge, diag_mid, off, q, logp_out, g_out);
   return bjx_check_launch("bjx_target_ar1_gaussian");

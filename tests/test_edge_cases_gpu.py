@@ -1,0 +1,84 @@
+"""Edge cases at the boundary: empty batches, zero-length trajectories, one-dimensional targets,
+automatic chain blocking."""
+import numpy as np
+import pytest
+import torch
+
+import blackjax_amd as bjx
+from blackjax_amd.hmc import auto_chain_block
+from oracle import hmc as ohmc
+from oracle import prng, targets as otargets
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def dev_t(a, dev):
+    return torch.as_tensor(np.asarray(a), device=dev)
+
+
+def test_empty_batch_everywhere(dev):
+    D = 12
+    inv_var = torch.ones(D, device=dev)
+    fn = bjx.targets.DiagGaussian(inv_var)
+    q0 = torch.empty(0, D, device=dev)
+    for L in (0, 3):
+        alg = bjx.hmc(fn, 0.1, torch.ones(D, device=dev), L)
+        st = alg.init(q0)
+        st2, info = alg.step(prng.key(0), st)
+        assert st2.position.shape == (0, D) and info.acceptance_rate.shape == (0,)
+        assert info.proposal.position.shape == (0, D)
+    dh = bjx.dynamic_hmc(fn, 0.1, torch.ones(D, device=dev))
+    st = dh.init(q0, prng.key(1))
+    assert st.random_generator_arg.shape == (0, 2)
+
+
+@pytest.mark.parametrize("N,D", [(9, 1), (5, 3)])
+def test_zero_length_trajectory_and_tiny_dims(dev, N, D):
+    """L = 0: the proposal is the initial state, delta = 0, always accepted (trajectory.py:155-165
+    with an empty loop); D = 1 exercises the scalar (non-float4) path end to end."""
+    inv_var = np.linspace(0.5, 2.0, D).astype(f32)
+    fn_o, fn_g = otargets.diag_gaussian(inv_var), bjx.targets.DiagGaussian(dev_t(inv_var, dev))
+    q0 = prng.normal(prng.key(2), (N, D))
+    imm = np.linspace(1.0, 3.0, D).astype(f32)
+    for L in (0, 1, 4):
+        st_o = ohmc.init(q0, fn_o)
+        alg = bjx.hmc(fn_g, 0.3, dev_t(imm, dev), L)
+        st_g = alg.init(dev_t(q0, dev))
+        for k in prng.split(prng.key(5), 3):
+            st_o, info_o = ohmc.kernel(k, st_o, fn_o, f32(0.3), imm, L)
+            st_g, info_g = alg.step(k, st_g)
+            assert np.array_equal(t2n(info_g.is_accepted), info_o.is_accepted)
+            assert np.array_equal(t2n(st_g.position), st_o.position)
+            np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-5, atol=1e-7)
+            assert np.array_equal(t2n(info_g.momentum), info_o.momentum)
+        if L == 0:
+            assert bool(info_g.is_accepted.all()) and float(info_g.acceptance_rate.min()) == 1.0
+
+
+def test_auto_chain_block(dev):
+    assert auto_chain_block(65536, 1024) == 16384
+    assert auto_chain_block(32768, 4096) == 4096
+    assert auto_chain_block(65536, 256) == 65536  # the whole batch fits: one block
+    assert auto_chain_block(1000, 1024) == 1000
+    assert auto_chain_block(100000, 3) == 100000
+    # blocked == unblocked bit for bit, ragged last block (40 000 = 2 x 16 384 + 7 232)
+    N, D, L = 40000, 1024, 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    fn = bjx.targets.DiagGaussian(torch.ones(D, device=dev))
+    imm = torch.ones(D, device=dev)
+    a = bjx.hmc(fn, 0.05, imm, L)
+    b = bjx.hmc(fn, 0.05, imm, L, chain_block="auto")
+    sa, sb = a.init(q0), b.init(q0)
+    for k in prng.split(prng.key(8), 2):
+        sa, ia = a.step(k, sa)
+        sb, ib = b.step(k, sb)
+    assert torch.equal(sa.position, sb.position) and torch.equal(ia.is_accepted, ib.is_accepted)
+    assert torch.equal(ia.proposal.position, ib.proposal.position)
+    assert torch.equal(ia.energy, ib.energy)
