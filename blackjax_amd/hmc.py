@@ -150,9 +150,9 @@ def _default_chain_block():
     import os
 
     v = os.environ.get("BJX_CHAIN_BLOCK", "")
-    if v == "auto":
+    if v in ("", "auto"):
         return "auto"
-    return int(v) if v else None
+    return int(v)  # 0 = all chains in one launch
 
 
 # MI355X: 256 MiB Infinity Cache in front of HBM.  A chain block whose q, p and g (3 arrays) take
@@ -160,11 +160,12 @@ def _default_chain_block():
 _IC_WORKING_SET_BYTES = 192 << 20
 
 
-def auto_chain_block(n_chains: int, dim: int) -> int:
+def auto_chain_block(n_chains: int, dim: int, arrays: int = 3) -> int:
     """Chains per block for ``chain_block="auto"``: the largest multiple of 1024 chains whose
-    q/p/g working set (12 bytes per element) fits the Infinity-Cache budget; all chains at once when
-    the whole batch fits or the blocks would be too small to amortise a launch."""
-    blk = (_IC_WORKING_SET_BYTES // (12 * max(int(dim), 1))) // 1024 * 1024
+    working set (``arrays`` fp32 arrays per element: q, p, g, plus a per-chain inverse mass matrix
+    when there is one) fits the Infinity-Cache budget; all chains at once when the whole batch fits
+    or the blocks would be too small to amortise a launch."""
+    blk = (_IC_WORKING_SET_BYTES // (4 * int(arrays) * max(int(dim), 1))) // 1024 * 1024
     if blk < 1024 or blk >= n_chains:
         return int(n_chains)
     return int(blk)
@@ -283,7 +284,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         is_acc = torch.empty(N, dtype=torch.bool, device=dev)
         is_div = torch.empty(N, dtype=torch.bool, device=dev)
 
-        cb = auto_chain_block(N, D) if chain_block == "auto" else chain_block
+        cb = chain_block
+        if cb == "auto":  # Infinity-Cache tiling pays for the streaming (diagonal) kernels only
+            cb = (auto_chain_block(N, D, 3 + (1 if metric.imm_stride else 0))
+                  if metric.kind == "diag" else N)
         blk = N if not cb or cb >= N else int(cb)
         n_blocks = (N + blk - 1) // blk if N else 0
         single = n_blocks <= 1 and not graphed
