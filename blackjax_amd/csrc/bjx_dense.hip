@@ -39,6 +39,8 @@ struct GemmArgs {
   float* C;              // EPI_STORE: (M, D) output
   const float* Q_in;     // EPI_DRIFT: q_out = fma(eps, C, Q_in)
   float* Q_out;
+  bool b_symmetric = false;  // B is the inverse mass matrix: B[k][n] and B[n][k] are interchangeable,
+                             // so complete aligned tiles may take the k-contiguous "TN" kernel
 };
 
 // FULL: M % BM == 0 and D % BN == 0 (hence D % BK == 0): every tile is complete, no bounds checks.
@@ -279,6 +281,171 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// "TN" variant for complete, 16-byte-aligned tiles: C[m][n] = sum_k A'[m][k] * Bt[n][k] with Bt the
+// (Nn x K) row-major matrix -- for v = M^{-1} p that is the inverse mass matrix exactly as the
+// reference stores it (linear_map(imm, p) = imm @ p, util.py:58-61), no symmetry assumed.
+//
+// Both operands have k contiguous in memory, so both tiles are staged ROW-major in LDS
+// ([rows][BK], row stride LDK = 20 floats) with 16-byte stores, and an MFMA step u pairs
+// k = u (lanes 0-31) with k = 8 + u (lanes 32-63): the 8 operands a lane needs for a whole K-tile
+// are 8 consecutive floats of one LDS row = two ds_read_b128 per 32-row operand half (conflict
+// free at stride 20) instead of eight ds_read_b32.  Per K-tile and wave: 8 LDS reads feed 32 MFMAs.
+constexpr int LDK = BK + 4;
+
+template <int EPI, int KICKS>
+__global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
+  static_assert(2 * BM * LDK + 2 * BN * LDK >= 4 * 32 * 64, "epilogue staging needs 32 KiB");
+  static_assert(BK == 16, "the k pairing below assumes two 8-wide halves");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t n_col = a.D / BN, n_row = a.M / BM;
+  const int64_t lin = blockIdx.x;
+  int64_t row_blk, col_blk;
+  {  // XCD-aware tile order, as in k_dense_gemm
+    const int64_t full = (n_row / 8) * 8 * n_col;
+    if (lin < full) {
+      const int64_t xcd = lin % 8, slot = lin / 8;
+      col_blk = slot % n_col;
+      row_blk = (slot / n_col) * 8 + xcd;
+    } else {
+      const int64_t r = lin - full;
+      row_blk = (n_row / 8) * 8 + r / n_col;
+      col_blk = r % n_col;
+    }
+  }
+  const int64_t row0 = row_blk * BM, col0 = col_blk * BN, D = a.D;
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BM * LDK;
+
+  // staging: thread -> (tile row tid/2, 8 consecutive k starting at (tid&1)*8) of A and of Bt
+  const int s_row = tid >> 1, s_k = (tid & 1) * 8;
+  const float* a_src = a.A + (row0 + s_row) * D + s_k;
+  const float* g_src = KICKS > 0 ? a.G + (row0 + s_row) * D + s_k : nullptr;
+  const float* b_src = a.B + (col0 + s_row) * D + s_k;
+  float* a_out = (KICKS > 0 && a.A_out && col_blk == 0) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
+  float h = 0.0f;
+  if (KICKS > 0) h = (a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps) * 0.5f;
+  // Software pipeline over K-tiles with two register sets (loop unrolled by two so the set index
+  // is static).  In iteration t, in program order:
+  //   LDS operand reads of tile t, first half of its MFMAs           (matrix pipe now busy)
+  //   staging of tile t+1 from set (t+1)&1: kick, A_out store, LDS store   (in the MFMA shadow;
+  //       its global loads were issued one iteration ago)
+  //   issue the global loads of tile t+2 into set t&1 (whose A_out store is one iteration old)
+  //   second half of the MFMAs, workgroup barrier
+  // Loads and stores share one in-order counter that the compiler must drain completely once
+  // stores are in flight, so the loads are issued AFTER the stores of the same iteration and the
+  // only full drain sits where everything outstanding is a full iteration old.
+  struct Regs {
+    F4 a[2], g[2], b[2];
+  };
+  Regs R0, R1;
+  auto load_tiles = [&](Regs& r, int64_t k0) {
+    r.a[0] = ld4(a_src + k0); r.a[1] = ld4(a_src + k0 + 4);
+    if constexpr (KICKS > 0) { r.g[0] = ld4(g_src + k0); r.g[1] = ld4(g_src + k0 + 4); }
+    r.b[0] = ld4(b_src + k0); r.b[1] = ld4(b_src + k0 + 4);
+  };
+  auto kick = [&](F4& x, const F4& g) {
+    x.x = fmaf(h, g.x, x.x); x.y = fmaf(h, g.y, x.y); x.z = fmaf(h, g.z, x.z); x.w = fmaf(h, g.w, x.w);
+  };
+  auto store_tiles = [&](Regs& r, int buf, int64_t k0) {
+    if constexpr (KICKS > 0) {
+      kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]);
+      if constexpr (KICKS == 2) { kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]); }
+      if (a_out) { st4(a_out + k0, r.a[0]); st4(a_out + k0 + 4, r.a[1]); }
+    }
+    float* as = As0 + buf * BM * LDK + s_row * LDK + s_k;
+    float* bs = Bs0 + buf * BN * LDK + s_row * LDK + s_k;
+    st4(as, r.a[0]); st4(as + 4, r.a[1]);
+    st4(bs, r.b[0]); st4(bs + 4, r.b[1]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
+  load_tiles(R0, 0);
+  load_tiles(R1, BK);
+  store_tiles(R0, 0, 0);
+  __syncthreads();
+  const int lm = lane & 31, lk = lane >> 5;
+  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
+  const int b_off = (wn * 64 + lm) * LDK + lk * 8;
+  auto mfma4 = [&](float x0, float x1, float y0, float y1) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+  };
+  // tile t: `stage` holds tile t+1 (in flight), `refill` is the set whose contents (tile t) are
+  // already in LDS and which receives tile t+2
+  auto tile = [&](int64_t t, Regs& stage, Regs& refill) {
+    const int buf = (int)(t & 1);
+    const float* as = As0 + buf * BM * LDK + a_off;
+    const float* bs = Bs0 + buf * BN * LDK + b_off;
+    float fa0[8], fa1[8], fb0[8], fb1[8];
+    *reinterpret_cast<F4*>(fa0) = ld4(as);                 *reinterpret_cast<F4*>(fa0 + 4) = ld4(as + 4);
+    *reinterpret_cast<F4*>(fb0) = ld4(bs);                 *reinterpret_cast<F4*>(fb0 + 4) = ld4(bs + 4);
+    *reinterpret_cast<F4*>(fa1) = ld4(as + 32 * LDK);      *reinterpret_cast<F4*>(fa1 + 4) = ld4(as + 32 * LDK + 4);
+    *reinterpret_cast<F4*>(fb1) = ld4(bs + 32 * LDK);      *reinterpret_cast<F4*>(fb1 + 4) = ld4(bs + 32 * LDK + 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mfma4(fa0[u], fa1[u], fb0[u], fb1[u]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the staging work here, behind 16 queued MFMAs
+    if (t + 1 < n_tiles) store_tiles(stage, buf ^ 1, (t + 1) * BK);
+    if (t + 2 < n_tiles) load_tiles(refill, (t + 2) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 4; u < 8; ++u) mfma4(fa0[u], fa1[u], fb0[u], fb1[u]);
+    __syncthreads();
+  };
+  for (int64_t t = 0; t < n_tiles; t += 2) {
+    tile(t, R1, R0);
+    tile(t + 1, R0, R1);
+  }
+
+  // epilogue: identical to the ALIGNED && FULL path of k_dense_gemm (LDS transpose, 16-byte rows)
+  float* stage = smem + wave * (32 * 64);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(bq * 8 + lk * 4 + r) * 64 + j * 32 + lm] = acc[i][j][bq * 4 + r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int c4 = (lane & 15) * 4;
+    const int64_t col = col0 + wn * 64 + c4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = (lane >> 4) + 4 * it;
+      const int64_t row = row0 + wm * 64 + i * 32 + rl;
+      const F4 c = *reinterpret_cast<const F4*>(stage + rl * 64 + c4);
+      if constexpr (EPI == EPI_STORE) {
+        st4(a.C + row * D + col, c);
+      } else {
+        const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
+        const F4 q = ld4(a.Q_in + row * D + col);
+        st4(a.Q_out + row * D + col,
+            F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
 __device__ __forceinline__ int64_t wave_row0() {
@@ -485,6 +652,17 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B, ga.C, ga.Q_in, ga.Q_out);
   const bool full = (ga.M % BM == 0) && (ga.D % BN == 0);
+  if (ga.b_symmetric && aligned && full) {
+#define BJX_LAUNCH_TN(E, K) hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga)
+    const int kicks = ga.G ? ga.n_kicks : 0;
+    if (epi == EPI_STORE) {
+      if (kicks == 0) BJX_LAUNCH_TN(EPI_STORE, 0); else if (kicks == 1) BJX_LAUNCH_TN(EPI_STORE, 1); else BJX_LAUNCH_TN(EPI_STORE, 2);
+    } else {
+      if (kicks == 0) BJX_LAUNCH_TN(EPI_DRIFT, 0); else if (kicks == 1) BJX_LAUNCH_TN(EPI_DRIFT, 1); else BJX_LAUNCH_TN(EPI_DRIFT, 2);
+    }
+#undef BJX_LAUNCH_TN
+    return bjx_check_launch("bjx_dense gemm (tn)");
+  }
   if (epi == EPI_STORE) {
     if (aligned && full) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true, true>), grid, dim3(kThreads), 0, s, ga);
     else if (aligned) hipLaunchKernelGGL((k_dense_gemm<EPI_STORE, true, false>), grid, dim3(kThreads), 0, s, ga);
@@ -523,6 +701,7 @@ int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t c
   GemmArgs g1{N, D, z_work, nullptr, 0, 0.0f, nullptr, nullptr, mass_sqrt_t, p_out, nullptr, nullptr};
   if (int rc = launch_gemm(s, EPI_STORE, g1)) return rc;  // p = L^{-T} z   (metrics.py:260-261)
   GemmArgs g2{N, D, p_out, nullptr, 0, 0.0f, nullptr, nullptr, imm, v_work, nullptr, nullptr};
+  g2.b_symmetric = true;
   if (int rc = launch_gemm(s, EPI_STORE, g2)) return rc;  // v = imm p
   hipLaunchKernelGGL(k_rowdot_half, rgrid, rblock, 0, s, N, D, v_work, p_out, ke_out);
   return bjx_check_launch("bjx_hmc_momentum_dense(ke)");
@@ -537,6 +716,7 @@ int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float ep
   BJX_CHECK_ARG(p_out != p_in, "bjx_leapfrog_dense: p_out must not alias p_in");
   if (N == 0) return 0;
   GemmArgs ga{N, D, p_in, g, n_kicks, eps, eps_per_chain, p_out, imm, nullptr, q_in, q_out};
+  ga.b_symmetric = true;
   return launch_gemm((hipStream_t)stream, EPI_DRIFT, ga);
 }
 
@@ -557,6 +737,7 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
   hipStream_t s = (hipStream_t)stream;
   // closing half kick fused into the GEMM prologue: p1 = p + (eps/2) g1 ; v1 = imm p1
   GemmArgs ga{N, D, p, g1, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+  ga.b_symmetric = true;
   if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
   hipLaunchKernelGGL(k_hmc_finish_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
                      Key{key0, key1}, chain_offset, step_fold, N, D, divergence_threshold, q0, logp0,

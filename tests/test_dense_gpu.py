@@ -63,9 +63,10 @@ def test_reference_golden_velocity_verlet_through_dense_kernels(dev):
     np.testing.assert_allclose(t2n(p)[0], k["p_final"], atol=k["atol"])
 
 
-@pytest.mark.parametrize("N,D,L", [(100, 64, 8), (37, 30, 5)])
+@pytest.mark.parametrize("N,D,L", [(100, 64, 8), (37, 30, 5), (256, 128, 4), (128, 256, 3)])
 def test_dense_hmc_vs_oracle(dev, N, D, L):
-    """Scaled-down configs[4]: AR(1) correlated Gaussian, dense imm = Sigma."""
+    """Scaled-down configs[4]: AR(1) correlated Gaussian, dense imm = Sigma.  N and D multiples of
+    128 take the k-contiguous ("TN") GEMM kernel, the others the general one."""
     rho = 0.9
     fn_o = otargets.ar1_gaussian(rho, D)
     cov = otargets.ar1_covariance(rho, D)
