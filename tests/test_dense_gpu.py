@@ -218,3 +218,48 @@ def test_dense_window_adaptation_vs_oracle(dev):
     alg = bjx.hmc(bjx.targets.AR1Gaussian(rho, D), par_g["step_size"], par_g["inverse_mass_matrix"], L)
     st, inf = alg.step(bjx.random.key(1), st_g)
     assert torch.isfinite(st.position).all() and inf.acceptance_rate.mean() > 0.3
+
+
+def test_dense_full_size_properties(dev):
+    """configs[4] at full size (16 384 x 512, AR(1) covariance as the dense inverse mass matrix):
+    the MFMA leapfrog kernel against an fp64 torch evaluation on the whole batch, time reversibility
+    of L velocity-Verlet steps and conservation of the Hamiltonian -- size-independent properties."""
+    N, D, L, eps = 16384, 512, 8, 0.3
+    rho = 0.9
+    cov = torch.as_tensor(otargets.ar1_covariance(rho, D), device=dev)
+    tgt = bjx.targets.AR1Gaussian(rho, D)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    p0 = torch.randn(N, D, device=dev, generator=g) * 0.7
+    logp0, g0 = tgt(q0)
+    s = _lib.current_stream()
+
+    # one fused kick + GEMM + drift launch vs fp64
+    q1, p1 = torch.empty_like(q0), torch.empty_like(p0)
+    _lib.call("bjx_leapfrog_dense", s, N, D, 1, eps, None, cov.data_ptr(), q0.data_ptr(), p0.data_ptr(),
+              g0.data_ptr(), q1.data_ptr(), p1.data_ptr())
+    p_ref = p0.double() + 0.5 * eps * g0.double()
+    q_ref = q0.double() + eps * (p_ref @ cov.double().T)
+    assert torch.equal(p1, torch.addcmul(p0, g0, torch.tensor(0.5 * eps, device=dev)).float()) or \
+        (p1.double() - p_ref).abs().max().item() < 1e-6
+    assert (q1.double() - q_ref).abs().max().item() < 2e-5 * q_ref.abs().max().item()
+
+    def integrate(q, p, grad, steps):
+        for i in range(steps):
+            qn, pn = torch.empty_like(q), torch.empty_like(p)
+            _lib.call("bjx_leapfrog_dense", s, N, D, 1 if i == 0 else 2, eps, None, cov.data_ptr(),
+                      q.data_ptr(), p.data_ptr(), grad.data_ptr(), qn.data_ptr(), pn.data_ptr())
+            q, p = qn, pn
+            logp, grad = tgt(q)
+        return q, p + (0.5 * eps) * grad, logp, grad
+
+    def energy(logp, p):
+        return -logp.double() + 0.5 * ((p.double() @ cov.double().T) * p.double()).sum(-1)
+
+    qa, pa, logpa, ga = integrate(q0, p0, g0, L)
+    h0, h1 = energy(logp0, p0), energy(logpa, pa)
+    assert ((h1 - h0).abs() / h0.abs()).max().item() < 2e-2
+    qb, pb, _, _ = integrate(qa, -pa, ga, L)
+    assert (qb - q0).abs().max().item() < 5e-4
+    assert (pb + p0).abs().max().item() < 5e-4
