@@ -126,6 +126,25 @@ SIGNATURES.update({
     "bjx_nuts_merge": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p],
 })
 
+
+class NutsAsync(ctypes.Structure):
+    """ctypes mirror of ``bjx_nuts_async_t`` (include/bjx_nuts.h): free-running chains."""
+
+    _fields_ = [
+        ("step_keys", c_void_p), ("t_first", ctypes.c_int32), ("n_steps", ctypes.c_int32),
+        ("q", c_void_p), ("g", c_void_p), ("logp", c_void_p), ("p", c_void_p),
+        ("t", c_void_p), ("phase", c_void_p), ("n_done", c_void_p),
+        ("out_position", c_void_p), ("out_logdensity", c_void_p), ("out_acceptance_rate", c_void_p),
+        ("out_energy", c_void_p), ("out_num_integration_steps", c_void_p),
+        ("out_num_trajectory_expansions", c_void_p), ("out_is_divergent", c_void_p),
+        ("out_is_turning", c_void_p),
+    ]
+
+
+SIGNATURES.update({
+    "bjx_nuts_async_tick": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), _f32p, _f32p, _f32p],
+})
+
 # include/bjx_pool.h (pooled cross-chain statistics; bjx_pool_workspace_bytes returns int64, see load())
 _f64p = c_void_p
 SIGNATURES.update({

@@ -134,10 +134,11 @@ __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, 
 }
 
 // ------------------------------------------------------------------------------------ init
-__global__ void __launch_bounds__(kBlock)
-k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restrict__ ke0) {
+// Tree state of chain c at the start of a transition (nuts.py:278-291): both ends and the proposal
+// are the current state, momentum_sum = p0, num_states = 0.  lp = logdensity, ke = K(p0).
+__device__ __forceinline__ void nuts_init_chain(const bjx_nuts_t& nt, int64_t c, float lp, float ke) {
   const int lane = threadIdx.x & 63;
-  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) {
+  {
     const int64_t base = c * nt.D;
     for (int64_t j = lane; j < nt.D; j += 64) {
       const float q = nt.q0[base + j], p = nt.p0[base + j], g = nt.g0[base + j];
@@ -150,8 +151,7 @@ k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restr
       }
     }
     if (lane == 0) {
-      const float lp = logp0[c];
-      const float H0 = -lp + ke0[c];
+      const float H0 = -lp + ke;
       FS(BJX_NUTS_F_H0, c) = H0;
       FS(BJX_NUTS_F_LLOGP, c) = lp;
       FS(BJX_NUTS_F_RLOGP, c) = lp;
@@ -178,11 +178,33 @@ k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restr
   }
 }
 
+__global__ void __launch_bounds__(kBlock)
+k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restrict__ ke0) {
+  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) nuts_init_chain(nt, c, logp0[c], ke0[c]);
+}
+
+// Start of doubling `depth` for chain c: draw the direction and reset the subtree flags
+// (trajectory.py:645-650).  Returns the direction (+1 / -1).
+__device__ __forceinline__ int nuts_begin_doubling(const bjx_nuts_t& nt, const StepCtx& cx, int64_t c,
+                                                   int32_t depth) {
+  const int lane = threadIdx.x & 63;
+  const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);  // trajectory.py:645
+  const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
+  const int dir = key_uniform(kd) < 0.5f ? 1 : -1;                        // trajectory.py:650
+  if (lane == 0) {
+    IS(BJX_NUTS_I_DIR, c) = dir;
+    IS(BJX_NUTS_I_SUB_ACTIVE, c) = 1;
+    IS(BJX_NUTS_I_SDIV, c) = 0;
+    IS(BJX_NUTS_I_STURN, c) = 0;
+    IS(BJX_NUTS_I_SUBN, c) = 0;
+  }
+  return dir;
+}
+
 // ------------------------------------------------------------------------------------ pre
 __global__ void __launch_bounds__(kBlock)
 k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* __restrict__ qf) {
-  const int lane = threadIdx.x & 63;
   const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
   const int32_t depth = cx.depth, s = cx.s;
   const int64_t n_rows = cx.n_rows;
@@ -191,16 +213,7 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
     int dir;
     if (s == 0) {
-      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);  // trajectory.py:645
-      const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
-      dir = key_uniform(kd) < 0.5f ? 1 : -1;                                  // trajectory.py:650
-      if (lane == 0) {
-        IS(BJX_NUTS_I_DIR, c) = dir;
-        IS(BJX_NUTS_I_SUB_ACTIVE, c) = 1;
-        IS(BJX_NUTS_I_SDIV, c) = 0;
-        IS(BJX_NUTS_I_STURN, c) = 0;
-        IS(BJX_NUTS_I_SUBN, c) = 0;
-      }
+      dir = nuts_begin_doubling(nt, cx, c, depth);
     } else {
       if (!IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
       dir = IS(BJX_NUTS_I_DIR, c);
@@ -213,17 +226,17 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 }
 
 // ------------------------------------------------------------------------------------ post
-__global__ void __launch_bounds__(kBlock)
-k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
-            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* qf,
-            const float* __restrict__ logp_f, const float* __restrict__ gf, int fuse_next) {
+// Second half of leaf s of doubling `depth` for chain c, whose new position / log-density /
+// gradient sit in row b of (qf, logp_f, gf): closing kick, energy, progressive sampling,
+// momentum-sum append, checkpoint store, iterative U-turn (trajectory.py:242-395,
+// termination.py:31-106).  With fuse_next the opening half of leaf s+1 follows when the subtree
+// keeps integrating.  Returns true when the subtree stops (divergence or U-turn).
+__device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const StepCtx& cx, int64_t c,
+                                                int64_t b, int32_t depth, int32_t s, float* qf,
+                                                const float* __restrict__ logp_f,
+                                                const float* __restrict__ gf, bool fuse_next) {
   const int lane = threadIdx.x & 63;
-  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
-  const int32_t depth = cx.depth, s = cx.s;
-  const int64_t n_rows = cx.n_rows;
-  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
-    const int64_t c = idx ? (int64_t)idx[b] : b;
-    if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+  {
     const int dir = IS(BJX_NUTS_I_DIR, c);
     const float deps = (float)dir * chain_eps(nt, c);
     const float h = deps * 0.5f;
@@ -355,16 +368,32 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
     // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
     if (fuse_next && !(sdiv || turning)) nuts_open_half(nt, c, dir, deps, h, gn, qn);
+    return sdiv || turning;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
+            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* qf,
+            const float* __restrict__ logp_f, const float* __restrict__ gf, int fuse_next) {
+  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
+  const int32_t depth = cx.depth, s = cx.s;
+  const int64_t n_rows = cx.n_rows;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+    nuts_post_chain(nt, cx, c, b, depth, s, qf, logp_f, gf, fuse_next != 0);
   }
 }
 
 // ------------------------------------------------------------------------------------ merge
-__global__ void __launch_bounds__(kBlock)
-k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __restrict__ idx) {
+// End of doubling `depth` for chain c: biased progressive sampling of the new subtree's proposal,
+// momentum-sum merge, U-turn of the whole trajectory, stop flags (trajectory.py:680-727,
+// proposal.py:146-176, nuts.py:303-305).  Returns true when the tree keeps growing.
+__device__ __forceinline__ bool nuts_merge_chain(const bjx_nuts_t& nt, const StepCtx& kcx, int64_t c,
+                                                 int32_t depth) {
   const int lane = threadIdx.x & 63;
-  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
-    const int64_t c = idx ? (int64_t)idx[b] : b;
-    if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
+  {
     const bool sdiv = IS(BJX_NUTS_I_SDIV, c) != 0, sturn = IS(BJX_NUTS_I_STURN, c) != 0;
     const int64_t base = c * nt.D;
     const float pw = FS(BJX_NUTS_F_PW, c), sw = FS(BJX_NUTS_F_SW, c);
@@ -373,8 +402,7 @@ k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __rest
     float new_pw = pw;
     const float new_pslpa = logaddexp_cr(pslpa, sslpa);
     if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
-      const StepCtx cx{depth, 0, n_rows, Key{nt.key0, nt.key1}, nt.chain_offset, nt.step_fold};
-      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
+      const Key subkey = key_child(integrator_key(kcx, c), (uint64_t)depth);
       const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
       const float pa = min1_nan(exp_cr(sw - pw));
       take = key_uniform(kp) < pa;
@@ -415,6 +443,122 @@ k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __rest
       IS(BJX_NUTS_I_DEPTH, c) = depth + 1;
       IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
       IS(BJX_NUTS_I_ACTIVE, c) = (!sdiv && !turn && depth + 1 < nt.max_depth) ? 1 : 0;
+    }
+    return !sdiv && !turn && depth + 1 < nt.max_depth;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __restrict__ idx) {
+  const StepCtx kcx{depth, 0, n_rows, Key{nt.key0, nt.key1}, nt.chain_offset, nt.step_fold};
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
+    nuts_merge_chain(nt, kcx, c, depth);
+  }
+}
+
+// ------------------------------------------------------------------------------------ free-running chains
+// One tick of the asynchronous schedule (include/bjx_nuts.h): every chain that is not finished
+// ends the tick with the opening half of a leapfrog done and its new position in qf[c].
+//   phase 1: post(leaf) [-> fused pre(next leaf)] | [-> merge [-> begin next doubling + pre]
+//            | -> record transition, accept proposal as the new state -> phase 0]
+//   phase 0: momentum draw, tree init, begin doubling 0, pre
+// All per-chain decisions are wave-uniform; scalars written by lane 0 and read by the whole wave
+// later in the same kernel are separated by a workgroup-scope fence (one CU, one L1).
+__device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, int32_t t) {
+  StepCtx cx;
+  cx.depth = 0;
+  cx.s = 0;
+  cx.n_rows = nt.N;
+  cx.off = nt.chain_offset;
+  if (ax.step_keys) {
+    cx.key = Key{ax.step_keys[2 * (int64_t)t], ax.step_keys[2 * (int64_t)t + 1]};
+    cx.fold = -1;
+  } else {
+    cx.key = Key{nt.key0, nt.key1};
+    cx.fold = (int64_t)ax.t_first + t;
+  }
+  return cx;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nuts_async_tick(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                  const float* __restrict__ gf) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) {
+    int phase = ax.phase[c];
+    if (phase == 2) continue;
+    int32_t t = ax.t[c];
+    StepCtx cx = async_ctx(nt, ax, t);
+    const int64_t base = c * nt.D;
+    if (phase == 1) {
+      const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
+      const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
+      const bool last = (s + 1) >= (1 << depth);
+      const bool stop = nuts_post_chain(nt, cx, c, c, depth, s, qf, logp_f, gf, !last);
+      if (!stop && !last) continue;  // the fused opening half of leaf s+1 is done
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const bool grow = nuts_merge_chain(nt, cx, c, depth);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (grow) {
+        const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
+        const float deps = (float)dir * chain_eps(nt, c);
+        nuts_open_half(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base, qf + base);
+        continue;
+      }
+      // transition t is complete: record it and make the proposal the chain's state
+      const int64_t row = (int64_t)t * nt.N + c;
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float q = nt.Pq[base + j];
+        ax.q[base + j] = q;
+        ax.g[base + j] = nt.Pg[base + j];
+        if (ax.out_position) ax.out_position[row * nt.D + j] = q;
+      }
+      if (lane == 0) {
+        const float lp = FS(BJX_NUTS_F_PLOGP, c);
+        ax.logp[c] = lp;
+        if (ax.out_logdensity) ax.out_logdensity[row] = lp;
+        if (ax.out_acceptance_rate) ax.out_acceptance_rate[row] = FS(BJX_NUTS_F_ACC, c);
+        if (ax.out_energy) ax.out_energy[row] = FS(BJX_NUTS_F_PENERGY, c);
+        if (ax.out_num_integration_steps) ax.out_num_integration_steps[row] = IS(BJX_NUTS_I_NSTATES, c);
+        if (ax.out_num_trajectory_expansions) ax.out_num_trajectory_expansions[row] = IS(BJX_NUTS_I_DEPTH, c);
+        if (ax.out_is_divergent) ax.out_is_divergent[row] = (uint8_t)(IS(BJX_NUTS_I_DIV, c) != 0);
+        if (ax.out_is_turning) ax.out_is_turning[row] = (uint8_t)(IS(BJX_NUTS_I_TURN, c) != 0);
+      }
+      t += 1;
+      if (lane == 0) ax.t[c] = t;
+      if (t >= ax.n_steps) {
+        if (lane == 0) {
+          ax.phase[c] = 2;
+          atomicAdd(ax.n_done, 1);
+        }
+        continue;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      cx = async_ctx(nt, ax, t);
+    }
+    // phase 0: start transition t -- momentum draw (hmc.py:299-302, metrics.py:260-270) with the
+    // lane <-> element mapping of nuts_init_chain, then the tree of nuts.py:278-294
+    {
+      const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
+      const Key km = key_child(kc, 0);  // split(kc, 2)[0]
+      const float* im = nt.imm + c * nt.imm_stride;
+      double acc = 0.0;
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)j));
+        const float ms = 1.0f / sqrtf(im[j]);
+        const float pv = ms * z;
+        ax.p[base + j] = pv;
+        acc += (double)(im[j] * pv) * (double)pv;
+      }
+      acc = wave_sum(acc);
+      nuts_init_chain(nt, c, ax.logp[c], 0.5f * (float)acc);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const int dir = nuts_begin_doubling(nt, cx, c, 0);
+      const float deps = (float)dir * chain_eps(nt, c);
+      nuts_open_half(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base, qf + base);
+      if (lane == 0 && phase != 1) ax.phase[c] = 1;
     }
   }
 }
@@ -573,6 +717,23 @@ int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t 
   hipLaunchKernelGGL(k_nuts_merge, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, *nuts, depth, n_rows, idx);
   return bjx_check_launch("bjx_nuts_merge");
+}
+
+int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run, float* qf,
+                        const float* logp_f, const float* gf) {
+  if (check_nuts(nuts, "bjx_nuts_async_tick")) return 1;
+  BJX_CHECK_ARG(run && qf && logp_f && gf, "bjx_nuts_async_tick: null argument");
+  BJX_CHECK_ARG(!nuts->Mdense, "bjx_nuts_async_tick: free-running chains support the diagonal metric only");
+  BJX_CHECK_ARG(nuts->max_depth >= 1, "bjx_nuts_async_tick: max_depth must be >= 1");
+  BJX_CHECK_ARG(run->n_steps >= 0 && run->t_first >= 0 && run->q && run->g && run->logp && run->p &&
+                    run->t && run->phase && run->n_done,
+                "bjx_nuts_async_tick: bad run descriptor");
+  BJX_CHECK_ARG(run->q == nuts->q0 && run->g == nuts->g0 && run->p == nuts->p0,
+                "bjx_nuts_async_tick: run->q / g / p must alias nuts->q0 / g0 / p0");
+  if (nuts->N == 0 || run->n_steps == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_async_tick, dim3(bjx_row_grid(nuts->N, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, *run, qf, logp_f, gf);
+  return bjx_check_launch("bjx_nuts_async_tick");
 }
 
 }  // extern "C"

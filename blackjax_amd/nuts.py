@@ -33,7 +33,7 @@ from .base import SamplingAlgorithm
 from .hmc import HMCState, IntegratorState, init
 from .random import key_spec
 
-__all__ = ["NUTSInfo", "init", "build_kernel", "as_top_level_api"]
+__all__ = ["NUTSInfo", "NUTSRunInfo", "init", "build_kernel", "run_free", "as_top_level_api"]
 
 _BUFS = ["Lq", "Lp", "Lg", "Rq", "Rp", "Rg", "msum", "Smsum", "Pq", "Pg", "Sq", "Sg"]
 
@@ -311,12 +311,129 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     return kernel_graph if use_graph else kernel_eager
 
 
+class NUTSRunInfo(NamedTuple):
+    """Per-(transition, chain) records of a free-running run, each ``(num_steps, N)``: the scalar
+    fields of ``NUTSInfo`` plus the log-density of the accepted state."""
+
+    logdensity: torch.Tensor
+    acceptance_rate: torch.Tensor
+    energy: torch.Tensor
+    num_integration_steps: torch.Tensor
+    num_trajectory_expansions: torch.Tensor
+    is_divergent: torch.Tensor
+    is_turning: torch.Tensor
+
+
+def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
+             num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
+             chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
+             sync_every: int = 16):
+    """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
+    "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
+    a chain that completes a transition starts its next one at once, so the user callable always
+    sees N useful rows.  In a lockstep ``step`` a transition lasts as long as the deepest tree of
+    the whole ensemble (2^max_depth - 1 dependent leaves when a single chain goes deep); here the
+    run lasts as long as the chain with the largest TOTAL number of leapfrogs.
+
+    Chain ``c`` at transition ``t`` uses exactly the key ``step`` would give it
+    (``key_layout="step_major"``: ``split(split(rng_key, num_steps)[t], N)[c]``, the layout of
+    ``run_inference_algorithm``; ``"chain_major"``: ``split(split(rng_key, N)[c], num_steps)[t]``),
+    so the draws are identical to ``num_steps`` calls of ``step``.
+
+    Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
+    ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
+    import numpy as np
+
+    from . import random as bjx_random
+
+    q = check_batch(state.position, "state.position").clone()
+    logp = check_batch(state.logdensity, "state.logdensity").clone()
+    g = check_batch(state.logdensity_grad, "state.logdensity_grad").clone()
+    N, D = q.shape
+    dev = q.device
+    T = int(num_steps)
+    max_depth = int(max_num_doublings)
+    if max_depth < 1:
+        raise ValueError("free-running chains need max_num_doublings >= 1")
+    if key_layout not in ("step_major", "chain_major"):
+        raise ValueError("key_layout must be 'step_major' or 'chain_major'")
+    vg = value_and_grad(logdensity_fn)
+    metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+    if metric.kind != "diag":
+        raise NotImplementedError("free-running chains are implemented for diagonal metrics only")
+    eps, eps_pc = step_size_args(step_size, N, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    info = NUTSRunInfo(torch.empty((T, N), **f32), torch.empty((T, N), **f32), torch.empty((T, N), **f32),
+                       torch.empty((T, N), **i32), torch.empty((T, N), **i32),
+                       torch.empty((T, N), dtype=torch.bool, device=dev),
+                       torch.empty((T, N), dtype=torch.bool, device=dev))
+    positions = torch.empty((T, N, D), **f32) if store_positions else None
+    if T == 0 or N == 0:
+        return HMCState(q, logp, g), positions, info
+
+    if key_layout == "step_major":
+        keys = bjx_random.split(rng_key, T)
+        step_keys = torch.as_tensor(keys.view(np.int32), device=dev).contiguous()
+        k0 = k1 = 0
+    else:
+        step_keys = None
+        k0, k1 = bjx_random.key_words(rng_key)
+    bufs = {n: torch.empty_like(q) for n in _BUFS}
+    ck_r = torch.empty((N, max_depth, D), **f32)
+    ck_rs = torch.empty_like(ck_r)
+    fs = torch.empty((_lib.NUTS_NF, N), **f32)
+    is_ = torch.zeros((_lib.NUTS_NI, N), **i32)
+    p = torch.empty_like(q)
+    qf = torch.zeros_like(q)
+    t_done = torch.zeros(N, **i32)
+    phase = torch.zeros(N, **i32)
+    n_done = torch.zeros(1, **i32)
+    desc = _lib.NutsDesc(
+        N=N, D=D, max_depth=max_depth, reserved=0, imm=metric.imm.data_ptr(),
+        imm_stride=metric.imm_stride, eps_per_chain=_lib.ptr(eps_pc), eps=eps,
+        divergence_threshold=float(divergence_threshold), key0=k0, key1=k1,
+        chain_offset=int(chain_offset), step_fold=-1, q0=q.data_ptr(), g0=g.data_ptr(),
+        p0=p.data_ptr(), ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(),
+        is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()},
+        **_dense_fields("diag", None, N, D, max_depth, dev)["fields"])
+    run = _lib.NutsAsync(
+        step_keys=_lib.ptr(step_keys), t_first=0, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
+        logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
+        n_done=n_done.data_ptr(), out_position=_lib.ptr(positions),
+        out_logdensity=info.logdensity.data_ptr(), out_acceptance_rate=info.acceptance_rate.data_ptr(),
+        out_energy=info.energy.data_ptr(),
+        out_num_integration_steps=info.num_integration_steps.data_ptr(),
+        out_num_trajectory_expansions=info.num_trajectory_expansions.data_ptr(),
+        out_is_divergent=info.is_divergent.data_ptr(), out_is_turning=info.is_turning.data_ptr())
+    dref, rref = ctypes.byref(desc), ctypes.byref(run)
+    stream = _lib.current_stream()
+    logp_f = torch.zeros(N, **f32)  # the first tick only starts transitions: nothing reads these
+    gf = torch.zeros_like(q)
+    max_ticks = T * ((1 << max_depth) - 1) + 2
+    sync_every = max(1, int(sync_every))
+    for tick in range(max_ticks):
+        _lib.call("bjx_nuts_async_tick", stream, dref, rref, qf.data_ptr(), logp_f.data_ptr(),
+                  gf.data_ptr())
+        if tick % sync_every == sync_every - 1 and int(n_done.item()) == N:  # occasional host sync
+            break
+        logp_f, gf = eval_logdensity(vg, qf)
+    else:
+        if int(n_done.item()) != N:
+            raise RuntimeError("free-running NUTS did not finish within its tick bound")
+    return HMCState(q, logp, g), positions, info
+
+
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
                      recompact_every: int = 16, use_graph: bool = False,
                      graph_sync_every: int = 4) -> SamplingAlgorithm:
-    """blackjax/mcmc/nuts.py:150-220."""
+    """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
+    ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
+    ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
+    should be driven on this engine."""
+    integrators.check_supported(integrator)
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
                           use_graph=use_graph, graph_sync_every=graph_sync_every)
 
@@ -328,4 +445,11 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
         return kernel(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                       max_num_doublings, chain_offset=chain_offset)
 
-    return SamplingAlgorithm(init_fn, step_fn)
+    def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
+               store_positions: bool = True):
+        return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
+                        max_num_doublings, divergence_threshold=divergence_threshold,
+                        chain_offset=chain_offset, key_layout=key_layout,
+                        store_positions=store_positions)
+
+    return SamplingAlgorithm(init_fn, step_fn, run_fn)

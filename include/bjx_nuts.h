@@ -144,6 +144,48 @@ int bjx_nuts_set_ctl(void* stream, int64_t* ctl, int32_t depth, int64_t s_base, 
 int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t n_rows,
                    const int32_t* idx);
 
+/* ---- Free-running chains: many transitions per chain without lockstep ---------------------------
+ *
+ * A run of n_steps transitions (blackjax/util.py:150-213 run_inference_algorithm over
+ * nuts.step) in which every chain advances through ITS OWN sequence of trees: one "tick" =
+ * one leapfrog of whatever tree each chain is building; a chain that finishes a transition
+ * records it and starts the next one in the same tick.  Every tick therefore carries N useful
+ * leapfrogs (until chains run out of transitions) instead of the lockstep scheme's handful of
+ * stragglers in deep doublings; the number of ticks is max_c sum_t leaves(c, t) instead of
+ * sum_t max_c leaves(c, t).  Per-chain results are IDENTICAL to n_steps lockstep transitions:
+ * chain c at transition t uses the same key either way.
+ *
+ * The host loops   bjx_nuts_async_tick -> user callable on qf (all N rows) -> bjx_nuts_async_tick ...
+ * until *n_done == N.  Diagonal metric, max_depth >= 1. */
+typedef struct {
+  const uint32_t* step_keys;  /* (n_steps, 2) device table of the run's per-transition keys
+                                 (step-major layout: chain key = split(step_keys[t], N)[c]); NULL:
+                                 chain-major layout, transition t folds t_first + t into the chain key
+                                 derived from nuts->key0/key1 */
+  int32_t t_first, n_steps;
+  float *q, *g, *logp;        /* (N,D), (N,D), (N,): current chain state, in/out; q, g must be the
+                                 buffers nuts->q0 / nuts->g0 point to */
+  float* p;                   /* (N,D) momentum buffer; must be the buffer nuts->p0 points to */
+  int32_t* t;                 /* (N,) transitions completed per chain, in/out (start at 0) */
+  int32_t* phase;             /* (N,) 0 = start a transition, 1 = a leaf awaits its gradient, 2 = done */
+  int32_t* n_done;            /* device counter of chains that completed n_steps transitions */
+  /* per-(transition, chain) records, row-major (n_steps, N[, D]); any of them may be NULL */
+  float* out_position;
+  float* out_logdensity;
+  float* out_acceptance_rate;
+  float* out_energy;
+  int32_t* out_num_integration_steps;
+  int32_t* out_num_trajectory_expansions;
+  uint8_t* out_is_divergent;
+  uint8_t* out_is_turning;
+} bjx_nuts_async_t;
+
+/* One tick for all N chains.  logp_f (N,), gf (N,D): callable outputs at qf from the previous tick
+ * (ignored by chains in phase 0); qf (N,D): positions whose log-density / gradient the next tick
+ * needs (rows of finished chains are left untouched). */
+int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run, float* qf,
+                        const float* logp_f, const float* gf);
+
 #ifdef __cplusplus
 }
 #endif

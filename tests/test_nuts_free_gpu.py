@@ -1,0 +1,105 @@
+"""Free-running (asynchronous) NUTS chains (include/bjx_nuts.h, blackjax_amd.nuts.run_free): many
+transitions per chain without lockstep must reproduce, chain by chain and transition by transition,
+what the oracle's (and the engine's) lockstep transitions produce with the same keys."""
+import numpy as np
+import pytest
+import torch
+
+import blackjax_amd as bjx
+from oracle import hmc as ohmc
+from oracle import nuts as onuts
+from oracle import prng, targets as otargets
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-6
+f32 = np.float32
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def dev_t(a, dev):
+    return torch.as_tensor(np.asarray(a), device=dev)
+
+
+def _check_against_oracle(dev, fn_o, fn_g, q0, eps, imm, T, max_depth, key_layout, chain_offset=0):
+    N, D = q0.shape
+    run_key = prng.key(42)
+    alg = bjx.nuts(fn_g, dev_t(eps, dev) if np.ndim(eps) else float(eps),
+                   bjx.metrics.PerChainDiag(dev_t(imm, dev)) if np.ndim(imm) == 2 else dev_t(imm, dev),
+                   max_num_doublings=max_depth, chain_offset=chain_offset)
+    st_g0 = alg.init(dev_t(q0, dev))
+    final, positions, info = alg.run(run_key, st_g0, T, key_layout=key_layout)
+    assert positions.shape == (T, N, D)
+    st_o = ohmc.init(q0, fn_o)
+    depths = []
+    for t in range(T):
+        if key_layout == "step_major":
+            st_o, info_o = onuts.kernel(prng.split(run_key, T)[t], st_o, fn_o, eps, imm, max_depth,
+                                        chain_offset=chain_offset, per_chain_diag=np.ndim(imm) == 2)
+        else:
+            ck = prng.split(prng.split(run_key, N, offset=chain_offset), T)[:, t]
+            st_o, info_o = onuts.kernel(None, st_o, fn_o, eps, imm, max_depth, chain_keys_override=ck,
+                                        per_chain_diag=np.ndim(imm) == 2)
+        assert np.array_equal(t2n(info.num_integration_steps[t]), info_o.num_integration_steps), t
+        assert np.array_equal(t2n(info.num_trajectory_expansions[t]), info_o.num_trajectory_expansions)
+        assert np.array_equal(t2n(info.is_divergent[t]), info_o.is_divergent)
+        assert np.array_equal(t2n(info.is_turning[t]), info_o.is_turning)
+        np.testing.assert_allclose(t2n(positions[t]), st_o.position, rtol=ATOL, atol=ATOL)
+        np.testing.assert_allclose(t2n(info.logdensity[t]), st_o.logdensity, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(t2n(info.acceptance_rate[t]), info_o.acceptance_rate, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(t2n(info.energy[t]), info_o.energy, rtol=1e-6, atol=1e-6)
+        depths += list(info_o.num_trajectory_expansions)
+    np.testing.assert_allclose(t2n(final.position), st_o.position, rtol=ATOL, atol=ATOL)
+    np.testing.assert_allclose(t2n(final.logdensity_grad), st_o.logdensity_grad, rtol=ATOL, atol=ATOL)
+    return depths
+
+
+@pytest.mark.parametrize("key_layout", ["step_major", "chain_major"])
+@pytest.mark.parametrize("N,D", [(24, 16), (7, 5)])
+def test_free_running_matches_oracle_gaussian(dev, key_layout, N, D):
+    sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(f32)
+    inv_var = (f32(1) / (sig * sig)).astype(f32)
+    q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(f32)
+    depths = _check_against_oracle(dev, otargets.diag_gaussian(inv_var),
+                                   bjx.targets.DiagGaussian(dev_t(inv_var, dev)), q0, f32(0.15),
+                                   np.ones(D, f32), T=5, max_depth=7, key_layout=key_layout, chain_offset=3)
+    assert len(set(depths)) > 2  # chains were at different depths: the schedule really was asynchronous
+
+
+def test_free_running_matches_oracle_funnel_per_chain_params(dev):
+    """Neal's funnel with per-chain step sizes and per-chain diagonal metrics, divergences and
+    max-depth stops included."""
+    N, D = 20, 8
+    rng = np.random.default_rng(3)
+    q0 = (0.5 * prng.normal(prng.key(2), (N, D))).astype(f32)
+    eps = rng.uniform(0.05, 0.6, N).astype(f32)
+    imm = rng.uniform(0.5, 2.0, (N, D)).astype(f32)
+    depths = _check_against_oracle(dev, otargets.neal_funnel(), bjx.targets.NealFunnel(), q0, eps, imm,
+                                   T=4, max_depth=5, key_layout="step_major")
+    assert max(depths) == 5
+
+
+def test_free_running_equals_lockstep_steps_at_scale(dev):
+    """4 096 chains x 64 dims, funnel: run(T) == T x step, bit for bit (positions, tree sizes)."""
+    N, D, T = 4096, 64, 6
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
+    alg = bjx.nuts(bjx.targets.NealFunnel(), 0.1, torch.ones(D, device=dev), max_num_doublings=8)
+    st0 = alg.init(q0)
+    final, positions, info = alg.run(bjx.random.key(9), st0, T)
+    st = st0
+    for t, k in enumerate(bjx.random.split(bjx.random.key(9), T)):
+        st, inf = alg.step(k, st)
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps), t
+        assert torch.equal(info.is_divergent[t], inf.is_divergent)
+        assert torch.equal(positions[t], st.position), t
+        assert torch.equal(info.acceptance_rate[t], inf.acceptance_rate)
+    assert torch.equal(final.position, st.position) and torch.equal(final.logdensity, st.logdensity)
+    assert int(info.num_trajectory_expansions.max()) >= 6
+    # store_positions=False returns only the final state and the scalar records
+    final2, none_pos, info2 = alg.run(bjx.random.key(9), st0, T, store_positions=False)
+    assert none_pos is None and torch.equal(final2.position, final.position)
+    assert torch.equal(info2.energy, info.energy)

@@ -23,6 +23,8 @@ ap.add_argument("--eps", type=float, default=0.1)
 ap.add_argument("--max-depth", type=int, default=10)
 ap.add_argument("--recompact", type=int, default=16)
 ap.add_argument("--use-graph", action="store_true")
+ap.add_argument("--free-running", action="store_true",
+                help="drive the timed transitions with alg.run (asynchronous chains) instead of step")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 N, D = args.chains, args.dim
@@ -36,6 +38,37 @@ keys = bjx.random.split(bjx.random.key(0), args.warmup + args.steps)
 for t in range(args.warmup):
     state, info = alg.step(keys[t], state)
 torch.cuda.synchronize()
+if args.free_running:
+    alg.run(bjx.random.key(5), state, 2, store_positions=False)  # first use of the tick kernel
+    tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=8)
+    _lib.set_timer(tick_timer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    state, positions, rinfo = alg.run(bjx.random.key(1), state, args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    ticks = tick_timer.seen["bjx_nuts_async_tick"]
+    tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick")
+    tot = int(rinfo.num_integration_steps.sum())
+    per_chain = rinfo.num_integration_steps.sum(0).float()
+    avg_tick_us = sum(tick_ms) / len(tick_ms) * 1e3
+    print(json.dumps({
+        "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot / dt, "unit": "chain-leapfrog-steps/s",
+        "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
+                   "driver": "free-running chains (alg.run)"},
+        "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
+        "mean_leapfrogs_per_chain_transition": tot / (N * args.steps),
+        "ticks": ticks, "max_chain_total_leapfrogs": int(per_chain.max()),
+        "utilisation": tot / (N * ticks),
+        "tick_kernel_avg_us": avg_tick_us,
+        "tick_kernel_us_first_20_samples": sum(tick_ms[:20]) / max(len(tick_ms[:20]), 1) * 1e3,
+        "tick_kernel_us_last_20_samples": sum(tick_ms[-20:]) / max(len(tick_ms[-20:]), 1) * 1e3,
+        "tick_kernel_GBps_at_52B_per_element": 52.0 * N * D / (avg_tick_us * 1e-6) / 1e9,
+        "mean_depth": float(rinfo.num_trajectory_expansions.float().mean()),
+        "frac_divergent": float(rinfo.is_divergent.float().mean()),
+    }))
+    sys.exit(0)
 timer = _lib.LaunchTimer(["bjx_nuts_pre", "bjx_nuts_post"])
 if not args.use_graph:
     _lib.set_timer(timer)
