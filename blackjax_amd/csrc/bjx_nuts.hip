@@ -1,8 +1,13 @@
-// NUTS kernels (gfx950): lockstep iterative tree doubling for N chains, diagonal metric.
-// C ABI and the algorithm map are in include/bjx_nuts.h.
+// NUTS kernels (gfx950): iterative tree doubling for N chains -- lockstep launches and free-running
+// (asynchronous) chains share the per-chain device functions below.  C ABI and the algorithm map are
+// in include/bjx_nuts.h.
 //
 // One wavefront per chain row.  Per-chain control state lives in the fs / is slot tables so that
 // every decision (direction, progressive sampling, divergence, U-turn) is wave-uniform.
+// Row sweeps move 16 bytes per lane (VEC = 4) whenever D % 4 == 0 and the buffers are 16-byte
+// aligned; the dense-metric paths keep the 4-byte mapping (VEC = 1) their shuffle-based
+// matrix-vector product needs.  All sweeps of one instantiation use the same lane <-> element
+// mapping, so a lane only ever re-reads elements it wrote itself within a kernel.
 // Numerics contract as in bjx_device.h: explicit fmaf, fp64-accumulated reductions, fp64 scalar
 // transcendentals rounded once.
 #include "../../include/bjx_hip.h"
@@ -16,13 +21,39 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
 
+// The wave's index is the same in all 64 lanes: readfirstlane tells the compiler so, which puts
+// everything derived from it (chain index, slot-table addresses, the threefry key arithmetic of the
+// chain's RNG stream) on the scalar unit instead of repeating it in 64 vector lanes.
 __device__ __forceinline__ int64_t wave_row0() {
-  return (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  return (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 __device__ __forceinline__ int64_t wave_row_stride() { return (int64_t)gridDim.x * kWavesPerBlock; }
 
 #define FS(slot, c) nt.fs[(int64_t)(slot)*nt.N + (c)]
 #define IS(slot, c) nt.is[(int64_t)(slot)*nt.N + (c)]
+// this lane's pieces of a row: VEC consecutive elements starting at j0
+#define BJX_ROW_SWEEP(j0) for (int64_t j0 = (int64_t)(threadIdx.x & 63) * VEC; j0 < nt.D; j0 += 64 * VEC)
+
+template <int VEC>
+struct Row {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Row<VEC> ldr(const float* p) {
+  Row<VEC> r;
+  if constexpr (VEC == 4) {
+    const F4 t = ld4(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void str(float* p, const Row<VEC>& r) {
+  if constexpr (VEC == 4) st4(p, F4{r.v[0], r.v[1], r.v[2], r.v[3]});
+  else p[0] = r.v[0];
+}
 
 // np.logaddexp / jnp.logaddexp in fp64, rounded once
 __device__ __forceinline__ float logaddexp_cr(float a, float b) {
@@ -103,13 +134,15 @@ __device__ __forceinline__ double matvec_t_lane(const float* __restrict__ M, int
 // Opening half of a leapfrog on the trajectory end `dir` of chain c (integrators.py:104-150 with
 // step dir*eps): p += h g ; q += deps * (M^{-1} p) ; new position also to the compact row qo.
 // gsrc = gradient at the current end state.
+template <int VEC, bool DENSE>
 __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, int dir, float deps,
                                                float h, const float* gsrc, float* qo) {
-  const int lane = threadIdx.x & 63;
   const int64_t base = c * nt.D;
   float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
   float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
-  if (nt.Mdense) {
+  if constexpr (DENSE) {
+    static_assert(VEC == 1, "dense metric uses the 4-byte mapping");
+    const int lane = threadIdx.x & 63;
     const float* M = nt.Mdense + c * nt.Mdense_stride;
     for (int64_t ic = 0; ic < nt.D; ic += 64) {
       const int64_t i = ic + lane;
@@ -123,12 +156,17 @@ __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, 
     for (int64_t j = lane; j < nt.D; j += 64) fp[j] = fmaf(h, gsrc[j], fp[j]);
   } else {
     const float* im = nt.imm + c * nt.imm_stride;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float pn = fmaf(h, gsrc[j], fp[j]);
-      const float qn = fmaf(deps, im[j] * pn, fq[j]);
-      fp[j] = pn;
-      fq[j] = qn;
-      qo[j] = qn;
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> g = ldr<VEC>(gsrc + j0), m = ldr<VEC>(im + j0);
+      Row<VEC> p = ldr<VEC>(fp + j0), q = ldr<VEC>(fq + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        p.v[e] = fmaf(h, g.v[e], p.v[e]);
+        q.v[e] = fmaf(deps, m.v[e] * p.v[e], q.v[e]);
+      }
+      str<VEC>(fp + j0, p);
+      str<VEC>(fq + j0, q);
+      str<VEC>(qo + j0, q);
     }
   }
 }
@@ -136,51 +174,53 @@ __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, 
 // ------------------------------------------------------------------------------------ init
 // Tree state of chain c at the start of a transition (nuts.py:278-291): both ends and the proposal
 // are the current state, momentum_sum = p0, num_states = 0.  lp = logdensity, ke = K(p0).
+template <int VEC, bool DENSE>
 __device__ __forceinline__ void nuts_init_chain(const bjx_nuts_t& nt, int64_t c, float lp, float ke) {
   const int lane = threadIdx.x & 63;
-  {
-    const int64_t base = c * nt.D;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float q = nt.q0[base + j], p = nt.p0[base + j], g = nt.g0[base + j];
-      nt.Lq[base + j] = q; nt.Rq[base + j] = q; nt.Pq[base + j] = q;
-      nt.Lp[base + j] = p; nt.Rp[base + j] = p; nt.msum[base + j] = p;
-      nt.Lg[base + j] = g; nt.Rg[base + j] = g; nt.Pg[base + j] = g;
-      if (nt.Mdense) {
-        const float v = nt.v0[base + j];
-        nt.Lv[base + j] = v; nt.Rv[base + j] = v;
-      }
+  const int64_t base = c * nt.D;
+  BJX_ROW_SWEEP(j0) {
+    const Row<VEC> q = ldr<VEC>(nt.q0 + base + j0), p = ldr<VEC>(nt.p0 + base + j0),
+                   g = ldr<VEC>(nt.g0 + base + j0);
+    str<VEC>(nt.Lq + base + j0, q); str<VEC>(nt.Rq + base + j0, q); str<VEC>(nt.Pq + base + j0, q);
+    str<VEC>(nt.Lp + base + j0, p); str<VEC>(nt.Rp + base + j0, p); str<VEC>(nt.msum + base + j0, p);
+    str<VEC>(nt.Lg + base + j0, g); str<VEC>(nt.Rg + base + j0, g); str<VEC>(nt.Pg + base + j0, g);
+    if constexpr (DENSE) {
+      const Row<VEC> v = ldr<VEC>(nt.v0 + base + j0);
+      str<VEC>(nt.Lv + base + j0, v); str<VEC>(nt.Rv + base + j0, v);
     }
-    if (lane == 0) {
-      const float H0 = -lp + ke;
-      FS(BJX_NUTS_F_H0, c) = H0;
-      FS(BJX_NUTS_F_LLOGP, c) = lp;
-      FS(BJX_NUTS_F_RLOGP, c) = lp;
-      FS(BJX_NUTS_F_PLOGP, c) = lp;
-      FS(BJX_NUTS_F_PENERGY, c) = H0;
-      FS(BJX_NUTS_F_PW, c) = 0.0f;
-      FS(BJX_NUTS_F_PSLPA, c) = -__builtin_inff();
-      FS(BJX_NUTS_F_SLOGP, c) = lp;
-      FS(BJX_NUTS_F_SENERGY, c) = H0;
-      FS(BJX_NUTS_F_SW, c) = 0.0f;
-      FS(BJX_NUTS_F_SSLPA, c) = -__builtin_inff();
-      FS(BJX_NUTS_F_ACC, c) = __builtin_nanf("");
-      IS(BJX_NUTS_I_ACTIVE, c) = nt.max_depth > 0 ? 1 : 0;
-      IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
-      IS(BJX_NUTS_I_DIR, c) = 1;
-      IS(BJX_NUTS_I_NSTATES, c) = 0;
-      IS(BJX_NUTS_I_SUBN, c) = 0;
-      IS(BJX_NUTS_I_SDIV, c) = 0;
-      IS(BJX_NUTS_I_STURN, c) = 0;
-      IS(BJX_NUTS_I_DIV, c) = 0;
-      IS(BJX_NUTS_I_TURN, c) = 0;
-      IS(BJX_NUTS_I_DEPTH, c) = 0;
-    }
+  }
+  if (lane == 0) {
+    const float H0 = -lp + ke;
+    FS(BJX_NUTS_F_H0, c) = H0;
+    FS(BJX_NUTS_F_LLOGP, c) = lp;
+    FS(BJX_NUTS_F_RLOGP, c) = lp;
+    FS(BJX_NUTS_F_PLOGP, c) = lp;
+    FS(BJX_NUTS_F_PENERGY, c) = H0;
+    FS(BJX_NUTS_F_PW, c) = 0.0f;
+    FS(BJX_NUTS_F_PSLPA, c) = -__builtin_inff();
+    FS(BJX_NUTS_F_SLOGP, c) = lp;
+    FS(BJX_NUTS_F_SENERGY, c) = H0;
+    FS(BJX_NUTS_F_SW, c) = 0.0f;
+    FS(BJX_NUTS_F_SSLPA, c) = -__builtin_inff();
+    FS(BJX_NUTS_F_ACC, c) = __builtin_nanf("");
+    IS(BJX_NUTS_I_ACTIVE, c) = nt.max_depth > 0 ? 1 : 0;
+    IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+    IS(BJX_NUTS_I_DIR, c) = 1;
+    IS(BJX_NUTS_I_NSTATES, c) = 0;
+    IS(BJX_NUTS_I_SUBN, c) = 0;
+    IS(BJX_NUTS_I_SDIV, c) = 0;
+    IS(BJX_NUTS_I_STURN, c) = 0;
+    IS(BJX_NUTS_I_DIV, c) = 0;
+    IS(BJX_NUTS_I_TURN, c) = 0;
+    IS(BJX_NUTS_I_DEPTH, c) = 0;
   }
 }
 
+template <int VEC, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restrict__ ke0) {
-  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) nuts_init_chain(nt, c, logp0[c], ke0[c]);
+  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride())
+    nuts_init_chain<VEC, DENSE>(nt, c, logp0[c], ke0[c]);
 }
 
 // Start of doubling `depth` for chain c: draw the direction and reset the subtree flags
@@ -202,6 +242,7 @@ __device__ __forceinline__ int nuts_begin_doubling(const bjx_nuts_t& nt, const S
 }
 
 // ------------------------------------------------------------------------------------ pre
+template <int VEC, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
            const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* __restrict__ qf) {
@@ -221,7 +262,7 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     const float deps = (float)dir * chain_eps(nt, c);  // direction * step_size (trajectory.py:323)
     const float h = deps * 0.5f;
     const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
-    nuts_open_half(nt, c, dir, deps, h, fg, qf + b * nt.D);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps, h, fg, qf + b * nt.D);
   }
 }
 
@@ -231,147 +272,169 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 // momentum-sum append, checkpoint store, iterative U-turn (trajectory.py:242-395,
 // termination.py:31-106).  With fuse_next the opening half of leaf s+1 follows when the subtree
 // keeps integrating.  Returns true when the subtree stops (divergence or U-turn).
+template <int VEC, bool DENSE>
 __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const StepCtx& cx, int64_t c,
                                                 int64_t b, int32_t depth, int32_t s, float* qf,
                                                 const float* __restrict__ logp_f,
                                                 const float* __restrict__ gf, bool fuse_next) {
   const int lane = threadIdx.x & 63;
-  {
-    const int dir = IS(BJX_NUTS_I_DIR, c);
-    const float deps = (float)dir * chain_eps(nt, c);
-    const float h = deps * 0.5f;
-    const int64_t base = c * nt.D;
-    float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
-    float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
-    const float* im = nt.imm + c * nt.imm_stride;
-    const float* gn = gf + b * nt.D;
-    float* qn = qf + b * nt.D;
+  const int dir = IS(BJX_NUTS_I_DIR, c);
+  const float deps = (float)dir * chain_eps(nt, c);
+  const float h = deps * 0.5f;
+  const int64_t base = c * nt.D;
+  float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+  float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+  const float* im = nt.imm + c * nt.imm_stride;
+  const float* gn = gf + b * nt.D;
+  float* qn = qf + b * nt.D;
 
-    // pass 1: closing half kick, store the new end state, kinetic energy
-    double acc = 0.0;
-    float* fv = nullptr;  // dense metric: velocity M^{-1} p of the new end state
-    if (nt.Mdense) {
-      const float* M = nt.Mdense + c * nt.Mdense_stride;
-      fv = (dir > 0 ? nt.Rv : nt.Lv) + base;
-      for (int64_t ic = 0; ic < nt.D; ic += 64) {
-        const int64_t i = ic + lane;
-        const double av = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gn[j], fp[j]); });
-        if (i < nt.D) {
-          const float p = fmaf(h, gn[i], fp[i]);
-          const float v = (float)av;
-          fv[i] = v;
-          acc += (double)v * (double)p;
+  // pass 1: closing half kick, store the new end state, kinetic energy
+  double acc = 0.0;
+  float* fv = nullptr;  // dense metric: velocity M^{-1} p of the new end state
+  if constexpr (DENSE) {
+    const float* M = nt.Mdense + c * nt.Mdense_stride;
+    fv = (dir > 0 ? nt.Rv : nt.Lv) + base;
+    for (int64_t ic = 0; ic < nt.D; ic += 64) {
+      const int64_t i = ic + lane;
+      const double av = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gn[j], fp[j]); });
+      if (i < nt.D) {
+        const float p = fmaf(h, gn[i], fp[i]);
+        const float v = (float)av;
+        fv[i] = v;
+        acc += (double)v * (double)p;
+      }
+    }
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      fp[j] = fmaf(h, gn[j], fp[j]);
+      fg[j] = gn[j];
+    }
+  } else {
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> g = ldr<VEC>(gn + j0), m = ldr<VEC>(im + j0);
+      Row<VEC> p = ldr<VEC>(fp + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        p.v[e] = fmaf(h, g.v[e], p.v[e]);
+        acc += (double)(m.v[e] * p.v[e]) * (double)p.v[e];
+      }
+      str<VEC>(fp + j0, p);
+      str<VEC>(fg + j0, g);
+    }
+  }
+  acc = wave_sum(acc);
+  const float ke = 0.5f * (float)acc;
+  const float lp = logp_f[b];
+  const float e_new = -lp + ke;                       // hmc_energy (trajectory.py:745-748)
+  float w = FS(BJX_NUTS_F_H0, c) - e_new;             // proposal.py:91-95
+  if (w != w) w = -__builtin_inff();
+  const float slpa_new = fminf(w, 0.0f);
+  const bool sdiv = (-w) > nt.divergence_threshold;   // trajectory.py:325
+
+  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
+  bool take;
+  float Wn, Sn;
+  if (s == 0) {
+    take = true;
+    Wn = w;
+    Sn = slpa_new;
+  } else {
+    const float sw = FS(BJX_NUTS_F_SW, c);
+    const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
+    const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
+    const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
+    const float pa = expit_cr(w - sw);
+    take = u < pa;
+    Wn = logaddexp_cr(sw, w);
+    Sn = logaddexp_cr(FS(BJX_NUTS_F_SSLPA, c), slpa_new);
+  }
+  // checkpoint indices (termination.py:75-84)
+  const uint32_t us = (uint32_t)s;
+  const int idx_max = __popc(us >> 1);
+  const int nsub = __popc((~us & (us + 1u)) - 1u);
+  const int idx_min = idx_max - nsub + 1;
+  const bool even = (us & 1u) == 0u;
+
+  // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
+  float* sm = nt.Smsum + base;
+  float* ckr = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+  float* ckrs = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
+  float* sq = nt.Sq + base;
+  float* sg = nt.Sg + base;
+  BJX_ROW_SWEEP(j0) {
+    const Row<VEC> p = ldr<VEC>(fp + j0);
+    Row<VEC> m = p;
+    if (s != 0) {  // append_to_trajectory (trajectory.py:62-67)
+      const Row<VEC> old = ldr<VEC>(sm + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) m.v[e] = old.v[e] + p.v[e];
+    }
+    str<VEC>(sm + j0, m);
+    if (even) {
+      str<VEC>(ckr + j0, p);
+      str<VEC>(ckrs + j0, m);
+      if constexpr (DENSE) str<VEC>(nt.ckpt_v + (c * nt.max_depth + idx_max) * nt.D + j0, ldr<VEC>(fv + j0));
+    }
+    if (take) {
+      str<VEC>(sq + j0, ldr<VEC>(qn + j0));
+      str<VEC>(sg + j0, ldr<VEC>(gn + j0));
+    }
+  }
+
+  // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104)
+  bool turning = false;
+  for (int i = idx_max; i >= idx_min && !turning; --i) {
+    const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
+    const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
+    double a_left = 0.0, a_right = 0.0;
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> p = ldr<VEC>(fp + j0), rl = ldr<VEC>(r_ck + j0), msum = ldr<VEC>(sm + j0),
+                     rs = ldr<VEC>(rs_ck + j0);
+      Row<VEC> vl, vr;
+      if constexpr (DENSE) {
+        vl = ldr<VEC>(nt.ckpt_v + (c * nt.max_depth + i) * nt.D + j0);
+        vr = ldr<VEC>(fv + j0);
+      } else {
+        const Row<VEC> m = ldr<VEC>(im + j0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          vl.v[e] = m.v[e] * rl.v[e];  // velocity_left / velocity_right
+          vr.v[e] = m.v[e] * p.v[e];
         }
       }
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        fp[j] = fmaf(h, gn[j], fp[j]);
-        fg[j] = gn[j];
-      }
-    } else {
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        const float g = gn[j];
-        const float p = fmaf(h, g, fp[j]);
-        fp[j] = p;
-        fg[j] = g;
-        acc += (double)(im[j] * p) * (double)p;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float ssum = (msum.v[e] - rs.v[e]) + rl.v[e];
+        const float rho = ssum - (p.v[e] + rl.v[e]) * 0.5f;  // metrics.py:300
+        a_left += (double)vl.v[e] * (double)rho;
+        a_right += (double)vr.v[e] * (double)rho;
       }
     }
-    acc = wave_sum(acc);
-    const float ke = 0.5f * (float)acc;
-    const float lp = logp_f[b];
-    const float e_new = -lp + ke;                       // hmc_energy (trajectory.py:745-748)
-    float w = FS(BJX_NUTS_F_H0, c) - e_new;             // proposal.py:91-95
-    if (w != w) w = -__builtin_inff();
-    const float slpa_new = fminf(w, 0.0f);
-    const bool sdiv = (-w) > nt.divergence_threshold;   // trajectory.py:325
-
-    // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
-    bool take;
-    float Wn, Sn;
-    if (s == 0) {
-      take = true;
-      Wn = w;
-      Sn = slpa_new;
-    } else {
-      const float sw = FS(BJX_NUTS_F_SW, c);
-      const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
-      const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
-      const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
-      const float pa = expit_cr(w - sw);
-      take = u < pa;
-      Wn = logaddexp_cr(sw, w);
-      Sn = logaddexp_cr(FS(BJX_NUTS_F_SSLPA, c), slpa_new);
-    }
-    // checkpoint indices (termination.py:75-84)
-    const uint32_t us = (uint32_t)s;
-    const int idx_max = __popc(us >> 1);
-    const int nsub = __popc((~us & (us + 1u)) - 1u);
-    const int idx_min = idx_max - nsub + 1;
-    const bool even = (us & 1u) == 0u;
-
-    // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
-    float* sm = nt.Smsum + base;
-    float* ckr = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
-    float* ckrs = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
-    float* sq = nt.Sq + base;
-    float* sg = nt.Sg + base;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float p = fp[j];
-      const float m = (s == 0) ? p : sm[j] + p;  // append_to_trajectory (trajectory.py:62-67)
-      sm[j] = m;
-      if (even) {
-        ckr[j] = p;
-        ckrs[j] = m;
-        if (fv) nt.ckpt_v[(c * nt.max_depth + idx_max) * nt.D + j] = fv[j];
-      }
-      if (take) {
-        sq[j] = qn[j];
-        sg[j] = gn[j];
-      }
-    }
-
-    // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104)
-    bool turning = false;
-    for (int i = idx_max; i >= idx_min && !turning; --i) {
-      const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
-      const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
-      const float* v_ck = fv ? nt.ckpt_v + (c * nt.max_depth + i) * nt.D : nullptr;
-      double a_left = 0.0, a_right = 0.0;
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        const float p = fp[j], rl = r_ck[j];
-        const float ssum = (sm[j] - rs_ck[j]) + rl;
-        const float rho = ssum - (p + rl) * 0.5f;      // metrics.py:300
-        const float vl = fv ? v_ck[j] : im[j] * rl;    // velocity_left / velocity_right
-        const float vr = fv ? fv[j] : im[j] * p;
-        a_left += (double)vl * (double)rho;
-        a_right += (double)vr * (double)rho;
-      }
-      a_left = wave_sum(a_left);
-      a_right = wave_sum(a_right);
-      turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
-    }
-
-    if (lane == 0) {
-      FS(dir > 0 ? BJX_NUTS_F_RLOGP : BJX_NUTS_F_LLOGP, c) = lp;
-      FS(BJX_NUTS_F_SW, c) = Wn;
-      FS(BJX_NUTS_F_SSLPA, c) = Sn;
-      if (take) {
-        FS(BJX_NUTS_F_SLOGP, c) = lp;
-        FS(BJX_NUTS_F_SENERGY, c) = e_new;
-      }
-      IS(BJX_NUTS_I_SUBN, c) = s + 1;
-      IS(BJX_NUTS_I_SDIV, c) = sdiv ? 1 : 0;
-      IS(BJX_NUTS_I_STURN, c) = turning ? 1 : 0;
-      if (sdiv || turning) IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
-    }
-
-    // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
-    // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
-    if (fuse_next && !(sdiv || turning)) nuts_open_half(nt, c, dir, deps, h, gn, qn);
-    return sdiv || turning;
+    a_left = wave_sum(a_left);
+    a_right = wave_sum(a_right);
+    turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
   }
+
+  if (lane == 0) {
+    FS(dir > 0 ? BJX_NUTS_F_RLOGP : BJX_NUTS_F_LLOGP, c) = lp;
+    FS(BJX_NUTS_F_SW, c) = Wn;
+    FS(BJX_NUTS_F_SSLPA, c) = Sn;
+    if (take) {
+      FS(BJX_NUTS_F_SLOGP, c) = lp;
+      FS(BJX_NUTS_F_SENERGY, c) = e_new;
+    }
+    IS(BJX_NUTS_I_SUBN, c) = s + 1;
+    IS(BJX_NUTS_I_SDIV, c) = sdiv ? 1 : 0;
+    IS(BJX_NUTS_I_STURN, c) = turning ? 1 : 0;
+    if (sdiv || turning) IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+  }
+
+  // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
+  // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
+  if (fuse_next && !(sdiv || turning)) nuts_open_half<VEC, DENSE>(nt, c, dir, deps, h, gn, qn);
+  return sdiv || turning;
 }
 
+template <int VEC, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
             const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* qf,
@@ -382,7 +445,7 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
   for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
     const int64_t c = idx ? (int64_t)idx[b] : b;
     if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
-    nuts_post_chain(nt, cx, c, b, depth, s, qf, logp_f, gf, fuse_next != 0);
+    nuts_post_chain<VEC, DENSE>(nt, cx, c, b, depth, s, qf, logp_f, gf, fuse_next != 0);
   }
 }
 
@@ -390,80 +453,99 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 // End of doubling `depth` for chain c: biased progressive sampling of the new subtree's proposal,
 // momentum-sum merge, U-turn of the whole trajectory, stop flags (trajectory.py:680-727,
 // proposal.py:146-176, nuts.py:303-305).  Returns true when the tree keeps growing.
+template <int VEC, bool DENSE>
 __device__ __forceinline__ bool nuts_merge_chain(const bjx_nuts_t& nt, const StepCtx& kcx, int64_t c,
                                                  int32_t depth) {
   const int lane = threadIdx.x & 63;
-  {
-    const bool sdiv = IS(BJX_NUTS_I_SDIV, c) != 0, sturn = IS(BJX_NUTS_I_STURN, c) != 0;
-    const int64_t base = c * nt.D;
-    const float pw = FS(BJX_NUTS_F_PW, c), sw = FS(BJX_NUTS_F_SW, c);
-    const float pslpa = FS(BJX_NUTS_F_PSLPA, c), sslpa = FS(BJX_NUTS_F_SSLPA, c);
-    bool take = false;
-    float new_pw = pw;
-    const float new_pslpa = logaddexp_cr(pslpa, sslpa);
-    if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
-      const Key subkey = key_child(integrator_key(kcx, c), (uint64_t)depth);
-      const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
-      const float pa = min1_nan(exp_cr(sw - pw));
-      take = key_uniform(kp) < pa;
-      new_pw = logaddexp_cr(pw, sw);
-    }
-    // merged trajectory: momentum sum + U-turn of the whole trajectory (trajectory.py:696-710)
-    const float* im = nt.imm + c * nt.imm_stride;
-    double a_left = 0.0, a_right = 0.0;
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      const float m = nt.msum[base + j] + nt.Smsum[base + j];
-      nt.msum[base + j] = m;
-      const float pl = nt.Lp[base + j], pr = nt.Rp[base + j];
-      const float rho = m - (pr + pl) * 0.5f;
-      const float vl = nt.Mdense ? nt.Lv[base + j] : im[j] * pl;
-      const float vr = nt.Mdense ? nt.Rv[base + j] : im[j] * pr;
-      a_left += (double)vl * (double)rho;
-      a_right += (double)vr * (double)rho;
-      if (take) {
-        nt.Pq[base + j] = nt.Sq[base + j];
-        nt.Pg[base + j] = nt.Sg[base + j];
-      }
-    }
-    a_left = wave_sum(a_left);
-    a_right = wave_sum(a_right);
-    const bool turn = sturn || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
-    if (lane == 0) {
-      const int n = IS(BJX_NUTS_I_NSTATES, c) + IS(BJX_NUTS_I_SUBN, c);
-      FS(BJX_NUTS_F_PW, c) = new_pw;
-      FS(BJX_NUTS_F_PSLPA, c) = new_pslpa;
-      if (take) {
-        FS(BJX_NUTS_F_PLOGP, c) = FS(BJX_NUTS_F_SLOGP, c);
-        FS(BJX_NUTS_F_PENERGY, c) = FS(BJX_NUTS_F_SENERGY, c);
-      }
-      FS(BJX_NUTS_F_ACC, c) = exp_cr(new_pslpa) / (float)n;  // nuts.py:303-305
-      IS(BJX_NUTS_I_NSTATES, c) = n;
-      IS(BJX_NUTS_I_DIV, c) = sdiv ? 1 : 0;
-      IS(BJX_NUTS_I_TURN, c) = turn ? 1 : 0;
-      IS(BJX_NUTS_I_DEPTH, c) = depth + 1;
-      IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
-      IS(BJX_NUTS_I_ACTIVE, c) = (!sdiv && !turn && depth + 1 < nt.max_depth) ? 1 : 0;
-    }
-    return !sdiv && !turn && depth + 1 < nt.max_depth;
+  const bool sdiv = IS(BJX_NUTS_I_SDIV, c) != 0, sturn = IS(BJX_NUTS_I_STURN, c) != 0;
+  const int64_t base = c * nt.D;
+  const float pw = FS(BJX_NUTS_F_PW, c), sw = FS(BJX_NUTS_F_SW, c);
+  const float pslpa = FS(BJX_NUTS_F_PSLPA, c), sslpa = FS(BJX_NUTS_F_SSLPA, c);
+  bool take = false;
+  float new_pw = pw;
+  const float new_pslpa = logaddexp_cr(pslpa, sslpa);
+  if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
+    const Key subkey = key_child(integrator_key(kcx, c), (uint64_t)depth);
+    const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
+    const float pa = min1_nan(exp_cr(sw - pw));
+    take = key_uniform(kp) < pa;
+    new_pw = logaddexp_cr(pw, sw);
   }
+  // merged trajectory: momentum sum + U-turn of the whole trajectory (trajectory.py:696-710)
+  const float* im = nt.imm + c * nt.imm_stride;
+  double a_left = 0.0, a_right = 0.0;
+  BJX_ROW_SWEEP(j0) {
+    Row<VEC> m = ldr<VEC>(nt.msum + base + j0);
+    const Row<VEC> sm = ldr<VEC>(nt.Smsum + base + j0), pl = ldr<VEC>(nt.Lp + base + j0),
+                   pr = ldr<VEC>(nt.Rp + base + j0);
+    Row<VEC> vl, vr;
+    if constexpr (DENSE) {
+      vl = ldr<VEC>(nt.Lv + base + j0);
+      vr = ldr<VEC>(nt.Rv + base + j0);
+    } else {
+      const Row<VEC> mm = ldr<VEC>(im + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        vl.v[e] = mm.v[e] * pl.v[e];
+        vr.v[e] = mm.v[e] * pr.v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      m.v[e] = m.v[e] + sm.v[e];
+      const float rho = m.v[e] - (pr.v[e] + pl.v[e]) * 0.5f;
+      a_left += (double)vl.v[e] * (double)rho;
+      a_right += (double)vr.v[e] * (double)rho;
+    }
+    str<VEC>(nt.msum + base + j0, m);
+    if (take) {
+      str<VEC>(nt.Pq + base + j0, ldr<VEC>(nt.Sq + base + j0));
+      str<VEC>(nt.Pg + base + j0, ldr<VEC>(nt.Sg + base + j0));
+    }
+  }
+  a_left = wave_sum(a_left);
+  a_right = wave_sum(a_right);
+  const bool turn = sturn || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+  const bool grow = !sdiv && !turn && depth + 1 < nt.max_depth;
+  if (lane == 0) {
+    const int n = IS(BJX_NUTS_I_NSTATES, c) + IS(BJX_NUTS_I_SUBN, c);
+    FS(BJX_NUTS_F_PW, c) = new_pw;
+    FS(BJX_NUTS_F_PSLPA, c) = new_pslpa;
+    if (take) {
+      FS(BJX_NUTS_F_PLOGP, c) = FS(BJX_NUTS_F_SLOGP, c);
+      FS(BJX_NUTS_F_PENERGY, c) = FS(BJX_NUTS_F_SENERGY, c);
+    }
+    FS(BJX_NUTS_F_ACC, c) = exp_cr(new_pslpa) / (float)n;  // nuts.py:303-305
+    IS(BJX_NUTS_I_NSTATES, c) = n;
+    IS(BJX_NUTS_I_DIV, c) = sdiv ? 1 : 0;
+    IS(BJX_NUTS_I_TURN, c) = turn ? 1 : 0;
+    IS(BJX_NUTS_I_DEPTH, c) = depth + 1;
+    IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+    IS(BJX_NUTS_I_ACTIVE, c) = grow ? 1 : 0;
+  }
+  return grow;
 }
 
+template <int VEC, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_merge(bjx_nuts_t nt, int32_t depth, int64_t n_rows, const int32_t* __restrict__ idx) {
   const StepCtx kcx{depth, 0, n_rows, Key{nt.key0, nt.key1}, nt.chain_offset, nt.step_fold};
   for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
     const int64_t c = idx ? (int64_t)idx[b] : b;
     if (!IS(BJX_NUTS_I_ACTIVE, c)) continue;
-    nuts_merge_chain(nt, kcx, c, depth);
+    nuts_merge_chain<VEC, DENSE>(nt, kcx, c, depth);
   }
 }
 
 // ------------------------------------------------------------------------------------ free-running chains
 // One tick of the asynchronous schedule (include/bjx_nuts.h): every chain that is not finished
 // ends the tick with the opening half of a leapfrog done and its new position in qf[c].
-//   phase 1: post(leaf) [-> fused pre(next leaf)] | [-> merge [-> begin next doubling + pre]
-//            | -> record transition, accept proposal as the new state -> phase 0]
-//   phase 0: momentum draw, tree init, begin doubling 0, pre
+//   phase 1: post(leaf) [-> fused pre(next leaf)]  | subtree complete -> phase 3       (k_nuts_async_leaf)
+//   phase 3: merge [-> begin next doubling + pre -> phase 1]
+//            | record the transition, accept its proposal -> phase 0                   (k_nuts_async_boundary)
+//   phase 0: momentum draw, tree init, begin doubling 0, pre -> phase 1
+// Two kernels because the leaf path runs for every chain in every tick and must stay light in
+// registers (occupancy hides its dependent memory round trips); the boundary path is heavy and rare.
 // All per-chain decisions are wave-uniform; scalars written by lane 0 and read by the whole wave
 // later in the same kernel are separated by a workgroup-scope fence (one CU, one L1).
 __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, int32_t t) {
@@ -482,38 +564,75 @@ __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nut
   return cx;
 }
 
+// Work distribution of the free-running kernels: a wave owns groups of kAsyncGroup consecutive
+// chains; one coalesced load + ballot finds the chains of a group that have work in this kernel, so a
+// tick in which most chains are finished costs a few microseconds instead of one wave per chain.
+constexpr int kAsyncGroup = 8;
+
+template <class F>
+__device__ __forceinline__ void async_for_each_chain(const bjx_nuts_t& nt, const int32_t* __restrict__ phase,
+                                                     int want_a, int want_b, F f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_groups = (nt.N + kAsyncGroup - 1) / kAsyncGroup;
+  for (int64_t grp = wave_row0(); grp < n_groups; grp += wave_row_stride()) {
+    const int64_t c0 = grp * kAsyncGroup;
+    const int ph = (lane < kAsyncGroup && c0 + lane < nt.N) ? phase[c0 + lane] : -1;
+    unsigned long long m = __ballot(ph == want_a || ph == want_b);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      f(c0 + l, __builtin_amdgcn_readlane(ph, l));
+    }
+  }
+}
+
+// Tick, part 1 (every chain with a leaf in flight, phase 1): the second half of the leaf and, when
+// the subtree keeps integrating, the fused opening half of the next leaf.  A chain whose subtree is
+// complete moves to phase 3 and is finished by part 2.
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_nuts_async_tick(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
   const int lane = threadIdx.x & 63;
-  for (int64_t c = wave_row0(); c < nt.N; c += wave_row_stride()) {
-    int phase = ax.phase[c];
-    if (phase == 2) continue;
+  async_for_each_chain(nt, ax.phase, 1, 1, [&](int64_t c, int) {
+    const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
+    const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
+    const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
+    const bool last = (s + 1) >= (1 << depth);
+    const bool stop = nuts_post_chain<VEC, false>(nt, cx, c, c, depth, s, qf, logp_f, gf, !last);
+    if ((stop || last) && lane == 0) ax.phase[c] = 3;
+  });
+}
+
+// Tick, part 2 (phase 3: subtree complete; phase 0: start a transition): merge, then either the
+// next doubling, or record the finished transition, accept its proposal and start the next one.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
+  const int lane = threadIdx.x & 63;
+  async_for_each_chain(nt, ax.phase, 3, 0, [&](int64_t c, int phase) {
     int32_t t = ax.t[c];
     StepCtx cx = async_ctx(nt, ax, t);
     const int64_t base = c * nt.D;
-    if (phase == 1) {
+    if (phase == 3) {
       const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
-      const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
-      const bool last = (s + 1) >= (1 << depth);
-      const bool stop = nuts_post_chain(nt, cx, c, c, depth, s, qf, logp_f, gf, !last);
-      if (!stop && !last) continue;  // the fused opening half of leaf s+1 is done
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const bool grow = nuts_merge_chain(nt, cx, c, depth);
+      const bool grow = nuts_merge_chain<VEC, false>(nt, cx, c, depth);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (grow) {
         const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
         const float deps = (float)dir * chain_eps(nt, c);
-        nuts_open_half(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base, qf + base);
-        continue;
+        nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
+                                   qf + base);
+        if (lane == 0) ax.phase[c] = 1;
+        return;
       }
       // transition t is complete: record it and make the proposal the chain's state
       const int64_t row = (int64_t)t * nt.N + c;
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        const float q = nt.Pq[base + j];
-        ax.q[base + j] = q;
-        ax.g[base + j] = nt.Pg[base + j];
-        if (ax.out_position) ax.out_position[row * nt.D + j] = q;
+      BJX_ROW_SWEEP(j0) {
+        const Row<VEC> q = ldr<VEC>(nt.Pq + base + j0);
+        str<VEC>(ax.q + base + j0, q);
+        str<VEC>(ax.g + base + j0, ldr<VEC>(nt.Pg + base + j0));
+        if (ax.out_position) str<VEC>(ax.out_position + row * nt.D + j0, q);
       }
       if (lane == 0) {
         const float lp = FS(BJX_NUTS_F_PLOGP, c);
@@ -533,34 +652,38 @@ k_nuts_async_tick(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __
           ax.phase[c] = 2;
           atomicAdd(ax.n_done, 1);
         }
-        continue;
+        return;
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       cx = async_ctx(nt, ax, t);
     }
-    // phase 0: start transition t -- momentum draw (hmc.py:299-302, metrics.py:260-270) with the
-    // lane <-> element mapping of nuts_init_chain, then the tree of nuts.py:278-294
-    {
-      const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
-      const Key km = key_child(kc, 0);  // split(kc, 2)[0]
-      const float* im = nt.imm + c * nt.imm_stride;
-      double acc = 0.0;
-      for (int64_t j = lane; j < nt.D; j += 64) {
-        const float z = normal_from_bits(key_bits32(km, (uint64_t)j));
-        const float ms = 1.0f / sqrtf(im[j]);
-        const float pv = ms * z;
-        ax.p[base + j] = pv;
-        acc += (double)(im[j] * pv) * (double)pv;
+    // start transition t -- momentum draw (hmc.py:299-302, metrics.py:260-270) with the lane <->
+    // element mapping of the other sweeps, then the tree of nuts.py:278-294
+    const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
+    const Key km = key_child(kc, 0);  // split(kc, 2)[0]
+    const float* im = nt.imm + c * nt.imm_stride;
+    double acc = 0.0;
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> m = ldr<VEC>(im + j0);
+      Row<VEC> pv;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0 + e)));
+        const float ms = 1.0f / sqrtf(m.v[e]);
+        pv.v[e] = ms * z;
+        acc += (double)(m.v[e] * pv.v[e]) * (double)pv.v[e];
       }
-      acc = wave_sum(acc);
-      nuts_init_chain(nt, c, ax.logp[c], 0.5f * (float)acc);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int dir = nuts_begin_doubling(nt, cx, c, 0);
-      const float deps = (float)dir * chain_eps(nt, c);
-      nuts_open_half(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base, qf + base);
-      if (lane == 0 && phase != 1) ax.phase[c] = 1;
+      str<VEC>(ax.p + base + j0, pv);
     }
-  }
+    acc = wave_sum(acc);
+    nuts_init_chain<VEC, false>(nt, c, ax.logp[c], 0.5f * (float)acc);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int dir = nuts_begin_doubling(nt, cx, c, 0);
+    const float deps = (float)dir * chain_eps(nt, c);
+    nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
+                               qf + base);
+    if (lane == 0) ax.phase[c] = 1;
+  });
 }
 
 __global__ void k_nuts_set_ctl(int64_t* ctl, int64_t depth, int64_t s_base, int64_t n_rows,
@@ -624,6 +747,24 @@ int check_nuts(const bjx_nuts_t* nt, const char* what) {
   return 0;
 }
 
+// 16-byte row accesses are legal when the metric is diagonal, D % 4 == 0 and every (N, D) buffer
+// the kernels touch is 16-byte aligned (rows then are, too).
+template <typename... P>
+bool nuts_vec4(const bjx_nuts_t* nt, P... extra) {
+  return !nt->Mdense &&
+         bjx_vec4_ok(nt->D, nt->imm, nt->q0, nt->g0, nt->p0, nt->Lq, nt->Lp, nt->Lg, nt->Rq, nt->Rp,
+                     nt->Rg, nt->msum, nt->Smsum, nt->Pq, nt->Pg, nt->Sq, nt->Sg, nt->ckpt_r,
+                     nt->ckpt_rs, extra...);
+}
+
+// pick the <VEC, DENSE> instantiation of a kernel template
+#define BJX_NUTS_LAUNCH(KERNEL, grid, stream, vec4, dense, ...)                                        \
+  do {                                                                                                 \
+    if (dense) hipLaunchKernelGGL((KERNEL<1, true>), grid, dim3(kBlock), 0, stream, __VA_ARGS__);      \
+    else if (vec4) hipLaunchKernelGGL((KERNEL<4, false>), grid, dim3(kBlock), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<1, false>), grid, dim3(kBlock), 0, stream, __VA_ARGS__);           \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -632,8 +773,9 @@ int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, cons
   if (check_nuts(nuts, "bjx_nuts_init")) return 1;
   BJX_CHECK_ARG(logp0 && ke0, "bjx_nuts_init: bad arguments");
   if (nuts->N == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_init, dim3(bjx_row_grid(nuts->N, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, logp0, ke0);
+  const dim3 grid(bjx_row_grid(nuts->N, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_init, grid, (hipStream_t)stream, nuts_vec4(nuts), nuts->Mdense != nullptr, *nuts,
+                  logp0, ke0);
   return bjx_check_launch("bjx_nuts_init");
 }
 
@@ -644,9 +786,9 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
                     n_rows >= 0 && n_rows <= nuts->N && qf,
                 "bjx_nuts_pre: bad arguments");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_pre, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx,
-                     (const int64_t*)nullptr, qf);
+  const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+                  *nuts, depth, (int32_t)s, n_rows, idx, (const int64_t*)nullptr, qf);
   return bjx_check_launch("bjx_nuts_pre");
 }
 
@@ -656,8 +798,9 @@ int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_
   BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf,
                 "bjx_nuts_pre_ctl: bad arguments");
   if (n_cap == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_pre, dim3(bjx_row_grid(n_cap, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf);
+  const dim3 grid(bjx_row_grid(n_cap, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+                  *nuts, 0, s_off, n_cap, idx, ctl, qf);
   return bjx_check_launch("bjx_nuts_pre_ctl");
 }
 
@@ -669,10 +812,11 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
                     n_rows >= 0 && n_rows <= nuts->N && qf && logp_f && gf,
                 "bjx_nuts_post: bad arguments");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx,
-                     (const int64_t*)nullptr, qf, logp_f, gf,
-                     (int)(fuse_next && s + 1 < ((int64_t)1 << depth)));
+  const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_post, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf),
+                  nuts->Mdense != nullptr, *nuts, depth, (int32_t)s, n_rows, idx,
+                  (const int64_t*)nullptr, qf, logp_f, gf,
+                  (int)(fuse_next && s + 1 < ((int64_t)1 << depth)));
   return bjx_check_launch("bjx_nuts_post");
 }
 
@@ -683,9 +827,10 @@ int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64
   BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf && logp_f && gf,
                 "bjx_nuts_post_ctl: bad arguments");
   if (n_cap == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_post, dim3(bjx_row_grid(n_cap, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf,
-                     (int)fuse_next);
+  const dim3 grid(bjx_row_grid(n_cap, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_post, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf),
+                  nuts->Mdense != nullptr, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf,
+                  (int)fuse_next);
   return bjx_check_launch("bjx_nuts_post_ctl");
 }
 
@@ -714,8 +859,9 @@ int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t 
   BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && n_rows >= 0 && n_rows <= nuts->N,
                 "bjx_nuts_merge: bad arguments");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_merge, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, n_rows, idx);
+  const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_merge, grid, (hipStream_t)stream, nuts_vec4(nuts), nuts->Mdense != nullptr,
+                  *nuts, depth, n_rows, idx);
   return bjx_check_launch("bjx_nuts_merge");
 }
 
@@ -731,8 +877,16 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   BJX_CHECK_ARG(run->q == nuts->q0 && run->g == nuts->g0 && run->p == nuts->p0,
                 "bjx_nuts_async_tick: run->q / g / p must alias nuts->q0 / g0 / p0");
   if (nuts->N == 0 || run->n_steps == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_async_tick, dim3(bjx_row_grid(nuts->N, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, *run, qf, logp_f, gf);
+  const int64_t groups = (nuts->N + kAsyncGroup - 1) / kAsyncGroup;
+  const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
+  hipStream_t s = (hipStream_t)stream;
+  if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+    hipLaunchKernelGGL(k_nuts_async_leaf<4>, grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    hipLaunchKernelGGL(k_nuts_async_boundary<4>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
+  } else {
+    hipLaunchKernelGGL(k_nuts_async_leaf<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    hipLaunchKernelGGL(k_nuts_async_boundary<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
+  }
   return bjx_check_launch("bjx_nuts_async_tick");
 }
 
