@@ -134,6 +134,7 @@ class NutsAsync(ctypes.Structure):
         ("step_keys", c_void_p), ("t_first", ctypes.c_int32), ("n_steps", ctypes.c_int32),
         ("q", c_void_p), ("g", c_void_p), ("logp", c_void_p), ("p", c_void_p),
         ("t", c_void_p), ("phase", c_void_p), ("n_done", c_void_p),
+        ("rows", c_void_p), ("n_rows", c_int64),
         ("out_position", c_void_p), ("out_logdensity", c_void_p), ("out_acceptance_rate", c_void_p),
         ("out_energy", c_void_p), ("out_num_integration_steps", c_void_p),
         ("out_num_trajectory_expansions", c_void_p), ("out_is_divergent", c_void_p),
@@ -143,6 +144,8 @@ class NutsAsync(ctypes.Structure):
 
 SIGNATURES.update({
     "bjx_nuts_async_tick": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), _f32p, _f32p, _f32p],
+    "bjx_nuts_async_compact": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), _f32p, c_void_p, _f32p,
+                               c_void_p, c_void_p],
 })
 
 # include/bjx_pool.h (pooled cross-chain statistics; bjx_pool_workspace_bytes returns int64, see load())

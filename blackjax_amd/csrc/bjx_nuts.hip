@@ -73,6 +73,34 @@ __device__ __forceinline__ float logaddexp_cr(float a, float b) {
 // jax.scipy.special.expit in fp64, rounded once
 __device__ __forceinline__ float expit_cr(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
 
+// The scalar transcendentals of one tree step, evaluated in ONE pass of the fp64 routines instead of
+// three: the values are wave-uniform, so three lanes get three different operands --
+//   lane 0: e0 = exp(arg0), r0 = 1 / (1 + e0)          lanes 1, 2: logaddexp(a1, b1), logaddexp(a2, b2)
+// (logaddexp = max + log1p(exp(-|a - b|)), the same expression tree as logaddexp_cr) -- and the
+// results are broadcast with readlane.  Bit-identical to the one-at-a-time helpers above.
+struct Scalars3 {
+  float e0, r0, lae1, lae2;
+};
+__device__ __forceinline__ float bcast_lane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ Scalars3 scalars3(double arg0, float a1, float b1, float a2, float b2) {
+  const int lane = threadIdx.x & 63;
+  const double xa = lane == 1 ? (double)a1 : (double)a2;
+  const double xb = lane == 1 ? (double)b1 : (double)b2;
+  const double t = xa - xb;
+  const double e = exp(lane == 0 ? arg0 : -fabs(t));
+  const double l1p = log1p(e);
+  double r;
+  if (lane == 0) r = 1.0 / (1.0 + e);
+  else if (xa == xb) r = xa + 0.6931471805599453;
+  else if (t > 0) r = xa + l1p;
+  else if (t <= 0) r = xb + l1p;
+  else r = t;  // NaN
+  const float rf = (float)r, ef = (float)e;
+  return Scalars3{bcast_lane(ef, 0), bcast_lane(rf, 0), bcast_lane(rf, 1), bcast_lane(rf, 2)};
+}
+
 // jnp.minimum(x, 1): NaN propagates
 __device__ __forceinline__ float min1_nan(float x) { return (x < 1.0f || x != x) ? x : 1.0f; }
 
@@ -342,10 +370,11 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
     const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
     const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
     const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
-    const float pa = expit_cr(w - sw);
-    take = u < pa;
-    Wn = logaddexp_cr(sw, w);
-    Sn = logaddexp_cr(FS(BJX_NUTS_F_SSLPA, c), slpa_new);
+    // pa = expit(w - sw), Wn = logaddexp(sw, w), Sn = logaddexp(sum_log_p_accept, min(w, 0))
+    const Scalars3 sc = scalars3(-(double)(w - sw), sw, w, FS(BJX_NUTS_F_SSLPA, c), slpa_new);
+    take = u < sc.r0;
+    Wn = sc.lae1;
+    Sn = sc.lae2;
   }
   // checkpoint indices (termination.py:75-84)
   const uint32_t us = (uint32_t)s;
@@ -463,13 +492,15 @@ __device__ __forceinline__ bool nuts_merge_chain(const bjx_nuts_t& nt, const Ste
   const float pslpa = FS(BJX_NUTS_F_PSLPA, c), sslpa = FS(BJX_NUTS_F_SSLPA, c);
   bool take = false;
   float new_pw = pw;
-  const float new_pslpa = logaddexp_cr(pslpa, sslpa);
+  // exp(sw - pw), logaddexp(pslpa, sslpa), logaddexp(pw, sw) in one pass
+  const Scalars3 sc = scalars3((double)(sw - pw), pslpa, sslpa, pw, sw);
+  const float new_pslpa = sc.lae1;
   if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
     const Key subkey = key_child(integrator_key(kcx, c), (uint64_t)depth);
     const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
-    const float pa = min1_nan(exp_cr(sw - pw));
+    const float pa = min1_nan(sc.e0);
     take = key_uniform(kp) < pa;
-    new_pw = logaddexp_cr(pw, sw);
+    new_pw = sc.lae2;
   }
   // merged trajectory: momentum sum + U-turn of the whole trajectory (trajectory.py:696-710)
   const float* im = nt.imm + c * nt.imm_stride;
@@ -569,19 +600,24 @@ __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nut
 // tick in which most chains are finished costs a few microseconds instead of one wave per chain.
 constexpr int kAsyncGroup = 8;
 
+// f(chain, compact row, phase) for every chain of the compact rows whose phase is want_a or want_b
 template <class F>
-__device__ __forceinline__ void async_for_each_chain(const bjx_nuts_t& nt, const int32_t* __restrict__ phase,
-                                                     int want_a, int want_b, F f) {
+__device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax, int want_a, int want_b,
+                                                     F f) {
   const int lane = threadIdx.x & 63;
-  const int64_t n_groups = (nt.N + kAsyncGroup - 1) / kAsyncGroup;
+  const int64_t n_groups = (ax.n_rows + kAsyncGroup - 1) / kAsyncGroup;
   for (int64_t grp = wave_row0(); grp < n_groups; grp += wave_row_stride()) {
-    const int64_t c0 = grp * kAsyncGroup;
-    const int ph = (lane < kAsyncGroup && c0 + lane < nt.N) ? phase[c0 + lane] : -1;
+    const int64_t b0 = grp * kAsyncGroup;
+    int chain = -1, ph = -1;
+    if (lane < kAsyncGroup && b0 + lane < ax.n_rows) {
+      chain = ax.rows ? ax.rows[b0 + lane] : (int)(b0 + lane);
+      ph = ax.phase[chain];
+    }
     unsigned long long m = __ballot(ph == want_a || ph == want_b);
     while (m) {
       const int l = __ffsll((long long)m) - 1;
       m &= m - 1;
-      f(c0 + l, __builtin_amdgcn_readlane(ph, l));
+      f((int64_t)__builtin_amdgcn_readlane(chain, l), b0 + l, __builtin_amdgcn_readlane(ph, l));
     }
   }
 }
@@ -594,12 +630,12 @@ __global__ void __launch_bounds__(kBlock)
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
   const int lane = threadIdx.x & 63;
-  async_for_each_chain(nt, ax.phase, 1, 1, [&](int64_t c, int) {
+  async_for_each_chain(ax, 1, 1, [&](int64_t c, int64_t b, int) {
     const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
     const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
     const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
     const bool last = (s + 1) >= (1 << depth);
-    const bool stop = nuts_post_chain<VEC, false>(nt, cx, c, c, depth, s, qf, logp_f, gf, !last);
+    const bool stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
     if ((stop || last) && lane == 0) ax.phase[c] = 3;
   });
 }
@@ -610,10 +646,11 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
   const int lane = threadIdx.x & 63;
-  async_for_each_chain(nt, ax.phase, 3, 0, [&](int64_t c, int phase) {
+  async_for_each_chain(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
     int32_t t = ax.t[c];
     StepCtx cx = async_ctx(nt, ax, t);
     const int64_t base = c * nt.D;
+    float* qrow = qf + b * nt.D;  // this chain's row of the callable's batch
     if (phase == 3) {
       const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
       const bool grow = nuts_merge_chain<VEC, false>(nt, cx, c, depth);
@@ -622,7 +659,7 @@ k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
         const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
         const float deps = (float)dir * chain_eps(nt, c);
         nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
-                                   qf + base);
+                                   qrow);
         if (lane == 0) ax.phase[c] = 1;
         return;
       }
@@ -681,9 +718,59 @@ k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
     const int dir = nuts_begin_doubling(nt, cx, c, 0);
     const float deps = (float)dir * chain_eps(nt, c);
     nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
-                               qf + base);
+                               qrow);
     if (lane == 0) ax.phase[c] = 1;
   });
+}
+
+// Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
+// One 1024-thread workgroup (same ballot + LDS scan as k_nuts_compact); src[b'] remembers the old
+// row so the pending positions can be gathered by k_nuts_async_gather.
+__global__ void __launch_bounds__(1024)
+k_nuts_async_compact(bjx_nuts_async_t ax, int32_t* __restrict__ rows_out, int32_t* __restrict__ src,
+                     int32_t* __restrict__ n_out) {
+  __shared__ int wave_counts[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int64_t start = 0; start < ax.n_rows; start += 1024) {
+    const int64_t i = start + tid;
+    int32_t c = -1;
+    if (i < ax.n_rows) c = ax.rows ? ax.rows[i] : (int32_t)i;
+    const bool keep = c >= 0 && ax.phase[c] != 2;
+    const unsigned long long ballot = __ballot(keep);
+    const int lane_prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_counts[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int cnt = wave_counts[w];
+      if (w < wave) wave_off += cnt;
+      total += cnt;
+    }
+    const int b0 = base;
+    if (keep) {
+      rows_out[b0 + wave_off + lane_prefix] = c;
+      src[b0 + wave_off + lane_prefix] = (int32_t)i;
+    }
+    __syncthreads();
+    if (tid == 0) base = b0 + total;
+    __syncthreads();
+  }
+  if (tid == 0) *n_out = base;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_nuts_async_gather(int64_t D, const int32_t* __restrict__ n_rows, const int32_t* __restrict__ src,
+                    const float* __restrict__ qf_in, float* __restrict__ qf_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = *n_rows;
+  for (int64_t b = wave_row0(); b < n; b += wave_row_stride()) {
+    const float* s = qf_in + (int64_t)src[b] * D;
+    float* d = qf_out + b * D;
+    for (int64_t j = lane; j < D; j += 64) d[j] = s[j];
+  }
 }
 
 __global__ void k_nuts_set_ctl(int64_t* ctl, int64_t depth, int64_t s_base, int64_t n_rows,
@@ -876,8 +963,10 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                 "bjx_nuts_async_tick: bad run descriptor");
   BJX_CHECK_ARG(run->q == nuts->q0 && run->g == nuts->g0 && run->p == nuts->p0,
                 "bjx_nuts_async_tick: run->q / g / p must alias nuts->q0 / g0 / p0");
-  if (nuts->N == 0 || run->n_steps == 0) return 0;
-  const int64_t groups = (nuts->N + kAsyncGroup - 1) / kAsyncGroup;
+  BJX_CHECK_ARG(run->n_rows >= 0 && run->n_rows <= nuts->N && (run->rows || run->n_rows == nuts->N),
+                "bjx_nuts_async_tick: n_rows must be N when rows is NULL and never exceed N");
+  if (run->n_rows == 0 || run->n_steps == 0) return 0;
+  const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
   if (nuts_vec4(nuts, qf, gf, run->out_position)) {
@@ -888,6 +977,23 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     hipLaunchKernelGGL(k_nuts_async_boundary<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
   }
   return bjx_check_launch("bjx_nuts_async_tick");
+}
+
+int bjx_nuts_async_compact(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run,
+                           const float* qf_in, int32_t* rows_out, float* qf_out, int32_t* src_work,
+                           int32_t* n_out) {
+  if (check_nuts(nuts, "bjx_nuts_async_compact")) return 1;
+  BJX_CHECK_ARG(run && run->phase && qf_in && rows_out && qf_out && src_work && n_out,
+                "bjx_nuts_async_compact: null argument");
+  BJX_CHECK_ARG(rows_out != run->rows && qf_out != qf_in, "bjx_nuts_async_compact: outputs must not alias inputs");
+  BJX_CHECK_ARG(run->n_rows >= 0 && run->n_rows <= nuts->N && (run->rows || run->n_rows == nuts->N),
+                "bjx_nuts_async_compact: bad row count");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_nuts_async_compact, dim3(1), dim3(1024), 0, s, *run, rows_out, src_work, n_out);
+  if (run->n_rows > 0)
+    hipLaunchKernelGGL(k_nuts_async_gather, dim3(bjx_row_grid(run->n_rows, kWavesPerBlock)), dim3(kBlock), 0,
+                       s, nuts->D, n_out, src_work, qf_in, qf_out);
+  return bjx_check_launch("bjx_nuts_async_compact");
 }
 
 }  // extern "C"

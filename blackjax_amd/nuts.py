@@ -327,7 +327,7 @@ class NUTSRunInfo(NamedTuple):
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every: int = 16):
+             sync_every: int = 16, use_graph: bool = False):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -339,6 +339,12 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     (``key_layout="step_major"``: ``split(split(rng_key, num_steps)[t], N)[c]``, the layout of
     ``run_inference_algorithm``; ``"chain_major"``: ``split(split(rng_key, N)[c], num_steps)[t]``),
     so the draws are identical to ``num_steps`` calls of ``step``.
+
+    The host syncs once per ``sync_every`` ticks (to stop, and to drop finished chains from the
+    callable's batch once fewer than half of its rows are still running).  ``use_graph=True``
+    replays those ``sync_every`` ticks + callable invocations as one HIP graph (the callable must be
+    capturable): in the tail of a run, where a few deep trees are all that is left, the ticks are
+    otherwise bound by the host's launch rate.
 
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
@@ -400,7 +406,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     run = _lib.NutsAsync(
         step_keys=_lib.ptr(step_keys), t_first=0, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
         logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
-        n_done=n_done.data_ptr(), out_position=_lib.ptr(positions),
+        n_done=n_done.data_ptr(), rows=None, n_rows=N, out_position=_lib.ptr(positions),
         out_logdensity=info.logdensity.data_ptr(), out_acceptance_rate=info.acceptance_rate.data_ptr(),
         out_energy=info.energy.data_ptr(),
         out_num_integration_steps=info.num_integration_steps.data_ptr(),
@@ -412,12 +418,57 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     gf = torch.zeros_like(q)
     max_ticks = T * ((1 << max_depth) - 1) + 2
     sync_every = max(1, int(sync_every))
-    for tick in range(max_ticks):
-        _lib.call("bjx_nuts_async_tick", stream, dref, rref, qf.data_ptr(), logp_f.data_ptr(),
-                  gf.data_ptr())
-        if tick % sync_every == sync_every - 1 and int(n_done.item()) == N:  # occasional host sync
+    # Finished chains are dropped from the callable's batch: when an occasional host sync shows that
+    # fewer than 3/4 of the current rows are still running, the device compacts the row list and
+    # gathers the pending positions into a smaller batch (two buffers, swapped at each compaction).
+    n_rows = N
+    rows_buf = [torch.empty(N, **i32), torch.empty(N, **i32)]
+    qf_buf = [qf, None]
+    src_work = torch.empty(N, **i32)
+    n_out = torch.zeros(1, **i32)
+    cur = 0
+
+    def chunk(qf, logp_f, gf):
+        """``sync_every`` ticks, each followed by the callable on the current batch."""
+        for _ in range(sync_every):
+            _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref, qf.data_ptr(),
+                      logp_f.data_ptr(), gf.data_ptr())
+            logp_f, gf = eval_logdensity(vg, qf)
+        return logp_f, gf
+
+    graph = None  # (CUDAGraph, static logp_f, static gf) for the current batch
+    n_chunks = -(-max_ticks // sync_every)
+    for ci in range(n_chunks):
+        if graph is not None:
+            graph[0].replay()
+        else:
+            logp_f, gf = chunk(qf, logp_f, gf)
+            if use_graph and ci >= 1:
+                # the eager chunks above warmed every kernel and the allocator; recording does not
+                # execute anything, so the chains' state is untouched by the capture
+                lp_s, g_s = logp_f.clone(), gf.clone()
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    lp_e, g_e = chunk(qf, lp_s, g_s)
+                    lp_s.copy_(lp_e)
+                    g_s.copy_(g_e)
+                graph = (cg, lp_s, g_s)
+        n_active = N - int(n_done.item())  # one host sync per chunk
+        if n_active == 0:
             break
-        logp_f, gf = eval_logdensity(vg, qf)
+        if n_active <= n_rows // 2 and n_rows > 64:
+            # drop the finished chains from the batch (device-side compaction + gather)
+            nxt = cur ^ 1
+            if qf_buf[nxt] is None:
+                qf_buf[nxt] = torch.empty_like(qf_buf[0])
+            _lib.call("bjx_nuts_async_compact", stream, dref, rref, qf.data_ptr(),
+                      rows_buf[nxt].data_ptr(), qf_buf[nxt].data_ptr(), src_work.data_ptr(),
+                      n_out.data_ptr())
+            cur, n_rows = nxt, n_active
+            qf = qf_buf[cur][:n_rows]
+            run.rows, run.n_rows = rows_buf[cur].data_ptr(), n_rows
+            logp_f, gf = eval_logdensity(vg, qf)  # the gathered positions, row for row
+            graph = None
     else:
         if int(n_done.item()) != N:
             raise RuntimeError("free-running NUTS did not finish within its tick bound")
@@ -450,6 +501,6 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,
-                        store_positions=store_positions)
+                        store_positions=store_positions, use_graph=use_graph)
 
     return SamplingAlgorithm(init_fn, step_fn, run_fn)

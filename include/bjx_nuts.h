@@ -167,8 +167,13 @@ typedef struct {
                                  buffers nuts->q0 / nuts->g0 point to */
   float* p;                   /* (N,D) momentum buffer; must be the buffer nuts->p0 points to */
   int32_t* t;                 /* (N,) transitions completed per chain, in/out (start at 0) */
-  int32_t* phase;             /* (N,) 0 = start a transition, 1 = a leaf awaits its gradient, 2 = done */
+  int32_t* phase;             /* (N,) 0 = start a transition, 1 = a leaf awaits its gradient, 2 = done,
+                                 3 = subtree complete (transient, between the two kernels of a tick) */
   int32_t* n_done;            /* device counter of chains that completed n_steps transitions */
+  const int32_t* rows;        /* compact row b of (qf, logp_f, gf) belongs to chain rows[b]; NULL = identity.
+                                 Lets the caller drop finished chains from the callable's batch
+                                 (bjx_nuts_async_compact). */
+  int64_t n_rows;             /* number of compact rows (N when rows == NULL) */
   /* per-(transition, chain) records, row-major (n_steps, N[, D]); any of them may be NULL */
   float* out_position;
   float* out_logdensity;
@@ -180,11 +185,18 @@ typedef struct {
   uint8_t* out_is_turning;
 } bjx_nuts_async_t;
 
-/* One tick for all N chains.  logp_f (N,), gf (N,D): callable outputs at qf from the previous tick
- * (ignored by chains in phase 0); qf (N,D): positions whose log-density / gradient the next tick
- * needs (rows of finished chains are left untouched). */
+/* One tick for the chains of the compact rows.  logp_f (n_rows,), gf (n_rows, D): callable outputs at
+ * qf from the previous tick (ignored by chains in phase 0); qf (n_rows, D): positions whose
+ * log-density / gradient the next tick needs (rows of finished chains are left untouched). */
 int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run, float* qf,
                         const float* logp_f, const float* gf);
+
+/* Drop the finished chains (phase 2) from the compact rows, order preserved: rows_out[b'] = chain,
+ * qf_out[b'] = the pending position of that chain (row gathered from qf_in), *n_out = new count.
+ * rows_out / qf_out must not alias run->rows / qf_in.  No host synchronisation. */
+int bjx_nuts_async_compact(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run,
+                           const float* qf_in, int32_t* rows_out, float* qf_out, int32_t* src_work,
+                           int32_t* n_out);
 
 #ifdef __cplusplus
 }

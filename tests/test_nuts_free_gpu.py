@@ -103,3 +103,9 @@ def test_free_running_equals_lockstep_steps_at_scale(dev):
     final2, none_pos, info2 = alg.run(bjx.random.key(9), st0, T, store_positions=False)
     assert none_pos is None and torch.equal(final2.position, final.position)
     assert torch.equal(info2.energy, info.energy)
+    # HIP-graph replay of the tick chunks (and the batch compactions in between) changes nothing
+    alg_g = bjx.nuts(bjx.targets.NealFunnel(), 0.1, torch.ones(D, device=dev), max_num_doublings=8,
+                     use_graph=True)
+    final3, pos3, info3 = alg_g.run(bjx.random.key(9), st0, T)
+    assert torch.equal(pos3, positions) and torch.equal(final3.logdensity_grad, final.logdensity_grad)
+    assert torch.equal(info3.num_integration_steps, info.num_integration_steps)

@@ -41,22 +41,23 @@ torch.cuda.synchronize()
 if args.free_running:
     alg.run(bjx.random.key(5), state, 2, store_positions=False)  # first use of the tick kernel
     tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=8)
-    _lib.set_timer(tick_timer)
+    if not args.use_graph:  # events cannot be recorded while a graph is being captured
+        _lib.set_timer(tick_timer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     state, positions, rinfo = alg.run(bjx.random.key(1), state, args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
-    ticks = tick_timer.seen["bjx_nuts_async_tick"]
-    tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick")
     tot = int(rinfo.num_integration_steps.sum())
     per_chain = rinfo.num_integration_steps.sum(0).float()
+    ticks = tick_timer.seen["bjx_nuts_async_tick"] or int(per_chain.max())
+    tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick") or [float("nan")]
     avg_tick_us = sum(tick_ms) / len(tick_ms) * 1e3
     print(json.dumps({
         "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot / dt, "unit": "chain-leapfrog-steps/s",
         "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
-                   "driver": "free-running chains (alg.run)"},
+                   "driver": "free-running chains (alg.run)", "hip_graph": bool(args.use_graph)},
         "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
         "mean_leapfrogs_per_chain_transition": tot / (N * args.steps),
         "ticks": ticks, "max_chain_total_leapfrogs": int(per_chain.max()),
