@@ -295,6 +295,170 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
 }
 
 // ------------------------------------------------------------------------------------ post
+// Register-resident leaf (diagonal metric, D <= 64 * VEC * NI): the same arithmetic as the general
+// nuts_post_chain below, but every row a leaf needs -- new gradient, metric, end momentum and
+// position, subtree momentum sum, new position -- is requested ONCE, up front, and the three passes
+// plus the fused opening half of the next leaf run out of registers.  A leaf is then a chain of
+// ~4 dependent memory round trips (scalars; rows; checkpoint rows per U-turn level; nothing) instead
+// of ~8, and moves ~12 rows instead of ~23: the tick kernels are latency-bound on exactly that chain.
+template <int VEC, int NI>
+__device__ __forceinline__ bool nuts_post_chain_resident(const bjx_nuts_t& nt, const StepCtx& cx,
+                                                         int64_t c, int64_t b, int32_t depth, int32_t s,
+                                                         float* qf, const float* __restrict__ logp_f,
+                                                         const float* __restrict__ gf, bool fuse_next) {
+  const int lane = threadIdx.x & 63;
+  const int dir = IS(BJX_NUTS_I_DIR, c);
+  const float deps = (float)dir * chain_eps(nt, c);
+  const float h = deps * 0.5f;
+  const int64_t base = c * nt.D;
+  float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+  float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+  float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+  const float* im = nt.imm + c * nt.imm_stride;
+  const float* gn = gf + b * nt.D;
+  float* qn = qf + b * nt.D;
+  float* sm = nt.Smsum + base;
+  // scalars the decisions need, requested together with the rows
+  const float lp = logp_f[b];
+  const float H0 = FS(BJX_NUTS_F_H0, c);
+  const float sw = FS(BJX_NUTS_F_SW, c);
+  const float sslpa = FS(BJX_NUTS_F_SSLPA, c);
+
+  int64_t j0[NI];
+  bool ok[NI];
+  Row<VEC> G[NI], M[NI], P[NI], S[NI], Q[NI], X[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    j0[k] = ((int64_t)lane + 64 * k) * VEC;
+    ok[k] = j0[k] < nt.D;
+    if (ok[k]) {
+      G[k] = ldr<VEC>(gn + j0[k]);
+      M[k] = ldr<VEC>(im + j0[k]);
+      P[k] = ldr<VEC>(fp + j0[k]);
+      Q[k] = ldr<VEC>(fq + j0[k]);
+      X[k] = ldr<VEC>(qn + j0[k]);
+      if (s != 0) S[k] = ldr<VEC>(sm + j0[k]);
+    }
+  }
+  // pass 1: closing half kick, kinetic energy
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        P[k].v[e] = fmaf(h, G[k].v[e], P[k].v[e]);
+        acc += (double)(M[k].v[e] * P[k].v[e]) * (double)P[k].v[e];
+      }
+    }
+  acc = wave_sum(acc);
+  const float ke = 0.5f * (float)acc;
+  const float e_new = -lp + ke;  // hmc_energy (trajectory.py:745-748)
+  float w = H0 - e_new;          // proposal.py:91-95
+  if (w != w) w = -__builtin_inff();
+  const float slpa_new = fminf(w, 0.0f);
+  const bool sdiv = (-w) > nt.divergence_threshold;  // trajectory.py:325
+  bool take;
+  float Wn, Sn;
+  if (s == 0) {
+    take = true;
+    Wn = w;
+    Sn = slpa_new;
+  } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
+    const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
+    const Key kt = key_child(subkey, 1);
+    const float u = key_uniform(key_child(kt, (uint64_t)s));
+    const Scalars3 sc = scalars3(-(double)(w - sw), sw, w, sslpa, slpa_new);
+    take = u < sc.r0;
+    Wn = sc.lae1;
+    Sn = sc.lae2;
+  }
+  const uint32_t us = (uint32_t)s;  // checkpoint indices (termination.py:75-84)
+  const int idx_max = __popc(us >> 1);
+  const int nsub = __popc((~us & (us + 1u)) - 1u);
+  const int idx_min = idx_max - nsub + 1;
+  const bool even = (us & 1u) == 0u;
+
+  // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
+  float* ckr = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+  float* ckrs = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      if (s != 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) S[k].v[e] = S[k].v[e] + P[k].v[e];
+      } else {
+        S[k] = P[k];
+      }
+      str<VEC>(sm + j0[k], S[k]);
+      str<VEC>(fg + j0[k], G[k]);
+      if (even) {
+        str<VEC>(ckr + j0[k], P[k]);
+        str<VEC>(ckrs + j0[k], S[k]);
+      }
+      if (take) {
+        str<VEC>(nt.Sq + base + j0[k], X[k]);
+        str<VEC>(nt.Sg + base + j0[k], G[k]);
+      }
+    }
+
+  // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (odd leaves only, so none of
+  // them was written by this leaf)
+  bool turning = false;
+  for (int i = idx_max; i >= idx_min && !turning; --i) {
+    const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
+    const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
+    double a_left = 0.0, a_right = 0.0;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        const Row<VEC> rl = ldr<VEC>(r_ck + j0[k]), rs = ldr<VEC>(rs_ck + j0[k]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float ssum = (S[k].v[e] - rs.v[e]) + rl.v[e];
+          const float rho = ssum - (P[k].v[e] + rl.v[e]) * 0.5f;  // metrics.py:300
+          a_left += (double)(M[k].v[e] * rl.v[e]) * (double)rho;
+          a_right += (double)(M[k].v[e] * P[k].v[e]) * (double)rho;
+        }
+      }
+    a_left = wave_sum(a_left);
+    a_right = wave_sum(a_right);
+    turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+  }
+  const bool stop = sdiv || turning;
+  if (lane == 0) {
+    FS(dir > 0 ? BJX_NUTS_F_RLOGP : BJX_NUTS_F_LLOGP, c) = lp;
+    FS(BJX_NUTS_F_SW, c) = Wn;
+    FS(BJX_NUTS_F_SSLPA, c) = Sn;
+    if (take) {
+      FS(BJX_NUTS_F_SLOGP, c) = lp;
+      FS(BJX_NUTS_F_SENERGY, c) = e_new;
+    }
+    IS(BJX_NUTS_I_SUBN, c) = s + 1;
+    IS(BJX_NUTS_I_SDIV, c) = sdiv ? 1 : 0;
+    IS(BJX_NUTS_I_STURN, c) = turning ? 1 : 0;
+    if (stop) IS(BJX_NUTS_I_SUB_ACTIVE, c) = 0;
+  }
+  // end momentum: as kicked by this leaf, or already carrying the opening half of the next one
+  const bool open_next = fuse_next && !stop;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      if (open_next) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          P[k].v[e] = fmaf(h, G[k].v[e], P[k].v[e]);
+          Q[k].v[e] = fmaf(deps, M[k].v[e] * P[k].v[e], Q[k].v[e]);
+        }
+        str<VEC>(fq + j0[k], Q[k]);
+        str<VEC>(qn + j0[k], Q[k]);
+      }
+      str<VEC>(fp + j0[k], P[k]);
+    }
+  return stop;
+}
+
 // Second half of leaf s of doubling `depth` for chain c, whose new position / log-density /
 // gradient sit in row b of (qf, logp_f, gf): closing kick, energy, progressive sampling,
 // momentum-sum append, checkpoint store, iterative U-turn (trajectory.py:242-395,
@@ -478,6 +642,22 @@ k_nuts_post(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
   }
 }
 
+// same launch contract, register-resident leaf (diagonal metric, 16-byte rows, D <= 256 * NI)
+template <int NI>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_post_res(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
+                const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl, float* qf,
+                const float* __restrict__ logp_f, const float* __restrict__ gf, int fuse_next) {
+  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
+  const int32_t depth = cx.depth, s = cx.s;
+  const int64_t n_rows = cx.n_rows;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+    nuts_post_chain_resident<4, NI>(nt, cx, c, b, depth, s, qf, logp_f, gf, fuse_next != 0);
+  }
+}
+
 // ------------------------------------------------------------------------------------ merge
 // End of doubling `depth` for chain c: biased progressive sampling of the new subtree's proposal,
 // momentum-sum merge, U-turn of the whole trajectory, stop flags (trajectory.py:680-727,
@@ -625,7 +805,8 @@ __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax,
 // Tick, part 1 (every chain with a leaf in flight, phase 1): the second half of the leaf and, when
 // the subtree keeps integrating, the fused opening half of the next leaf.  A chain whose subtree is
 // complete moves to phase 3 and is finished by part 2.
-template <int VEC>
+// NI = 0: general sweeps; NI > 0: register-resident leaf (VEC == 4, D <= 256 * NI)
+template <int VEC, int NI>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
@@ -635,7 +816,9 @@ k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __
     const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
     const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
     const bool last = (s + 1) >= (1 << depth);
-    const bool stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
+    bool stop;
+    if constexpr (NI > 0) stop = nuts_post_chain_resident<VEC, NI>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
+    else stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
     if ((stop || last) && lane == 0) ax.phase[c] = 3;
   });
 }
@@ -844,6 +1027,13 @@ bool nuts_vec4(const bjx_nuts_t* nt, P... extra) {
                      nt->ckpt_rs, extra...);
 }
 
+// rows per lane of the register-resident leaf (0 = use the general sweeps)
+template <typename... P>
+int nuts_resident_ni(const bjx_nuts_t* nt, P... extra) {
+  if (!nuts_vec4(nt, extra...)) return 0;
+  return nt->D <= 256 ? 1 : (nt->D <= 512 ? 2 : 0);
+}
+
 // pick the <VEC, DENSE> instantiation of a kernel template
 #define BJX_NUTS_LAUNCH(KERNEL, grid, stream, vec4, dense, ...)                                        \
   do {                                                                                                 \
@@ -900,10 +1090,18 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
                 "bjx_nuts_post: bad arguments");
   if (n_rows == 0) return 0;
   const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
-  BJX_NUTS_LAUNCH(k_nuts_post, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf),
-                  nuts->Mdense != nullptr, *nuts, depth, (int32_t)s, n_rows, idx,
-                  (const int64_t*)nullptr, qf, logp_f, gf,
-                  (int)(fuse_next && s + 1 < ((int64_t)1 << depth)));
+  const int fuse = (int)(fuse_next && s + 1 < ((int64_t)1 << depth));
+  const int ni = nuts_resident_ni(nuts, qf, gf);
+  hipStream_t st = (hipStream_t)stream;
+  if (ni == 1)
+    hipLaunchKernelGGL(k_nuts_post_res<1>, grid, dim3(kBlock), 0, st, *nuts, depth, (int32_t)s, n_rows, idx,
+                       (const int64_t*)nullptr, qf, logp_f, gf, fuse);
+  else if (ni == 2)
+    hipLaunchKernelGGL(k_nuts_post_res<2>, grid, dim3(kBlock), 0, st, *nuts, depth, (int32_t)s, n_rows, idx,
+                       (const int64_t*)nullptr, qf, logp_f, gf, fuse);
+  else
+    BJX_NUTS_LAUNCH(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr, *nuts, depth,
+                    (int32_t)s, n_rows, idx, (const int64_t*)nullptr, qf, logp_f, gf, fuse);
   return bjx_check_launch("bjx_nuts_post");
 }
 
@@ -915,9 +1113,17 @@ int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64
                 "bjx_nuts_post_ctl: bad arguments");
   if (n_cap == 0) return 0;
   const dim3 grid(bjx_row_grid(n_cap, kWavesPerBlock));
-  BJX_NUTS_LAUNCH(k_nuts_post, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf),
-                  nuts->Mdense != nullptr, *nuts, 0, s_off, n_cap, idx, ctl, qf, logp_f, gf,
-                  (int)fuse_next);
+  const int ni = nuts_resident_ni(nuts, qf, gf);
+  hipStream_t st = (hipStream_t)stream;
+  if (ni == 1)
+    hipLaunchKernelGGL(k_nuts_post_res<1>, grid, dim3(kBlock), 0, st, *nuts, 0, s_off, n_cap, idx, ctl, qf,
+                       logp_f, gf, (int)fuse_next);
+  else if (ni == 2)
+    hipLaunchKernelGGL(k_nuts_post_res<2>, grid, dim3(kBlock), 0, st, *nuts, 0, s_off, n_cap, idx, ctl, qf,
+                       logp_f, gf, (int)fuse_next);
+  else
+    BJX_NUTS_LAUNCH(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr, *nuts, 0, s_off,
+                    n_cap, idx, ctl, qf, logp_f, gf, (int)fuse_next);
   return bjx_check_launch("bjx_nuts_post_ctl");
 }
 
@@ -970,10 +1176,13 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
   if (nuts_vec4(nuts, qf, gf, run->out_position)) {
-    hipLaunchKernelGGL(k_nuts_async_leaf<4>, grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    const int ni = nuts_resident_ni(nuts, qf, gf);
+    if (ni == 1) hipLaunchKernelGGL((k_nuts_async_leaf<4, 1>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_leaf<4, 2>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    else hipLaunchKernelGGL((k_nuts_async_leaf<4, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
     hipLaunchKernelGGL(k_nuts_async_boundary<4>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
   } else {
-    hipLaunchKernelGGL(k_nuts_async_leaf<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    hipLaunchKernelGGL((k_nuts_async_leaf<1, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
     hipLaunchKernelGGL(k_nuts_async_boundary<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
   }
   return bjx_check_launch("bjx_nuts_async_tick");
