@@ -806,30 +806,39 @@ __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax,
 // the subtree keeps integrating, the fused opening half of the next leaf.  A chain whose subtree is
 // complete moves to phase 3 and is finished by part 2.
 // NI = 0: general sweeps; NI > 0: register-resident leaf (VEC == 4, D <= 256 * NI)
+// Returns true when the chain's subtree is complete (phase 3 written).
+template <int VEC, int NI>
+__device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
+                                                 float* qf, const float* __restrict__ logp_f,
+                                                 const float* __restrict__ gf, int64_t c, int64_t b) {
+  const int lane = threadIdx.x & 63;
+  const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
+  const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
+  const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
+  const bool last = (s + 1) >= (1 << depth);
+  bool stop;
+  if constexpr (NI > 0) stop = nuts_post_chain_resident<VEC, NI>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
+  else stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
+  if ((stop || last) && lane == 0) ax.phase[c] = 3;
+  return stop || last;
+}
+
 template <int VEC, int NI>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
-  const int lane = threadIdx.x & 63;
   async_for_each_chain(ax, 1, 1, [&](int64_t c, int64_t b, int) {
-    const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
-    const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
-    const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
-    const bool last = (s + 1) >= (1 << depth);
-    bool stop;
-    if constexpr (NI > 0) stop = nuts_post_chain_resident<VEC, NI>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
-    else stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
-    if ((stop || last) && lane == 0) ax.phase[c] = 3;
+    async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b);
   });
 }
 
 // Tick, part 2 (phase 3: subtree complete; phase 0: start a transition): merge, then either the
 // next doubling, or record the finished transition, accept its proposal and start the next one.
 template <int VEC>
-__global__ void __launch_bounds__(kBlock)
-k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
+__device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
+                                                     float* qf, int64_t c, int64_t b, int phase) {
   const int lane = threadIdx.x & 63;
-  async_for_each_chain(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
+  {
     int32_t t = ax.t[c];
     StepCtx cx = async_ctx(nt, ax, t);
     const int64_t base = c * nt.D;
@@ -903,6 +912,31 @@ k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
     nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
                                qrow);
     if (lane == 0) ax.phase[c] = 1;
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
+  async_for_each_chain(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
+    async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
+  });
+}
+
+// Both parts in one launch, for ticks with few live chains (the long tail of a run, where a tick is
+// bound by its dependent launches, not by the work): leaf, then -- same wave, after a fence -- the
+// boundary work the leaf may have produced.
+template <int VEC, int NI>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                   const float* __restrict__ gf) {
+  async_for_each_chain(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
+    if (phase == 1) {
+      if (!async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b)) return;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      phase = 3;
+    }
+    async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
   });
 }
 
@@ -1175,7 +1209,17 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
-  if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+  const bool fused = run->n_rows <= 2048;  // few rows: one launch per tick (latency), not two (occupancy)
+  if (fused) {
+    if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+      const int ni = nuts_resident_ni(nuts, qf, gf);
+      if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      else hipLaunchKernelGGL((k_nuts_async_fused<4, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    } else {
+      hipLaunchKernelGGL((k_nuts_async_fused<1, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    }
+  } else if (nuts_vec4(nuts, qf, gf, run->out_position)) {
     const int ni = nuts_resident_ni(nuts, qf, gf);
     if (ni == 1) hipLaunchKernelGGL((k_nuts_async_leaf<4, 1>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
     else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_leaf<4, 2>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
