@@ -824,7 +824,7 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
 }
 
 template <int VEC, int NI>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
   async_for_each_chain(ax, 1, 1, [&](int64_t c, int64_t b, int) {
@@ -916,7 +916,7 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
 }
 
 template <int VEC>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
   async_for_each_chain(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
     async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
