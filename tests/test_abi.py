@@ -75,3 +75,15 @@ def test_nuts_descriptor_and_slots_match_header():
     py = [f[0].rstrip("_") for f in _lib.NutsDesc._fields_]
     assert names == py, (names, py)
     assert ctypes.sizeof(_lib.NutsDesc) == 8 * 2 + 4 * 2 + 8 * 3 + 4 * 2 + 4 * 2 + 8 * 2 + 8 * 19 + 8 * 6
+    # the free-running run descriptor
+    body = re.search(r"typedef struct \{([^}]*?)\} bjx_nuts_async_t;", text_nc, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int64_t|int32_t|uint32_t|uint8_t|float)\s*\*?", "", decl)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    py = [f[0] for f in _lib.NutsAsync._fields_]
+    assert names == py, (names, py)
+    assert ctypes.sizeof(_lib.NutsAsync) == 8 + 4 * 2 + 8 * 7 + 8 * 2 + 8 * 8
