@@ -103,6 +103,8 @@ def main():
                     help="skip the extra all-chains-at-once (HBM streaming) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="bracket every k-th leapfrog launch with HIP events (0 = 16 for short launches, else 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,9 +158,13 @@ def main():
                       use_graph=use_graph)
         state = alg.init(q_init)
         launches = L * ((N + chain_block - 1) // chain_block)
-        every = 4 if launches >= 100 else 1
+        # Sampling rate of the HIP-event brackets.  A bracket costs host time and drains the
+        # queue around the launch; at ~50 us launches, bracketing every 4th one slowed the whole
+        # timed region by 13 % (16.4 vs 14.5 ms per transition), so short launches are sampled sparsely.
+        every = args.time_every or (16 if launches >= 100 else 1)
         timing = not args.no_launch_timing and not use_graph  # events cannot be recorded inside a graph
-        warm_timer = _lib.LaunchTimer([timed_kernel], every) if timing else None
+        cap = (launches // every + 1) * (max(args.steps, args.warmup + 1))
+        warm_timer = _lib.LaunchTimer([timed_kernel], every, cap) if timing else None
         _lib.set_timer(warm_timer)
         warm_acc = torch.zeros((), device=dev)
         prime_key = bjx.random.key(12345)
@@ -173,7 +179,8 @@ def main():
 
         timer = None
         if timing and rank == 0:
-            timer = _lib.LaunchTimer([timed_kernel], every)
+            timer = _lib.LaunchTimer([timed_kernel], every, cap)
+            torch.cuda.synchronize()
             _lib.set_timer(timer)
         acc_sum = torch.zeros((), device=dev)
         draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
@@ -199,7 +206,10 @@ def main():
             avg_s = float(np.mean(d_ms)) * 1e-3
             alg_bytes = 20.0 * D * min(chain_block, N)  # read p,g,q ; write p,q (imm (D,) is shared and cached)
             achieved = alg_bytes / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "k_leapfrog_diag<4,2>", "achieved": achieved,
+            # bjx_leapfrog_diag dispatches rows of a multiple of 1 024 floats to the flat kernel
+            flat = D % 1024 == 0 and os.environ.get("BJX_LF_FLAT", "1") != "0"
+            roof = {"bound": "hbm", "kernel": "k_leapfrog_diag_flat<2>" if flat else "k_leapfrog_diag<4,2>",
+                    "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                     "chains_per_launch": min(chain_block, N), "avg_launch_us": avg_s * 1e6,

@@ -204,13 +204,25 @@ class LaunchTimer:
     """Brackets selected entry points with HIP events on the current stream so a caller
     (bench.py) can read per-launch kernel durations of the timed region afterwards."""
 
-    def __init__(self, names, every: int = 1):
-        """``every``: bracket only every k-th launch of each name (two event records cost a few
-        microseconds of host time, which matters once launches are ~50 us)."""
+    def __init__(self, names, every: int = 1, capacity: int = 0):
+        """``every``: bracket only every k-th launch of each name (two event records cost host
+        time, which matters once launches are ~50 us).  ``capacity``: number of brackets whose
+        events are created up front, outside the timed region (creating an event costs more than
+        recording it); brackets beyond the pool create theirs on the fly."""
+        import torch
+
         self.names = set(names)
         self.events = {n: [] for n in self.names}
         self.every = max(1, int(every))
         self.seen = {n: 0 for n in self.names}
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max(0, int(capacity)))]
+        for ev in self.pool:  # torch creates the HIP event lazily, at the first record()
+            ev.record()
+
+    def take_event(self):
+        import torch
+
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     def durations_ms(self, name):
         import torch
@@ -234,10 +246,8 @@ def call(name: str, *args) -> None:
         _timer.seen[name] += 1
         timed = _timer.seen[name] % _timer.every == 0
     if timed:
-        import torch
-
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
+        s = _timer.take_event()
+        e = _timer.take_event()
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()

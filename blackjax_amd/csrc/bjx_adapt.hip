@@ -75,21 +75,28 @@ k_welford_update_diag(int64_t N, int64_t D, float n, const float* __restrict__ x
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const int64_t base = r * D;
     if constexpr (VEC == 4) {
-#pragma unroll 4
-      for (int64_t j = (int64_t)lane * 4; j < D; j += 256) {
-        const F4 xv = ld4(x + base + j), mv = ld4(mean_in + base + j), sv = ld4(m2_in + base + j);
-        F4 mo, so;
+      F4 xs[4], ms[4], ss[4];
+      row_sweep4<4>(
+          lane, D,
+          [&](int u, int64_t j) {
+            xs[u] = ld4(x + base + j);
+            ms[u] = ld4(mean_in + base + j);
+            ss[u] = ld4(m2_in + base + j);
+          },
+          [&](int u, int64_t j) {
+            const F4 xv = xs[u], mv = ms[u], sv = ss[u];
+            F4 mo, so;
 #define BJX_W(c)                                   \
   {                                                \
     const float d = xv.c - mv.c;                   \
     mo.c = mv.c + d / n;                           \
     so.c = fmaf(d, xv.c - mo.c, sv.c);             \
   }
-        BJX_W(x) BJX_W(y) BJX_W(z) BJX_W(w)
+            BJX_W(x) BJX_W(y) BJX_W(z) BJX_W(w)
 #undef BJX_W
-        st4(mean_out + base + j, mo);
-        st4(m2_out + base + j, so);
-      }
+            st4(mean_out + base + j, mo);
+            st4(m2_out + base + j, so);
+          });
     } else {
       for (int64_t j = lane; j < D; j += 64) {
         const float xv = x[base + j], mv = mean_in[base + j];

@@ -135,4 +135,25 @@ struct alignas(16) F4 {
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) = v; }
 
+// One wavefront sweeps a row of D floats (D % 4 == 0) 16 bytes per lane: for every span of
+// U x 1 KB, `load(u, j)` is called for all its 16-byte pieces first and `body(u, j)` afterwards,
+// both in ascending j (so fp64 accumulations keep their order).  Written this way because a loop
+// with a run-time trip count -- or with stores that may alias later loads -- leaves only 2-4
+// loads in flight per lane; here U x (loads per piece) are.
+template <int U, typename Load, typename Body>
+__device__ __forceinline__ void row_sweep4(int lane, int64_t D, Load&& load, Body&& body) {
+  for (int64_t j0 = (int64_t)lane * 4; j0 < D; j0 += 256 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = j0 + 256 * u;
+      if (j < D) load(u, j);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = j0 + 256 * u;
+      if (j < D) body(u, j);
+    }
+  }
+}
+
 }  // namespace bjx

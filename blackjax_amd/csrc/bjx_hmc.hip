@@ -113,23 +113,39 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
     const float ed = eps * drift;   // step_size * coef (integrators.py:200)
     const float* im = imm + r * imm_stride;
     if constexpr (VEC == 4) {
-#pragma unroll 4
-      for (int64_t j = (int64_t)lane * 4; j < D; j += 256) {
-        const F4 pp = ld4(p_in + base + j);
-        const F4 gg = ld4(g + base + j);
-        const F4 qq = ld4(q_in + base + j);
-        const F4 mm = ld4(im + j);
-        F4 pn, qn;
-        pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
-        pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
-        if constexpr (KICKS == 2) {
-          pn.x = fmaf(h2, gg.x, pn.x); pn.y = fmaf(h2, gg.y, pn.y);
-          pn.z = fmaf(h2, gg.z, pn.z); pn.w = fmaf(h2, gg.w, pn.w);
+      // The launch is usually in place (q_out == q_in, p_out == p_in), so the compiler may not move
+      // a load above an earlier store: all loads of a 4 KB span are issued first, in program
+      // order, then the arithmetic and the stores -- 16 x 16 B in flight per lane instead of 2.
+      constexpr int U = 4;
+      for (int64_t j0 = (int64_t)lane * 4; j0 < D; j0 += 256 * U) {
+        F4 pp[U], gg[U], qq[U], mm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = j0 + 256 * u;
+          if (j < D) {
+            pp[u] = ld4(p_in + base + j);
+            gg[u] = ld4(g + base + j);
+            qq[u] = ld4(q_in + base + j);
+            mm[u] = ld4(im + j);
+          }
         }
-        qn.x = fmaf(ed, mm.x * pn.x, qq.x); qn.y = fmaf(ed, mm.y * pn.y, qq.y);
-        qn.z = fmaf(ed, mm.z * pn.z, qq.z); qn.w = fmaf(ed, mm.w * pn.w, qq.w);
-        st4(p_out + base + j, pn);
-        st4(q_out + base + j, qn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = j0 + 256 * u;
+          if (j < D) {
+            F4 pn, qn;
+            pn.x = fmaf(h, gg[u].x, pp[u].x); pn.y = fmaf(h, gg[u].y, pp[u].y);
+            pn.z = fmaf(h, gg[u].z, pp[u].z); pn.w = fmaf(h, gg[u].w, pp[u].w);
+            if constexpr (KICKS == 2) {
+              pn.x = fmaf(h2, gg[u].x, pn.x); pn.y = fmaf(h2, gg[u].y, pn.y);
+              pn.z = fmaf(h2, gg[u].z, pn.z); pn.w = fmaf(h2, gg[u].w, pn.w);
+            }
+            qn.x = fmaf(ed, mm[u].x * pn.x, qq[u].x); qn.y = fmaf(ed, mm[u].y * pn.y, qq[u].y);
+            qn.z = fmaf(ed, mm[u].z * pn.z, qq[u].z); qn.w = fmaf(ed, mm[u].w * pn.w, qq[u].w);
+            st4(p_out + base + j, pn);
+            st4(q_out + base + j, qn);
+          }
+        }
       }
     } else {
       for (int64_t j = lane; j < D; j += 64) {
@@ -141,6 +157,47 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
       }
     }
   }
+}
+
+// Same stage, one 16-byte piece per lane and no loop: for rows that are a multiple of 1 KB floats
+// (D % 1024 == 0) a workgroup owns one 4 KB span of one row, so the row index is workgroup-uniform.
+// The leapfrog needs no row reduction, and many short waves fill the chip more evenly than one
+// wave per row (measured on pseudo-random data, tools/lf_variants: 46.6 vs 48.3 us for 16 384 rows
+// of 1 024, 233 vs 241 us for 65 536).  Workgroups are numbered from the END of the arrays for the
+// same Infinity-Cache reason as above.
+template <int KICKS>
+__global__ void __launch_bounds__(kBlock)
+k_leapfrog_diag_flat(int64_t D, int bpr, float eps_s, const float* __restrict__ eps_pc,
+                     const float* __restrict__ imm, int64_t imm_stride, const float* q_in,
+                     const float* p_in, const float* __restrict__ g, float* q_out, float* p_out,
+                     const int32_t* __restrict__ n_steps, int32_t step_idx, float kick_a, float kick_b,
+                     float drift) {
+  const unsigned b = BJX_REVERSE_ROWS ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const int64_t r = b / (unsigned)bpr;
+  const int64_t j = (int64_t)(b - (unsigned)r * (unsigned)bpr) * 1024 + threadIdx.x * 4;
+  const int64_t at = r * D + j;
+  if (n_steps && step_idx >= n_steps[r]) {
+    if (q_out != q_in) {
+      st4(q_out + at, ld4(q_in + at));
+      st4(p_out + at, ld4(p_in + at));
+    }
+    return;
+  }
+  const float eps = eps_pc ? eps_pc[r] : eps_s;
+  const float h = eps * kick_a, h2 = eps * kick_b, ed = eps * drift;
+  const F4 pp = ld4(p_in + at), gg = ld4(g + at), qq = ld4(q_in + at);
+  const F4 mm = ld4(imm + r * imm_stride + j);
+  F4 pn, qn;
+  pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
+  pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
+  if constexpr (KICKS == 2) {
+    pn.x = fmaf(h2, gg.x, pn.x); pn.y = fmaf(h2, gg.y, pn.y);
+    pn.z = fmaf(h2, gg.z, pn.z); pn.w = fmaf(h2, gg.w, pn.w);
+  }
+  qn.x = fmaf(ed, mm.x * pn.x, qq.x); qn.y = fmaf(ed, mm.y * pn.y, qq.y);
+  qn.z = fmaf(ed, mm.z * pn.z, qq.z); qn.w = fmaf(ed, mm.w * pn.w, qq.w);
+  st4(p_out + at, pn);
+  st4(q_out + at, qn);
 }
 
 // ------------------------------------------------------------------------------ finish
@@ -164,20 +221,27 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, floa
     const float* im = imm + r * imm_stride;
     double acc = 0.0;
     // pass 1: closing half kick, flipped momentum out, kinetic energy
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
-      if constexpr (VEC == 4) {
-        const F4 pp = ld4(p + base + j);
-        const F4 gg = ld4(g1 + base + j);
-        const F4 mm = ld4(im + j);
-        F4 pn;
-        pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
-        pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
-        acc += (double)(mm.x * pn.x) * (double)pn.x;
-        acc += (double)(mm.y * pn.y) * (double)pn.y;
-        acc += (double)(mm.z * pn.z) * (double)pn.z;
-        acc += (double)(mm.w * pn.w) * (double)pn.w;
-        if (p_end) st4(p_end + base + j, F4{-1.0f * pn.x, -1.0f * pn.y, -1.0f * pn.z, -1.0f * pn.w});
-      } else {
+    if constexpr (VEC == 4) {
+      F4 pp[4], gg[4], mm[4];
+      row_sweep4<4>(
+          lane, D,
+          [&](int u, int64_t j) {
+            pp[u] = ld4(p + base + j);
+            gg[u] = ld4(g1 + base + j);
+            mm[u] = ld4(im + j);
+          },
+          [&](int u, int64_t j) {
+            F4 pn;
+            pn.x = fmaf(h, gg[u].x, pp[u].x); pn.y = fmaf(h, gg[u].y, pp[u].y);
+            pn.z = fmaf(h, gg[u].z, pp[u].z); pn.w = fmaf(h, gg[u].w, pp[u].w);
+            acc += (double)(mm[u].x * pn.x) * (double)pn.x;
+            acc += (double)(mm[u].y * pn.y) * (double)pn.y;
+            acc += (double)(mm[u].z * pn.z) * (double)pn.z;
+            acc += (double)(mm[u].w * pn.w) * (double)pn.w;
+            if (p_end) st4(p_end + base + j, F4{-1.0f * pn.x, -1.0f * pn.y, -1.0f * pn.z, -1.0f * pn.w});
+          });
+    } else {
+      for (int64_t j = lane; j < D; j += 64) {
         const float pn = fmaf(h, g1[base + j], p[base + j]);
         acc += (double)(im[j] * pn) * (double)pn;
         if (p_end) p_end[base + j] = -1.0f * pn;
@@ -206,13 +270,20 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, floa
     // pass 2: select the new state (wave-uniform source)
     const float* qs = accept ? q1 : q0;
     const float* gs = accept ? g1 : g0;
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
-      if constexpr (VEC == 4) {
-        const F4 a = ld4(qs + base + j);
-        const F4 b = ld4(gs + base + j);
-        st4(q_out + base + j, a);
-        st4(g_out + base + j, b);
-      } else {
+    if constexpr (VEC == 4) {
+      F4 a[4], b[4];
+      row_sweep4<4>(
+          lane, D,
+          [&](int u, int64_t j) {
+            a[u] = ld4(qs + base + j);
+            b[u] = ld4(gs + base + j);
+          },
+          [&](int u, int64_t j) {
+            st4(q_out + base + j, a[u]);
+            st4(g_out + base + j, b[u]);
+          });
+    } else {
+      for (int64_t j = lane; j < D; j += 64) {
         q_out[base + j] = qs[base + j];
         g_out[base + j] = gs[base + j];
       }
@@ -243,14 +314,23 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
     const int64_t base = r * D;
     const float* im = imm + r * imm_stride;
     double acc = 0.0;
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
-      if constexpr (VEC == 4) {
-        const F4 pp = ld4(p + base + j), gg = ld4(g + base + j), mm = ld4(im + j);
-        const float a = fmaf(h, gg.x, pp.x), b = fmaf(h, gg.y, pp.y);
-        const float c = fmaf(h, gg.z, pp.z), d = fmaf(h, gg.w, pp.w);
-        acc += (double)(mm.x * a) * (double)a + (double)(mm.y * b) * (double)b;
-        acc += (double)(mm.z * c) * (double)c + (double)(mm.w * d) * (double)d;
-      } else {
+    if constexpr (VEC == 4) {
+      F4 pp[4], gg[4], mm[4];
+      row_sweep4<4>(
+          lane, D,
+          [&](int u, int64_t j) {
+            pp[u] = ld4(p + base + j);
+            gg[u] = ld4(g + base + j);
+            mm[u] = ld4(im + j);
+          },
+          [&](int u, int64_t) {
+            const float a = fmaf(h, gg[u].x, pp[u].x), b = fmaf(h, gg[u].y, pp[u].y);
+            const float c = fmaf(h, gg[u].z, pp[u].z), d = fmaf(h, gg[u].w, pp[u].w);
+            acc += (double)(mm[u].x * a) * (double)a + (double)(mm[u].y * b) * (double)b;
+            acc += (double)(mm[u].z * c) * (double)c + (double)(mm[u].w * d) * (double)d;
+          });
+    } else {
+      for (int64_t j = lane; j < D; j += 64) {
         const float a = fmaf(h, g[base + j], p[base + j]);
         acc += (double)(im[j] * a) * (double)a;
       }
@@ -289,24 +369,35 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
         Renergy[r] = e_new;
       }
     }
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
-      if constexpr (VEC == 4) {
-        const F4 pp = ld4(p + base + j), gg = ld4(g + base + j), qq = ld4(q + base + j);
-        F4 pf{fmaf(h, gg.x, pp.x), fmaf(h, gg.y, pp.y), fmaf(h, gg.z, pp.z), fmaf(h, gg.w, pp.w)};
-        if (take) {
-          st4(Rq + base + j, qq);
-          st4(Rp + base + j, pf);
-          st4(Rg + base + j, gg);
-        }
-        if (do_next) {
-          const F4 mm = ld4(im + j);
-          F4 pn{fmaf(h, gg.x, pf.x), fmaf(h, gg.y, pf.y), fmaf(h, gg.z, pf.z), fmaf(h, gg.w, pf.w)};
-          F4 qn{fmaf(eps, mm.x * pn.x, qq.x), fmaf(eps, mm.y * pn.y, qq.y),
-                fmaf(eps, mm.z * pn.z, qq.z), fmaf(eps, mm.w * pn.w, qq.w)};
-          st4(p + base + j, pn);
-          st4(q + base + j, qn);
-        }
-      } else {
+    if constexpr (VEC == 4) {
+      F4 pp[4], gg[4], qq[4], mm[4];
+      row_sweep4<4>(
+          lane, D,
+          [&](int u, int64_t j) {
+            pp[u] = ld4(p + base + j);
+            gg[u] = ld4(g + base + j);
+            qq[u] = ld4(q + base + j);
+            if (do_next) mm[u] = ld4(im + j);
+          },
+          [&](int u, int64_t j) {
+            const F4 G = gg[u], Q = qq[u];
+            F4 pf{fmaf(h, G.x, pp[u].x), fmaf(h, G.y, pp[u].y), fmaf(h, G.z, pp[u].z), fmaf(h, G.w, pp[u].w)};
+            if (take) {
+              st4(Rq + base + j, Q);
+              st4(Rp + base + j, pf);
+              st4(Rg + base + j, G);
+            }
+            if (do_next) {
+              const F4 M = mm[u];
+              F4 pn{fmaf(h, G.x, pf.x), fmaf(h, G.y, pf.y), fmaf(h, G.z, pf.z), fmaf(h, G.w, pf.w)};
+              F4 qn{fmaf(eps, M.x * pn.x, Q.x), fmaf(eps, M.y * pn.y, Q.y),
+                    fmaf(eps, M.z * pn.z, Q.z), fmaf(eps, M.w * pn.w, Q.w)};
+              st4(p + base + j, pn);
+              st4(q + base + j, qn);
+            }
+          });
+    } else {
+      for (int64_t j = lane; j < D; j += 64) {
         const float gg = g[base + j], qq = q[base + j];
         const float pf = fmaf(h, gg, p[base + j]);
         if (take) {
@@ -406,7 +497,21 @@ int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, floa
   hipLaunchKernelGGL((k_leapfrog_diag<V, K>), grid, block, 0, s, N, D, eps, eps_per_chain, imm, \
                      imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b,  \
                      drift)
-  if (bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
+  static const bool flat_ok = [] {
+    const char* e = getenv("BJX_LF_FLAT");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (flat_ok && D % 1024 == 0 && N * (D / 1024) < ((int64_t)1 << 31) &&
+      bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
+    const int bpr = (int)(D / 1024);
+    const dim3 fgrid((unsigned)(N * bpr));
+    if (n_kicks == 1)
+      hipLaunchKernelGGL(k_leapfrog_diag_flat<1>, fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm,
+                         imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
+    else
+      hipLaunchKernelGGL(k_leapfrog_diag_flat<2>, fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm,
+                         imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
+  } else if (bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     if (n_kicks == 1) BJX_LF(4, 1); else BJX_LF(4, 2);
   } else {
     if (n_kicks == 1) BJX_LF(1, 1); else BJX_LF(1, 2);

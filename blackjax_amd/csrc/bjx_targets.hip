@@ -28,16 +28,31 @@ k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float*
     const int64_t base = r * D;
     double acc = 0.0;
     if constexpr (VEC == 4) {
-#pragma unroll 4
-      for (int64_t j = (int64_t)lane * 4; j < D; j += 256) {
-        const F4 qq = ld4(q + base + j);
-        const F4 vv = ld4(iv + j);
-        F4 gg{-(qq.x * vv.x), -(qq.y * vv.y), -(qq.z * vv.z), -(qq.w * vv.w)};
-        acc += (double)qq.x * (double)gg.x;
-        acc += (double)qq.y * (double)gg.y;
-        acc += (double)qq.z * (double)gg.z;
-        acc += (double)qq.w * (double)gg.w;
-        st4(g + base + j, gg);
+      // all loads of a 4 KB span first (a loop with a run-time trip count is not batched by the
+      // compiler: it keeps 2 loads in flight per lane), then arithmetic and stores in the same order
+      constexpr int U = 4;
+      for (int64_t j0 = (int64_t)lane * 4; j0 < D; j0 += 256 * U) {
+        F4 qq[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = j0 + 256 * u;
+          if (j < D) {
+            qq[u] = ld4(q + base + j);
+            vv[u] = ld4(iv + j);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = j0 + 256 * u;
+          if (j < D) {
+            F4 gg{-(qq[u].x * vv[u].x), -(qq[u].y * vv[u].y), -(qq[u].z * vv[u].z), -(qq[u].w * vv[u].w)};
+            acc += (double)qq[u].x * (double)gg.x;
+            acc += (double)qq[u].y * (double)gg.y;
+            acc += (double)qq[u].z * (double)gg.z;
+            acc += (double)qq[u].w * (double)gg.w;
+            st4(g + base + j, gg);
+          }
+        }
       }
     } else {
       for (int64_t j = lane; j < D; j += 64) {

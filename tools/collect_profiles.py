@@ -15,7 +15,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "round_prof")
-KERNEL = "k_leapfrog_diag<4, 2>"
+KERNEL = "k_leapfrog_diag<4,2>"  # replaced by the bench line's roofline.kernel in main()
+
+
+def is_kernel(name):
+    return KERNEL.replace(" ", "") + "(" in name.replace(" ", "")
 
 
 def counter_avg(sub, counter):
@@ -23,18 +27,21 @@ def counter_avg(sub, counter):
     f = sorted(glob.glob(os.path.join(SRC, sub, "*", "*counter_collection.csv")))[-1]
     vals, grids = [], set()
     for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if is_kernel(r["Kernel_Name"]) and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
             grids.add(int(r["Grid_Size"]))
     return sum(vals) / len(vals), len(vals), sorted(grids)
 
 
 def main():
+    global KERNEL
     tag = sys.argv[1]
     out_dir = os.path.join(ROOT, "profiles", "r01")
     os.makedirs(out_dir, exist_ok=True)
     bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(out_dir, f"bench_c2_default_{tag}.json"), "w"), indent=1)
+    if bench.get("roofline"):
+        KERNEL = bench["roofline"]["kernel"]
     stats = sorted(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")))[-1]
     shutil.copy(stats, os.path.join(out_dir, f"bench_c2_kernel_stats_{tag}.csv"))
     fetch_kb, n_f, grid_f = counter_avg("fetch", "FETCH_SIZE")
@@ -45,7 +52,7 @@ def main():
     alg = 20.0 * cfg["dim"] * cpl
     pmc = {
         "chains": cfg["chains_per_gpu"], "dim": cfg["dim"], "chains_per_launch": cpl,
-        "kernel": "k_leapfrog_diag<4,2>", "fetch_size_KB_raw": fetch_kb, "write_size_KB_raw": write_kb,
+        "kernel": KERNEL, "fetch_size_KB_raw": fetch_kb, "write_size_KB_raw": write_kb,
         "launches": {"fetch_pass": n_f, "write_pass": n_w, "grid_sizes": sorted(set(grid_f + grid_w))},
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for wide coalesced reads, "
                       "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; separate --pmc passes",
@@ -59,7 +66,7 @@ def main():
     json.dump(pmc, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
     # kernel-trace average of the dominant kernel, to set beside the bench's HIP-event figure
     for r in csv.DictReader(open(stats)):
-        if KERNEL in r["Name"]:
+        if is_kernel(r["Name"]):
             print("rocprofv3 avg us:", float(r["AverageNs"]) / 1e3, "calls", r["Calls"])
     print("bench avg us:", bench["roofline"]["avg_launch_us"], "value M/s:", bench["value"] / 1e6)
     print("traffic ratio:", pmc["ratio"])

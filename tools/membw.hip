@@ -21,11 +21,26 @@ __global__ void __launch_bounds__(256) k_lf(F4* q, F4* p, const F4* g, size_t n)
     p[i] = pp; q[i] = qq;
   }
 }
-int main() {
+// pseudo-random fill: all-zero buffers flatter the Infinity-Cache path (measured: 8.3 vs 7.0 TB/s for
+// the 3r/2w mix on 64 MiB arrays), so zeros are only used when asked for (argv[1] = 0)
+__global__ void fill_random(float* a, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    a[i] = -1.0f + 2.0f * (float)(x >> 8) * (1.0f / 16777216.0f);
+  }
+}
+int main(int argc, char** argv) {
+  const bool randomize = !(argc > 1 && argv[1][0] == '0');
   size_t maxb = 1ull << 30;
   F4 *a, *b, *c; float* out;
   hipMalloc(&a, maxb); hipMalloc(&b, maxb); hipMalloc(&c, maxb); hipMalloc(&out, 4);
   hipMemset(a, 0, maxb); hipMemset(b, 0, maxb); hipMemset(c, 0, maxb);
+  if (randomize) {
+    fill_random<<<4096, 256>>>((float*)a, maxb / 4, 1u); fill_random<<<4096, 256>>>((float*)b, maxb / 4, 2u);
+    fill_random<<<4096, 256>>>((float*)c, maxb / 4, 3u);
+  }
+  printf("data: %s\n", randomize ? "pseudo-random" : "zeros");
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int grid : {2048, 4096, 16384}) {
   for (size_t mb : {8, 16, 32, 64, 128, 256, 1024}) {
