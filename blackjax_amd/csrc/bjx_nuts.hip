@@ -775,16 +775,29 @@ __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nut
   return cx;
 }
 
-// Work distribution of the free-running kernels: a wave owns groups of kAsyncGroup consecutive
-// chains; one coalesced load + ballot finds the chains of a group that have work in this kernel, so a
-// tick in which most chains are finished costs a few microseconds instead of one wave per chain.
+// Work distribution of the free-running kernels.  Default (GROUPED = false): one wave per compact row;
+// a wave whose chain has no work in this kernel exits after two loads.  GROUPED = true
+// (BJX_NUTS_GROUPED=1, kept for comparison): a wave owns kAsyncGroup consecutive rows, finds the ones
+// with work by one coalesced load + ballot and works them off one after the other -- cheap when
+// nearly every chain is finished, but the live chains of a group are then serialised behind one wave
+// while the rest of the chip idles, which is exactly the tail of a run (C3: 87 -> 101 M/s from
+// dropping the groups in the tail alone).
 constexpr int kAsyncGroup = 8;
 
 // f(chain, compact row, phase) for every chain of the compact rows whose phase is want_a or want_b
-template <class F>
+template <bool GROUPED = true, class F>
 __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax, int want_a, int want_b,
                                                      F f) {
   const int lane = threadIdx.x & 63;
+  if constexpr (!GROUPED) {
+    for (int64_t b = wave_row0(); b < ax.n_rows; b += wave_row_stride()) {
+      const int chain = ax.rows ? ax.rows[b] : (int)b;
+      const int ph = ax.phase[chain];
+      if (ph == want_a || ph == want_b)
+        f((int64_t)__builtin_amdgcn_readfirstlane(chain), b, __builtin_amdgcn_readfirstlane(ph));
+    }
+    return;
+  }
   const int64_t n_groups = (ax.n_rows + kAsyncGroup - 1) / kAsyncGroup;
   for (int64_t grp = wave_row0(); grp < n_groups; grp += wave_row_stride()) {
     const int64_t b0 = grp * kAsyncGroup;
@@ -823,11 +836,11 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
   return stop || last;
 }
 
-template <int VEC, int NI>
+template <int VEC, int NI, bool GROUPED>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
-  async_for_each_chain(ax, 1, 1, [&](int64_t c, int64_t b, int) {
+  async_for_each_chain<GROUPED>(ax, 1, 1, [&](int64_t c, int64_t b, int) {
     async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b);
   });
 }
@@ -915,10 +928,10 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
   }
 }
 
-template <int VEC>
+template <int VEC, bool GROUPED>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
-  async_for_each_chain(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
+  async_for_each_chain<GROUPED>(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
     async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
   });
 }
@@ -930,7 +943,7 @@ template <int VEC, int NI>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
-  async_for_each_chain(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
+  async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
     if (phase == 1) {
       if (!async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b)) return;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1209,25 +1222,51 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
-  const bool fused = run->n_rows <= 2048;  // few rows: one launch per tick (latency), not two (occupancy)
+  static const int64_t fused_rows = [] {
+    const char* e = getenv("BJX_NUTS_FUSED_ROWS");
+    return e ? atoll(e) : (int64_t)16384;
+  }();
+  // One launch per tick (leaf, fence, boundary in the same wave) unless nearly all chains of a large
+  // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
+  // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
+  const bool fused = run->n_rows <= fused_rows;
   if (fused) {
+    const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
     if (nuts_vec4(nuts, qf, gf, run->out_position)) {
       const int ni = nuts_resident_ni(nuts, qf, gf);
-      if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-      else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-      else hipLaunchKernelGGL((k_nuts_async_fused<4, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      else hipLaunchKernelGGL((k_nuts_async_fused<4, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
     } else {
-      hipLaunchKernelGGL((k_nuts_async_fused<1, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+      hipLaunchKernelGGL((k_nuts_async_fused<1, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
     }
-  } else if (nuts_vec4(nuts, qf, gf, run->out_position)) {
-    const int ni = nuts_resident_ni(nuts, qf, gf);
-    if (ni == 1) hipLaunchKernelGGL((k_nuts_async_leaf<4, 1>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_leaf<4, 2>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    else hipLaunchKernelGGL((k_nuts_async_leaf<4, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    hipLaunchKernelGGL(k_nuts_async_boundary<4>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
   } else {
-    hipLaunchKernelGGL((k_nuts_async_leaf<1, 0>), grid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    hipLaunchKernelGGL(k_nuts_async_boundary<1>, grid, dim3(kBlock), 0, s, *nuts, *run, qf);
+    static const bool grouped = [] {
+      const char* e = getenv("BJX_NUTS_GROUPED");
+      return e ? atoi(e) != 0 : false;
+    }();
+    const dim3 rgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));
+#define BJX_TICK2(V, NI_, G, GR)                                                                          \
+  do {                                                                                                    \
+    hipLaunchKernelGGL((k_nuts_async_leaf<V, NI_, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
+    hipLaunchKernelGGL((k_nuts_async_boundary<V, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf);            \
+  } while (0)
+    if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+      const int ni = nuts_resident_ni(nuts, qf, gf);
+      if (grouped) {
+        if (ni == 1) BJX_TICK2(4, 1, true, grid);
+        else if (ni == 2) BJX_TICK2(4, 2, true, grid);
+        else BJX_TICK2(4, 0, true, grid);
+      } else {
+        if (ni == 1) BJX_TICK2(4, 1, false, rgrid);
+        else if (ni == 2) BJX_TICK2(4, 2, false, rgrid);
+        else BJX_TICK2(4, 0, false, rgrid);
+      }
+    } else {
+      if (grouped) BJX_TICK2(1, 0, true, grid);
+      else BJX_TICK2(1, 0, false, rgrid);
+    }
+#undef BJX_TICK2
   }
   return bjx_check_launch("bjx_nuts_async_tick");
 }

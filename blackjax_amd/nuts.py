@@ -327,7 +327,7 @@ class NUTSRunInfo(NamedTuple):
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every: int = 16, use_graph: bool = False):
+             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -341,10 +341,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     so the draws are identical to ``num_steps`` calls of ``step``.
 
     The host syncs once per ``sync_every`` ticks (to stop, and to drop finished chains from the
-    callable's batch once fewer than half of its rows are still running).  ``use_graph=True``
-    replays those ``sync_every`` ticks + callable invocations as one HIP graph (the callable must be
-    capturable): in the tail of a run, where a few deep trees are all that is left, the ticks are
-    otherwise bound by the host's launch rate.
+    callable's batch once fewer than half of its rows are still running).  In the tail of a run,
+    where a few deep trees are all that is left, a tick is a few microseconds of GPU work and the
+    loop is bound by the host's launch rate; there (``use_graph="auto"``: once at most
+    ``graph_max_rows`` rows are live) chunks of ``4 * sync_every`` ticks + callable invocations are
+    recorded once per batch size and replayed as one HIP graph.  A callable that cannot be captured
+    (it synchronises, say) makes "auto" fall back to plain launches; ``use_graph=True`` captures from
+    the second chunk on whatever the batch size and lets a capture error propagate, ``False`` never
+    captures.
 
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
@@ -428,31 +432,46 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     n_out = torch.zeros(1, **i32)
     cur = 0
 
-    def chunk(qf, logp_f, gf):
-        """``sync_every`` ticks, each followed by the callable on the current batch."""
-        for _ in range(sync_every):
+    def chunk(n_ticks, qf, logp_f, gf):
+        """``n_ticks`` ticks, each followed by the callable on the current batch."""
+        for _ in range(n_ticks):
             _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref, qf.data_ptr(),
                       logp_f.data_ptr(), gf.data_ptr())
             logp_f, gf = eval_logdensity(vg, qf)
         return logp_f, gf
 
+    if use_graph not in (True, False, "auto"):
+        raise ValueError("use_graph must be True, False or 'auto'")
     graph = None  # (CUDAGraph, static logp_f, static gf) for the current batch
-    n_chunks = -(-max_ticks // sync_every)
-    for ci in range(n_chunks):
+    graph_ok = use_graph is not False
+    eager_chunks = 0  # plain chunks since the batch last changed (they warm kernels and allocator)
+    ticks_left = max_ticks
+    while ticks_left > 0:
+        tail = n_rows <= graph_max_rows
+        n_ticks = sync_every * (4 if tail else 1)
         if graph is not None:
             graph[0].replay()
         else:
-            logp_f, gf = chunk(qf, logp_f, gf)
-            if use_graph and ci >= 1:
-                # the eager chunks above warmed every kernel and the allocator; recording does not
-                # execute anything, so the chains' state is untouched by the capture
+            logp_f, gf = chunk(n_ticks, qf, logp_f, gf)
+            eager_chunks += 1
+            # "auto" records only when a batch size has lasted 4 plain chunks already: recording a
+            # chunk costs milliseconds, which only a long tail pays back
+            if graph_ok and ticks_left < max_ticks and (use_graph is True or (tail and eager_chunks >= 4)):
+                # recording does not execute anything, so the chains' state is untouched by it
                 lp_s, g_s = logp_f.clone(), gf.clone()
-                cg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(cg):
-                    lp_e, g_e = chunk(qf, lp_s, g_s)
-                    lp_s.copy_(lp_e)
-                    g_s.copy_(g_e)
-                graph = (cg, lp_s, g_s)
+                try:
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg):
+                        lp_e, g_e = chunk(n_ticks, qf, lp_s, g_s)
+                        lp_s.copy_(lp_e)
+                        g_s.copy_(g_e)
+                    graph = (cg, lp_s, g_s)
+                except Exception:
+                    if use_graph is True:
+                        raise
+                    graph_ok = False  # "auto": this callable cannot be captured -- plain launches
+                    torch.cuda.synchronize()
+        ticks_left -= n_ticks
         n_active = N - int(n_done.item())  # one host sync per chunk
         if n_active == 0:
             break
@@ -469,6 +488,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             run.rows, run.n_rows = rows_buf[cur].data_ptr(), n_rows
             logp_f, gf = eval_logdensity(vg, qf)  # the gathered positions, row for row
             graph = None
+            eager_chunks = 0
     else:
         if int(n_done.item()) != N:
             raise RuntimeError("free-running NUTS did not finish within its tick bound")
@@ -479,7 +499,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
                      recompact_every: int = 16, use_graph: bool = False,
-                     graph_sync_every: int = 4) -> SamplingAlgorithm:
+                     graph_sync_every: int = 4, run_use_graph="auto") -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
     ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
@@ -501,6 +521,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,
-                        store_positions=store_positions, use_graph=use_graph)
+                        store_positions=store_positions,
+                        use_graph=True if use_graph else run_use_graph)
 
     return SamplingAlgorithm(init_fn, step_fn, run_fn)

@@ -25,12 +25,17 @@ ap.add_argument("--recompact", type=int, default=16)
 ap.add_argument("--use-graph", action="store_true")
 ap.add_argument("--free-running", action="store_true",
                 help="drive the timed transitions with alg.run (asynchronous chains) instead of step")
+ap.add_argument("--no-tick-timing", action="store_true",
+                help="free-running: do not bracket ticks with HIP events (the brackets drain the queue)")
+ap.add_argument("--run-graph", default="auto", choices=["auto", "off", "on"],
+                help="free-running: HIP-graph replay of tick chunks (auto = in the tail of the run)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 N, D = args.chains, args.dim
 alg = bjx.nuts(bjx.targets.NealFunnel(), args.eps, torch.ones(D, device=dev),
                max_num_doublings=args.max_depth, recompact_every=args.recompact,
-               use_graph=args.use_graph)
+               use_graph=args.use_graph,
+               run_use_graph={"auto": "auto", "off": False, "on": True}[args.run_graph])
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=g))
@@ -40,8 +45,9 @@ for t in range(args.warmup):
 torch.cuda.synchronize()
 if args.free_running:
     alg.run(bjx.random.key(5), state, 2, store_positions=False)  # first use of the tick kernel
-    tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=8)
-    if not args.use_graph:  # events cannot be recorded while a graph is being captured
+    tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=8, capacity=4096)
+    # events cannot be recorded while a graph is being captured: ticks are only timed without graphs
+    if args.run_graph == "off" and not args.use_graph and not args.no_tick_timing:
         _lib.set_timer(tick_timer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -57,7 +63,8 @@ if args.free_running:
     print(json.dumps({
         "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot / dt, "unit": "chain-leapfrog-steps/s",
         "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
-                   "driver": "free-running chains (alg.run)", "hip_graph": bool(args.use_graph)},
+                   "driver": "free-running chains (alg.run)",
+                   "hip_graph": "on" if args.use_graph else args.run_graph},
         "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
         "mean_leapfrogs_per_chain_transition": tot / (N * args.steps),
         "ticks": ticks, "max_chain_total_leapfrogs": int(per_chain.max()),
