@@ -783,6 +783,11 @@ __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nut
 // while the rest of the chip idles, which is exactly the tail of a run (C3: 87 -> 101 M/s from
 // dropping the groups in the tail alone).
 constexpr int kAsyncGroup = 8;
+// occupancy hint of the fused tick kernel: 3 waves per SIMD (168 VGPRs); 4 forces 140 B of spills
+// per lane and measured slower (C3: 101 vs 108 M/s)
+#ifndef BJX_FUSED_WAVES
+#define BJX_FUSED_WAVES 3
+#endif
 
 // f(chain, compact row, phase) for every chain of the compact rows whose phase is want_a or want_b
 template <bool GROUPED = true, class F>
@@ -940,7 +945,7 @@ k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
 // bound by its dependent launches, not by the work): leaf, then -- same wave, after a fence -- the
 // boundary work the leaf may have produced.
 template <int VEC, int NI>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_FUSED_WAVES)))
 k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
   async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
