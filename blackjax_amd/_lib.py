@@ -205,7 +205,7 @@ class LaunchTimer:
     (bench.py) can read per-launch kernel durations of the timed region afterwards."""
 
     def __init__(self, names, every: int = 1, capacity: int = 0):
-        """``every``: bracket only every k-th launch of each name (two event records cost host
+        """``every``: bracket only every k-th launch of each name -- an int, or ``{name: k}`` (two event records cost host
         time, which matters once launches are ~50 us).  ``capacity``: number of brackets whose
         events are created up front, outside the timed region (creating an event costs more than
         recording it); brackets beyond the pool create theirs on the fly."""
@@ -213,7 +213,9 @@ class LaunchTimer:
 
         self.names = set(names)
         self.events = {n: [] for n in self.names}
-        self.every = max(1, int(every))
+        # one sampling rate for all names, or {name: rate} (names not listed: every launch)
+        self.every = ({n: max(1, int(every.get(n, 1))) for n in self.names} if isinstance(every, dict)
+                      else {n: max(1, int(every)) for n in self.names})
         self.seen = {n: 0 for n in self.names}
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max(0, int(capacity)))]
         for ev in self.pool:  # torch creates the HIP event lazily, at the first record()
@@ -244,7 +246,7 @@ def call(name: str, *args) -> None:
     timed = _timer is not None and name in _timer.names
     if timed:
         _timer.seen[name] += 1
-        timed = _timer.seen[name] % _timer.every == 0
+        timed = _timer.seen[name] % _timer.every[name] == 0
     if timed:
         s = _timer.take_event()
         e = _timer.take_event()

@@ -34,7 +34,7 @@ keys = bjx.random.split(bjx.random.key(0), args.warmup + args.steps)
 for t in range(args.warmup):
     state, info = alg.step(keys[t], state)
 torch.cuda.synchronize()
-timer = _lib.LaunchTimer(["bjx_leapfrog_dense"])
+timer = _lib.LaunchTimer(["bjx_leapfrog_dense"], every=4, capacity=L * args.steps)
 _lib.set_timer(timer)
 acc = 0.0
 t0 = time.perf_counter()
