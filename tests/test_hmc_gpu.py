@@ -82,7 +82,7 @@ def test_momentum_diag(dev, N, D, per_chain_imm):
     np.testing.assert_allclose(t2n(ke), ke_ref, rtol=1e-6)
 
 
-@pytest.mark.parametrize("N,D", [(33, 1024), (4, 6), (2, 1023)])
+@pytest.mark.parametrize("N,D", [(33, 1024), (4, 6), (2, 1023), (5, 2048), (3, 3072)])
 @pytest.mark.parametrize("per_chain", [False, True])
 def test_leapfrog_diag_bit_exact(dev, N, D, per_chain):
     rng = np.random.default_rng(1)
@@ -111,6 +111,34 @@ def test_leapfrog_diag_bit_exact(dev, N, D, per_chain):
               immt.data_ptr(), D if per_chain else 0, qo.data_ptr(), po.data_ptr(), g1.data_ptr(),
               qo.data_ptr(), po.data_ptr())
     assert np.array_equal(t2n(qo), z2.position)
+
+
+@pytest.mark.parametrize("N,D", [(9, 2048), (6, 1024), (5, 96)])
+def test_leapfrog_diag_masked_matches_unmasked(dev, N, D):
+    """dynamic HMC's per-chain trajectory lengths (mcmc/dynamic_hmc.py): chains whose trajectory is
+    complete (step_idx >= n_steps) are left untouched in place and copied through out of place; the
+    others get exactly the unmasked stage.  D = 2048 / 1024 take the flat kernel, 96 the row kernel."""
+    g_ = torch.Generator(device=dev)
+    g_.manual_seed(3)
+    q, p, g = (torch.randn(N, D, device=dev, generator=g_) for _ in range(3))
+    imm = torch.rand(N, D, device=dev, generator=g_) + 0.5
+    eps = torch.rand(N, device=dev, generator=g_) * 0.2 + 0.01
+    n_steps = torch.tensor([(i * 2) % 5 for i in range(N)], dtype=torch.int32, device=dev)
+    step_idx = 2
+    s = _lib.current_stream()
+    q_ref, p_ref = torch.empty_like(q), torch.empty_like(p)
+    _lib.call("bjx_leapfrog_diag", s, N, D, 2, 0.0, eps.data_ptr(), imm.data_ptr(), D, q.data_ptr(),
+              p.data_ptr(), g.data_ptr(), q_ref.data_ptr(), p_ref.data_ptr())
+    live = (n_steps > step_idx)[:, None]
+    want_q, want_p = torch.where(live, q_ref, q), torch.where(live, p_ref, p)
+    q_out, p_out = torch.full_like(q, float("nan")), torch.full_like(p, float("nan"))
+    _lib.call("bjx_leapfrog_diag_masked", s, N, D, 2, 0.0, eps.data_ptr(), imm.data_ptr(), D, q.data_ptr(),
+              p.data_ptr(), g.data_ptr(), q_out.data_ptr(), p_out.data_ptr(), n_steps.data_ptr(), step_idx)
+    assert torch.equal(q_out, want_q) and torch.equal(p_out, want_p)
+    q_in, p_in = q.clone(), p.clone()
+    _lib.call("bjx_leapfrog_diag_masked", s, N, D, 2, 0.0, eps.data_ptr(), imm.data_ptr(), D, q_in.data_ptr(),
+              p_in.data_ptr(), g.data_ptr(), q_in.data_ptr(), p_in.data_ptr(), n_steps.data_ptr(), step_idx)
+    assert torch.equal(q_in, want_q) and torch.equal(p_in, want_p)
 
 
 def _run_both(dev, N, D, L, T, eps, imm, inv_var, seed=0, chain_offset=0, q_scale=1.0):
