@@ -130,6 +130,7 @@ extern "C" {
 
 int bjx_da_init(void* stream, int64_t N, int from_log_avg, const float* x_in, float* log_x_out,
                 float* log_x_avg_out, float* avg_error_out, float* mu_out, float* step_size_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && x_in && log_x_out && log_x_avg_out && avg_error_out && mu_out &&
                     step_size_out,
                 "bjx_da_init: bad arguments");
@@ -145,6 +146,7 @@ int bjx_da_update(void* stream, int64_t N, int64_t step, float target, float t0,
                   const float* log_x_avg_in, const float* avg_error_in, const float* mu,
                   float* log_x_out, float* log_x_avg_out, float* avg_error_out,
                   float* step_size_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && step >= 1 && acceptance_rate && log_x_in && log_x_avg_in &&
                     avg_error_in && mu && log_x_out && log_x_avg_out && avg_error_out &&
                     step_size_out,
@@ -162,6 +164,7 @@ int bjx_da_update(void* stream, int64_t N, int64_t step, float target, float t0,
 }
 
 int bjx_exp(void* stream, int64_t N, const float* x, float* y) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && x && y, "bjx_exp: bad arguments");
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_exp, dim3(flat_grid(N)), dim3(kBlock), 0, (hipStream_t)stream, N, x, y);
@@ -171,6 +174,7 @@ int bjx_exp(void* stream, int64_t N, const float* x, float* y) {
 int bjx_welford_update_diag(void* stream, int64_t N, int64_t D, int64_t sample_size_new,
                             const float* value, const float* mean_in, const float* m2_in,
                             float* mean_out, float* m2_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size_new >= 1 && value && mean_in && m2_in && mean_out &&
                     m2_out,
                 "bjx_welford_update_diag: bad arguments");
@@ -189,6 +193,7 @@ int bjx_welford_update_diag(void* stream, int64_t N, int64_t D, int64_t sample_s
 int bjx_welford_final_diag(void* stream, int64_t N, int64_t D, int64_t sample_size,
                            float imm_shrinkage_to_previous, const float* m2, const float* imm_prev,
                            int64_t imm_prev_stride, float* imm_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size >= 0 && m2 && imm_prev && imm_out,
                 "bjx_welford_final_diag: bad arguments");
   BJX_CHECK_ARG(imm_prev_stride == 0 || imm_prev_stride == D,

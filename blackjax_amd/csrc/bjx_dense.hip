@@ -680,6 +680,7 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
 extern "C" {
 
 int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && A && B && C, "bjx_dense_matmul: bad arguments");
   if (N == 0) return 0;
   GemmArgs ga{N, D, A, nullptr, 0, 0.0f, nullptr, nullptr, B, C, nullptr, nullptr};
@@ -690,6 +691,7 @@ int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t c
                            int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
                            const float* imm, float* z_work, float* v_work, float* p_out,
                            float* ke_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out,
                 "bjx_hmc_momentum_dense: bad arguments");
   if (N == 0) return 0;
@@ -710,6 +712,7 @@ int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t c
 int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float eps,
                        const float* eps_per_chain, const float* imm, const float* q_in,
                        const float* p_in, const float* g, float* q_out, float* p_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
                 "bjx_leapfrog_dense: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense: n_kicks must be 1 or 2");
@@ -728,6 +731,7 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
                          float* p1_work, float* v_work, float* p_end_out, float* q_out,
                          float* logp_out, float* g_out, float* acceptance_rate_out,
                          uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
                     p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
                     is_accepted_out && is_divergent_out && energy_out,
@@ -749,6 +753,7 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
 // ------------------------------------------------------------------ per-chain dense metric
 int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, int64_t matrix_stride,
                     const float* x, float* y) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && M && x && y && (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_pc_matvec_t: bad arguments");
   if (N == 0) return 0;
@@ -760,6 +765,7 @@ int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_
                               int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
                               const float* imm, int64_t matrix_stride, float* z_work, float* v_work,
                               float* p_out, float* ke_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out &&
                     (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_hmc_momentum_dense_pc: bad arguments");
@@ -781,6 +787,7 @@ int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float
                           const float* eps_per_chain, const float* imm, int64_t matrix_stride,
                           const float* q_in, const float* p_in, const float* g, float* q_out,
                           float* p_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out &&
                     (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_leapfrog_dense_pc: bad arguments");
@@ -799,6 +806,7 @@ int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t 
                             float* p_end_out, float* q_out, float* logp_out, float* g_out,
                             float* acceptance_rate_out, uint8_t* is_accepted_out,
                             uint8_t* is_divergent_out, float* energy_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
                     p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
                     is_accepted_out && is_divergent_out && energy_out &&
@@ -818,6 +826,7 @@ int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t 
 int bjx_welford_update_dense(void* stream, int64_t N, int64_t D, int64_t sample_size_new,
                              const float* value, const float* mean_in, const float* m2_in,
                              float* mean_out, float* m2_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size_new >= 1 && value && mean_in && m2_in && mean_out &&
                     m2_out,
                 "bjx_welford_update_dense: bad arguments");
@@ -833,6 +842,7 @@ int bjx_welford_update_dense(void* stream, int64_t N, int64_t D, int64_t sample_
 int bjx_welford_final_dense(void* stream, int64_t N, int64_t D, int64_t sample_size,
                             float imm_shrinkage_to_previous, const float* m2, const float* imm_prev,
                             int imm_prev_per_chain, float* imm_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size >= 0 && m2 && imm_prev && imm_out,
                 "bjx_welford_final_dense: bad arguments");
   if (N == 0) return 0;

@@ -457,6 +457,7 @@ int bjx_rng_normal(void* stream, uint32_t key0, uint32_t key1, int64_t chain_off
 
 int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset, int64_t N,
                     float* u_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && (N == 0 || u_out), "bjx_rng_uniform: bad arguments");
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_rng_uniform, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
@@ -467,6 +468,7 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
 int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                           int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
                           float* p_out, float* ke_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && p_out && ke_out, "bjx_hmc_momentum_diag: bad arguments");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_momentum_diag: imm_stride must be 0 or D");
   if (N == 0) return 0;
@@ -486,6 +488,7 @@ int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, floa
                            const float* imm, int64_t imm_stride, const float* q_in,
                            const float* p_in, const float* g, float* q_out, float* p_out,
                            const int32_t* n_steps, int32_t step_idx) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out,
                 "bjx_leapfrog_diag: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_diag: n_kicks must be 1 or 2");
@@ -568,6 +571,7 @@ __global__ void k_keys_randint(int64_t N, const uint32_t* __restrict__ kin, int3
 
 int bjx_keys_child(void* stream, int64_t N, const uint32_t* keys_in, uint32_t child,
                    uint32_t* keys_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && keys_in && keys_out, "bjx_keys_child: bad arguments");
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_keys_child, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
@@ -577,6 +581,7 @@ int bjx_keys_child(void* stream, int64_t N, const uint32_t* keys_in, uint32_t ch
 
 int bjx_keys_randint(void* stream, int64_t N, const uint32_t* keys, int32_t minval, int32_t maxval,
                      int32_t* out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && keys && out, "bjx_keys_randint: bad arguments");
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_keys_randint, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
@@ -593,6 +598,7 @@ int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                         float* p_end_out, float* q_out, float* logp_out, float* g_out,
                         float* acceptance_rate_out, uint8_t* is_accepted_out,
                         uint8_t* is_divergent_out, float* energy_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
                     q_out && logp_out && g_out && acceptance_rate_out && is_accepted_out &&
                     is_divergent_out && energy_out,
@@ -636,6 +642,7 @@ int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain
                        float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
                        float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
                        float* prop_energy) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
                     weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q && prop_p &&
                     prop_g && prop_logp && prop_energy,
@@ -661,6 +668,7 @@ int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_
                     const float* ke0, const uint8_t* ever_accepted, const float* sum_log_p_accept,
                     float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
                     float* acceptance_rate_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && q0 && p0 && g0 && logp0 && ke0 && ever_accepted &&
                     sum_log_p_accept && prop_q && prop_p && prop_g && prop_logp && prop_energy &&
                     acceptance_rate_out,

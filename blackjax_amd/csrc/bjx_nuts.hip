@@ -1057,6 +1057,7 @@ k_nuts_compact(bjx_nuts_t nt, int flag_slot, int64_t n_in_arg, const int32_t* id
 
 int check_nuts(const bjx_nuts_t* nt, const char* what) {
   if (!nt) { bjx_set_error("%s: null descriptor", what); return 1; }
+  if (nt->N == 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30) return 0;  // callers return next
   const bool dense_ok =
       !nt->Mdense || ((nt->Mdense_stride == 0 || nt->Mdense_stride == nt->D * nt->D) && nt->v0 &&
                       nt->Lv && nt->Rv && (nt->max_depth == 0 || nt->ckpt_v));
@@ -1100,6 +1101,7 @@ extern "C" {
 
 int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, const float* ke0) {
   if (check_nuts(nuts, "bjx_nuts_init")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(logp0 && ke0, "bjx_nuts_init: bad arguments");
   if (nuts->N == 0) return 0;
   const dim3 grid(bjx_row_grid(nuts->N, kWavesPerBlock));
@@ -1111,6 +1113,7 @@ int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, cons
 int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
                  const int32_t* idx, float* qf) {
   if (check_nuts(nuts, "bjx_nuts_pre")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && s >= 0 && s < ((int64_t)1 << depth) &&
                     n_rows >= 0 && n_rows <= nuts->N && qf,
                 "bjx_nuts_pre: bad arguments");
@@ -1124,6 +1127,7 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
 int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_t n_cap,
                      const int32_t* idx, const int64_t* ctl, float* qf) {
   if (check_nuts(nuts, "bjx_nuts_pre_ctl")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf,
                 "bjx_nuts_pre_ctl: bad arguments");
   if (n_cap == 0) return 0;
@@ -1137,6 +1141,7 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
                   const int32_t* idx, float* qf, const float* logp_f, const float* gf,
                   int32_t fuse_next) {
   if (check_nuts(nuts, "bjx_nuts_post")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && s >= 0 && s < ((int64_t)1 << depth) &&
                     n_rows >= 0 && n_rows <= nuts->N && qf && logp_f && gf,
                 "bjx_nuts_post: bad arguments");
@@ -1161,6 +1166,7 @@ int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64
                       const int32_t* idx, const int64_t* ctl, float* qf, const float* logp_f,
                       const float* gf, int32_t fuse_next) {
   if (check_nuts(nuts, "bjx_nuts_post_ctl")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(s_off >= 0 && n_cap >= 0 && n_cap <= nuts->N && idx && ctl && qf && logp_f && gf,
                 "bjx_nuts_post_ctl: bad arguments");
   if (n_cap == 0) return 0;
@@ -1182,6 +1188,7 @@ int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64
 int bjx_nuts_compact(void* stream, const bjx_nuts_t* nuts, int32_t flag_slot, int64_t n_in,
                      const int32_t* idx_in, int32_t* idx_out, int64_t* ctl) {
   if (check_nuts(nuts, "bjx_nuts_compact")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG((flag_slot == BJX_NUTS_I_ACTIVE || flag_slot == BJX_NUTS_I_SUB_ACTIVE) && idx_out &&
                     ctl && n_in <= nuts->N,
                 "bjx_nuts_compact: bad arguments");
@@ -1201,6 +1208,7 @@ int bjx_nuts_set_ctl(void* stream, int64_t* ctl, int32_t depth, int64_t s_base, 
 int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t n_rows,
                    const int32_t* idx) {
   if (check_nuts(nuts, "bjx_nuts_merge")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(depth >= 0 && depth < nuts->max_depth && n_rows >= 0 && n_rows <= nuts->N,
                 "bjx_nuts_merge: bad arguments");
   if (n_rows == 0) return 0;
@@ -1213,6 +1221,7 @@ int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t 
 int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run, float* qf,
                         const float* logp_f, const float* gf) {
   if (check_nuts(nuts, "bjx_nuts_async_tick")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(run && qf && logp_f && gf, "bjx_nuts_async_tick: null argument");
   BJX_CHECK_ARG(!nuts->Mdense, "bjx_nuts_async_tick: free-running chains support the diagonal metric only");
   BJX_CHECK_ARG(nuts->max_depth >= 1, "bjx_nuts_async_tick: max_depth must be >= 1");
@@ -1280,6 +1289,7 @@ int bjx_nuts_async_compact(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_
                            const float* qf_in, int32_t* rows_out, float* qf_out, int32_t* src_work,
                            int32_t* n_out) {
   if (check_nuts(nuts, "bjx_nuts_async_compact")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(run && run->phase && qf_in && rows_out && qf_out && src_work && n_out,
                 "bjx_nuts_async_compact: null argument");
   BJX_CHECK_ARG(rows_out != run->rows && qf_out != qf_in, "bjx_nuts_async_compact: outputs must not alias inputs");

@@ -35,6 +35,16 @@ def test_empty_batch_everywhere(dev):
     dh = bjx.dynamic_hmc(fn, 0.1, torch.ones(D, device=dev))
     st = dh.init(q0, prng.key(1))
     assert st.random_generator_arg.shape == (0, 2)
+    nuts = bjx.nuts(fn, 0.1, torch.ones(D, device=dev), max_num_doublings=3)
+    st = nuts.init(q0)
+    st2, info = nuts.step(prng.key(2), st)
+    assert st2.position.shape == (0, D) and info.num_integration_steps.shape == (0,)
+    st3, positions, rinfo = nuts.run(prng.key(3), st, 4)
+    assert positions.shape == (4, 0, D) and rinfo.acceptance_rate.shape == (4, 0)
+    mh = bjx.mhmc(fn, 0.1, torch.ones(D, device=dev), 3)
+    st = mh.init(q0)
+    st2, info = mh.step(prng.key(4), st)
+    assert st2.position.shape == (0, D) and info.acceptance_rate.shape == (0,)
 
 
 @pytest.mark.parametrize("N,D", [(9, 1), (5, 3)])
