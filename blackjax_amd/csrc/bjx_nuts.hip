@@ -259,7 +259,12 @@ __device__ __forceinline__ int nuts_begin_doubling(const bjx_nuts_t& nt, const S
   const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);  // trajectory.py:645
   const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
   const int dir = key_uniform(kd) < 0.5f ? 1 : -1;                        // trajectory.py:650
+  // split(subkey,3)[1]: every leaf of this doubling folds its index into this key (trajectory.py:
+  // 329-339); kept in the slot table so a leaf derives ONE key instead of the whole chain of five
+  const Key kt = key_child(subkey, 1);
   if (lane == 0) {
+    IS(BJX_NUTS_I_KT, c) = (int32_t)kt.k0;
+    IS(BJX_NUTS_I_KTB, c) = (int32_t)kt.k1;
     IS(BJX_NUTS_I_DIR, c) = dir;
     IS(BJX_NUTS_I_SUB_ACTIVE, c) = 1;
     IS(BJX_NUTS_I_SDIV, c) = 0;
@@ -365,9 +370,9 @@ __device__ __forceinline__ bool nuts_post_chain_resident(const bjx_nuts_t& nt, c
     Wn = w;
     Sn = slpa_new;
   } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
-    const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
-    const Key kt = key_child(subkey, 1);
-    const float u = key_uniform(key_child(kt, (uint64_t)s));
+    const Key kt{(uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KT, c)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KTB, c))};  // nuts_begin_doubling
+    const float u = key_uniform(key_child(kt, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s)));  // fold_in(kt, s)
     const Scalars3 sc = scalars3(-(double)(w - sw), sw, w, sslpa, slpa_new);
     take = u < sc.r0;
     Wn = sc.lae1;
@@ -531,9 +536,9 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
     Sn = slpa_new;
   } else {
     const float sw = FS(BJX_NUTS_F_SW, c);
-    const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);
-    const Key kt = key_child(subkey, 1);                              // split(subkey,3)[1]
-    const float u = key_uniform(key_child(kt, (uint64_t)s));          // fold_in(kt, s)
+    const Key kt{(uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KT, c)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KTB, c))};  // nuts_begin_doubling
+    const float u = key_uniform(key_child(kt, (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s)));  // fold_in(kt, s)
     // pa = expit(w - sw), Wn = logaddexp(sw, w), Sn = logaddexp(sum_log_p_accept, min(w, 0))
     const Scalars3 sc = scalars3(-(double)(w - sw), sw, w, FS(BJX_NUTS_F_SSLPA, c), slpa_new);
     take = u < sc.r0;

@@ -55,7 +55,9 @@ enum {
   BJX_NUTS_I_DIV = 7,        /* NUTSInfo.is_divergent / is_turning */
   BJX_NUTS_I_TURN = 8,
   BJX_NUTS_I_DEPTH = 9,      /* NUTSInfo.num_trajectory_expansions */
-  BJX_NUTS_NI = 10
+  BJX_NUTS_I_KT = 10,        /* the two words of the current doubling's leaf-sampling key: */
+  BJX_NUTS_I_KTB = 11,       /*   split(fold_in(integrator_key, depth), 3)[1], written once per doubling */
+  BJX_NUTS_NI = 12
 };
 
 typedef struct {

@@ -8,7 +8,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM_NORM"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python $R/tools/bench_nuts.py --free-running --steps 20 > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing --run-graph off > $OUT/g$i.log 2>&1
 done
 cd $R
 python - <<'PY'
