@@ -325,7 +325,11 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
   const float* a_src = a.A + (row0 + s_row) * D + s_k;
   const float* g_src = KICKS > 0 ? a.G + (row0 + s_row) * D + s_k : nullptr;
   const float* b_src = a.B + (col0 + s_row) * D + s_k;
-  float* a_out = (KICKS > 0 && a.A_out && col_blk == 0) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
+  // The kicked operand p' is an output (A_out).  Every column block of a row block stages the same
+  // A rows, so the store is shared out: column block c writes the k range [c*BN, (c+1)*BN) -- one
+  // quarter of the K-tiles each at D = 512 instead of all of them in column block 0, whose
+  // store drains then made its row's slowest workgroup.
+  float* a_out = (KICKS > 0 && a.A_out) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
   float h = 0.0f;
   if (KICKS > 0) h = (a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps) * 0.5f;
   // Software pipeline over K-tiles with two register sets (loop unrolled by two so the set index
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
     if constexpr (KICKS > 0) {
       kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]);
       if constexpr (KICKS == 2) { kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]); }
-      if (a_out) { st4(a_out + k0, r.a[0]); st4(a_out + k0 + 4, r.a[1]); }
+      if (a_out && k0 / BN == col_blk) { st4(a_out + k0, r.a[0]); st4(a_out + k0 + 4, r.a[1]); }
     }
     float* as = As0 + buf * BM * LDK + s_row * LDK + s_k;
     float* bs = Bs0 + buf * BN * LDK + s_row * LDK + s_k;
