@@ -139,7 +139,17 @@ class NutsAsync(ctypes.Structure):
         ("out_energy", c_void_p), ("out_num_integration_steps", c_void_p),
         ("out_num_trajectory_expansions", c_void_p), ("out_is_divergent", c_void_p),
         ("out_is_turning", c_void_p),
+        ("adapt_tab", c_void_p), ("adapt_target", c_float), ("adapt_reserved", c_float),
+        ("adapt_log_x", c_void_p), ("adapt_log_x_avg", c_void_p), ("adapt_avg_err", c_void_p),
+        ("adapt_mu", c_void_p), ("adapt_step_size", c_void_p), ("adapt_mean", c_void_p),
+        ("adapt_m2", c_void_p), ("adapt_imm", c_void_p), ("out_step_size", c_void_p),
     ]
+
+
+# columns of bjx_nuts_async_t.adapt_tab (include/bjx_nuts.h BJX_NUTS_AT_*; checked by tests/test_abi.py)
+NUTS_AT = {"FLAGS": 0, "DA_REG": 1, "DA_INV_REG": 2, "DA_ETA": 3, "DA_COEF": 4, "WEL_N": 5,
+           "FIN_NM1": 6, "FIN_BETA_DATA": 7, "FIN_BETA_PREV": 8, "FIN_REG": 9}
+NUTS_ADAPT_COLS = 12
 
 
 SIGNATURES.update({

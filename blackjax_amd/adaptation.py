@@ -17,6 +17,7 @@ from __future__ import annotations
 
 from typing import Callable, NamedTuple, Optional
 
+import numpy as np
 import torch
 
 from . import _lib, integrators, metrics
@@ -214,8 +215,69 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
     mcmc_kernel = algorithm.build_kernel(integrator)  # the sampler validates the integrator
 
-    def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0):
-        """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains)."""
+    def _run_free_running(rng_key, state, imm, ss, eps0, num_steps, chain_offset):
+        """The same warm-up with free-running chains (nuts.run_free, include/bjx_nuts.h adapt_*): every
+        chain carries its own dual-averaging / Welford state through its own sequence of trees and
+        adapts when IT finishes a transition, so a warm-up no longer lasts as long as the deepest tree
+        of every step.  Chains are independent in the reference's vmapped warm-up, hence the results
+        are those of ``run`` bit for bit.  NUTS with a diagonal metric; the per-step record is the
+        ``NUTSRunInfo`` of the run (with ``step_size``), not ``adaptation_info_fn``'s."""
+        from .nuts import build_kernel as _nuts_build_kernel, run_free as _nuts_run_free
+
+        if getattr(algorithm, "build_kernel", None) is not _nuts_build_kernel:
+            raise NotImplementedError("free_running=True is implemented for blackjax_amd.nuts")
+        if not is_mass_matrix_diagonal:
+            raise NotImplementedError("free_running=True needs a diagonal mass matrix")
+        n, d = state.position.shape
+        dev = state.position.device
+        extra = dict(extra_parameters)
+        max_depth = int(extra.pop("max_num_doublings", 10))
+        div_thr = float(extra.pop("divergence_threshold", 1000))
+        if extra:
+            raise TypeError(f"unexpected parameters for a free-running NUTS warm-up: {sorted(extra)}")
+        # everything that depends on the step index only: schedule flags and the fp32 scalars the
+        # lockstep entry points (bjx_da_update, bjx_welford_final_diag) evaluate on the host
+        f32 = np.float32
+        tab = np.zeros((num_steps, _lib.NUTS_ADAPT_COLS), f32)
+        AT = _lib.NUTS_AT
+        da_step, wel = 1, 0
+        shrink = f32(imm_shrinkage_to_previous)
+        for t, (stage, is_window_end) in enumerate(build_schedule(num_steps)):
+            tab[t, AT["FLAGS"]] = (1 if stage == 1 else 0) | (2 if is_window_end else 0)
+            if stage == 1:
+                wel += 1
+                tab[t, AT["WEL_N"]] = wel
+            reg = f32(da_step) + f32(_DA_T0)
+            tab[t, AT["DA_REG"]] = reg
+            tab[t, AT["DA_INV_REG"]] = f32(1.0) / reg
+            tab[t, AT["DA_ETA"]] = f32(float(da_step) ** (-float(f32(_DA_KAPPA))))
+            tab[t, AT["DA_COEF"]] = np.sqrt(f32(da_step)) / f32(_DA_GAMMA)
+            da_step += 1
+            if is_window_end:
+                denom = f32(wel + 5) + shrink
+                tab[t, AT["FIN_NM1"]] = f32(wel - 1)
+                tab[t, AT["FIN_BETA_DATA"]] = f32(wel) / denom
+                tab[t, AT["FIN_BETA_PREV"]] = shrink / denom
+                tab[t, AT["FIN_REG"]] = (f32(5.0) / denom) * f32(1e-3)
+                wel, da_step = 0, 1
+        imm_pc = (imm if imm.ndim == 2 else imm.expand(n, d)).contiguous().clone()
+        ad = {"tab": tab, "target": float(target_acceptance_rate), "log_x": ss.log_step_size.clone(),
+              "log_x_avg": ss.log_step_size_avg.clone(), "avg_err": ss.avg_error.clone(), "mu": ss.mu.clone(),
+              "step_size": eps0.clone(), "mean": torch.zeros_like(state.position),
+              "m2": torch.zeros_like(state.position), "imm": imm_pc}
+        state, _, run_info = _nuts_run_free(
+            rng_key, state, logdensity_fn, ad["step_size"], imm_pc, num_steps, max_depth,
+            divergence_threshold=div_thr, chain_offset=chain_offset, key_layout="chain_major",
+            store_positions=False, adaptation=ad)
+        step_size = torch.empty_like(ad["log_x_avg"])
+        _lib.call("bjx_exp", _lib.current_stream(), n, ad["log_x_avg"].data_ptr(), step_size.data_ptr())
+        parameters = {"step_size": step_size, "inverse_mass_matrix": imm_pc, **extra_parameters}
+        return AdaptationResults(state, parameters), run_info
+
+    def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0,
+            free_running: bool = False):
+        """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains).
+        ``free_running=True`` (NUTS, diagonal metric): see ``_run_free_running``."""
         position = check_batch(position, "position")
         n, d = position.shape
         run_key = key_words(rng_key)
@@ -231,6 +293,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                                   device=position.device).contiguous()
         eps0 = torch.full((n,), float(initial_step_size), dtype=torch.float32, device=position.device)
         ss, _ = _da_init(eps0, from_log_avg=False)
+        if free_running:
+            return _run_free_running(rng_key, state, imm, ss, eps0, int(num_steps), chain_offset)
         zeros = torch.zeros_like(position)
         # Welford second moments: (N, D) diagonal, or (N, D, D) dense -- one matrix PER CHAIN, the
         # semantics of a vmapped dense warmup (N * D^2 words: meant for moderate N * D^2)

@@ -855,6 +855,76 @@ k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __
   });
 }
 
+// Per-chain window adaptation at the end of transition t (include/bjx_nuts.h, adapt_* fields): the
+// arithmetic of k_welford_update_diag, k_da_update, k_welford_final_diag and k_da_init
+// (bjx_adapt.hip), expression for expression, applied to one chain by its own wave.
+template <int VEC>
+__device__ __forceinline__ void async_adapt_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
+                                                  int64_t c, int32_t t) {
+  const int lane = threadIdx.x & 63;
+  const float* tab = ax.adapt_tab + (int64_t)t * BJX_NUTS_ADAPT_COLS;
+  const int flags = (int)tab[BJX_NUTS_AT_FLAGS];
+  const int64_t base = c * nt.D;
+  if (flags & 1) {  // slow window: Welford update with the chain's new position (mass_matrix.py:410-435)
+    const float n = tab[BJX_NUTS_AT_WEL_N];
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> x = ldr<VEC>(ax.q + base + j0);
+      Row<VEC> m = ldr<VEC>(ax.adapt_mean + base + j0), s2 = ldr<VEC>(ax.adapt_m2 + base + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = x.v[e] - m.v[e];
+        const float mo = m.v[e] + d / n;
+        s2.v[e] = fmaf(d, x.v[e] - mo, s2.v[e]);
+        m.v[e] = mo;
+      }
+      str<VEC>(ax.adapt_mean + base + j0, m);
+      str<VEC>(ax.adapt_m2 + base + j0, s2);
+    }
+  }
+  // dual averaging with gradient = target - acceptance_rate (dual_averaging.py:101-123)
+  const float reg = tab[BJX_NUTS_AT_DA_REG], inv_reg = tab[BJX_NUTS_AT_DA_INV_REG];
+  const float eta = tab[BJX_NUTS_AT_DA_ETA], coef = tab[BJX_NUTS_AT_DA_COEF];
+  const float g = ax.adapt_target - FS(BJX_NUTS_F_ACC, c);
+  float ae = (1.0f - inv_reg) * ax.adapt_avg_err[c] + g / reg;
+  const float lx_prev = ax.adapt_log_x[c];
+  float mu = ax.adapt_mu[c];
+  float lx = mu - coef * ae;
+  float lxa = eta * lx_prev + (1.0f - eta) * ax.adapt_log_x_avg[c];
+  float step = exp_cr(lx);
+  if (flags & 2) {  // window end: metric update + Welford reset, dual averaging restarts (staged_adaptation.py:233-249)
+    const float nm1 = tab[BJX_NUTS_AT_FIN_NM1], beta_data = tab[BJX_NUTS_AT_FIN_BETA_DATA];
+    const float beta_prev = tab[BJX_NUTS_AT_FIN_BETA_PREV], freg = tab[BJX_NUTS_AT_FIN_REG];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // m2 just written by this wave's lanes
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> s2 = ldr<VEC>(ax.adapt_m2 + base + j0), pv = ldr<VEC>(ax.adapt_imm + base + j0);
+      Row<VEC> im, zero;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float cov = s2.v[e] / nm1;
+        im.v[e] = fmaf(beta_prev, pv.v[e], beta_data * cov) + freg;
+        zero.v[e] = 0.0f;
+      }
+      str<VEC>(ax.adapt_imm + base + j0, im);
+      str<VEC>(ax.adapt_mean + base + j0, zero);
+      str<VEC>(ax.adapt_m2 + base + j0, zero);
+    }
+    const float x = exp_cr(lxa);
+    lx = (float)log((double)x);
+    mu = (float)log((double)(10.0f * x));
+    lxa = 0.0f;
+    ae = 0.0f;
+    step = exp_cr(lx);
+  }
+  if (lane == 0) {
+    ax.adapt_avg_err[c] = ae;
+    ax.adapt_log_x[c] = lx;
+    ax.adapt_log_x_avg[c] = lxa;
+    ax.adapt_mu[c] = mu;
+    ax.adapt_step_size[c] = step;
+    if (ax.out_step_size) ax.out_step_size[(int64_t)t * nt.N + c] = step;
+  }
+}
+
 // Tick, part 2 (phase 3: subtree complete; phase 0: start a transition): merge, then either the
 // next doubling, or record the finished transition, accept its proposal and start the next one.
 template <int VEC>
@@ -896,6 +966,10 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
         if (ax.out_num_trajectory_expansions) ax.out_num_trajectory_expansions[row] = IS(BJX_NUTS_I_DEPTH, c);
         if (ax.out_is_divergent) ax.out_is_divergent[row] = (uint8_t)(IS(BJX_NUTS_I_DIV, c) != 0);
         if (ax.out_is_turning) ax.out_is_turning[row] = (uint8_t)(IS(BJX_NUTS_I_TURN, c) != 0);
+      }
+      if (ax.adapt_tab) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ax.q: written above, read by the Welford update
+        async_adapt_chain<VEC>(nt, ax, c, t);
       }
       t += 1;
       if (lane == 0) ax.t[c] = t;
@@ -1237,6 +1311,13 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                 "bjx_nuts_async_tick: run->q / g / p must alias nuts->q0 / g0 / p0");
   BJX_CHECK_ARG(run->n_rows >= 0 && run->n_rows <= nuts->N && (run->rows || run->n_rows == nuts->N),
                 "bjx_nuts_async_tick: n_rows must be N when rows is NULL and never exceed N");
+  BJX_CHECK_ARG(!run->adapt_tab ||
+                    (run->adapt_log_x && run->adapt_log_x_avg && run->adapt_avg_err && run->adapt_mu &&
+                     run->adapt_step_size && run->adapt_mean && run->adapt_m2 && run->adapt_imm &&
+                     nuts->eps_per_chain == run->adapt_step_size && nuts->imm == run->adapt_imm &&
+                     nuts->imm_stride == nuts->D),
+                "bjx_nuts_async_tick: adaptation needs every adapt_* buffer, nuts->eps_per_chain == "
+                "adapt_step_size and nuts->imm == adapt_imm with imm_stride == D");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
   const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
@@ -1251,7 +1332,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const bool fused = run->n_rows <= fused_rows;
   if (fused) {
     const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
-    if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+    if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {
       const int ni = nuts_resident_ni(nuts, qf, gf);
       if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
       else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
@@ -1270,7 +1351,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     hipLaunchKernelGGL((k_nuts_async_leaf<V, NI_, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
     hipLaunchKernelGGL((k_nuts_async_boundary<V, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf);            \
   } while (0)
-    if (nuts_vec4(nuts, qf, gf, run->out_position)) {
+    if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {
       const int ni = nuts_resident_ni(nuts, qf, gf);
       if (grouped) {
         if (ni == 1) BJX_TICK2(4, 1, true, grid);

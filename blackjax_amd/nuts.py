@@ -23,7 +23,7 @@ Two drivers with identical results:
 from __future__ import annotations
 
 import ctypes
-from typing import Callable, NamedTuple
+from typing import Callable, NamedTuple, Optional
 
 import torch
 
@@ -322,12 +322,13 @@ class NUTSRunInfo(NamedTuple):
     num_trajectory_expansions: torch.Tensor
     is_divergent: torch.Tensor
     is_turning: torch.Tensor
+    step_size: Optional[torch.Tensor] = None  # adaptation runs only: the step size after transition t's update
 
 
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048):
+             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048, adaptation=None):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -350,6 +351,12 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     the second chunk on whatever the batch size and lets a capture error propagate, ``False`` never
     captures.
 
+    ``adaptation``: per-chain window adaptation carried by the chains themselves (include/bjx_nuts.h,
+    ``adapt_*`` fields; built by ``window_adaptation(...).run(..., free_running=True)``): a dict with the
+    host table ``tab`` (``(num_steps, NUTS_ADAPT_COLS)`` float32), ``target`` and the device buffers
+    ``log_x, log_x_avg, avg_err, mu, step_size`` (N,), ``mean, m2, imm`` (N, D), all updated in place;
+    ``step_size`` / ``inverse_mass_matrix`` arguments are then ignored in favour of those buffers.
+
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
     import numpy as np
@@ -368,16 +375,43 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if key_layout not in ("step_major", "chain_major"):
         raise ValueError("key_layout must be 'step_major' or 'chain_major'")
     vg = value_and_grad(logdensity_fn)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    adapt_fields = {}
+    out_step_size = None
+    if adaptation is not None:
+        ad = adaptation
+        for name, shape in (("log_x", (N,)), ("log_x_avg", (N,)), ("avg_err", (N,)), ("mu", (N,)),
+                            ("step_size", (N,)), ("mean", (N, D)), ("m2", (N, D)), ("imm", (N, D))):
+            b = ad[name]
+            if not (isinstance(b, torch.Tensor) and b.is_cuda and b.dtype == torch.float32
+                    and tuple(b.shape) == shape and b.is_contiguous()):
+                raise ValueError(f"adaptation['{name}'] must be a contiguous float32 device tensor of shape {shape}")
+        tab_host = np.ascontiguousarray(ad["tab"], dtype=np.float32)
+        if tab_host.shape != (T, _lib.NUTS_ADAPT_COLS):
+            raise ValueError(f"adaptation['tab'] must have shape ({T}, {_lib.NUTS_ADAPT_COLS})")
+        adapt_tab = torch.as_tensor(tab_host, device=dev)
+        out_step_size = torch.empty((T, N), **f32)
+        step_size, inverse_mass_matrix = ad["step_size"], metrics.PerChainDiag(ad["imm"])
+        adapt_fields = dict(
+            adapt_tab=adapt_tab.data_ptr(), adapt_target=float(ad["target"]), adapt_reserved=0.0,
+            adapt_log_x=ad["log_x"].data_ptr(), adapt_log_x_avg=ad["log_x_avg"].data_ptr(),
+            adapt_avg_err=ad["avg_err"].data_ptr(), adapt_mu=ad["mu"].data_ptr(),
+            adapt_step_size=ad["step_size"].data_ptr(), adapt_mean=ad["mean"].data_ptr(),
+            adapt_m2=ad["m2"].data_ptr(), adapt_imm=ad["imm"].data_ptr(),
+            out_step_size=out_step_size.data_ptr())
     metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
     if metric.kind != "diag":
         raise NotImplementedError("free-running chains are implemented for diagonal metrics only")
     eps, eps_pc = step_size_args(step_size, N, dev)
-    f32 = dict(dtype=torch.float32, device=dev)
-    i32 = dict(dtype=torch.int32, device=dev)
+    if adaptation is not None and (eps_pc is None or eps_pc.data_ptr() != adaptation["step_size"].data_ptr()
+                                   or metric.imm.data_ptr() != adaptation["imm"].data_ptr()
+                                   or metric.imm_stride != D):
+        raise RuntimeError("adaptation buffers were copied on the way to the kernels")
     info = NUTSRunInfo(torch.empty((T, N), **f32), torch.empty((T, N), **f32), torch.empty((T, N), **f32),
                        torch.empty((T, N), **i32), torch.empty((T, N), **i32),
                        torch.empty((T, N), dtype=torch.bool, device=dev),
-                       torch.empty((T, N), dtype=torch.bool, device=dev))
+                       torch.empty((T, N), dtype=torch.bool, device=dev), out_step_size)
     positions = torch.empty((T, N, D), **f32) if store_positions else None
     if T == 0 or N == 0:
         return HMCState(q, logp, g), positions, info
@@ -415,7 +449,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         out_energy=info.energy.data_ptr(),
         out_num_integration_steps=info.num_integration_steps.data_ptr(),
         out_num_trajectory_expansions=info.num_trajectory_expansions.data_ptr(),
-        out_is_divergent=info.is_divergent.data_ptr(), out_is_turning=info.is_turning.data_ptr())
+        out_is_divergent=info.is_divergent.data_ptr(), out_is_turning=info.is_turning.data_ptr(),
+        **adapt_fields)
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     logp_f = torch.zeros(N, **f32)  # the first tick only starts transitions: nothing reads these

@@ -185,7 +185,41 @@ typedef struct {
   int32_t* out_num_trajectory_expansions;
   uint8_t* out_is_divergent;
   uint8_t* out_is_turning;
+  /* Optional per-chain window adaptation (blackjax/adaptation/staged_adaptation.py:186-249 as a
+   * vmapped warm-up runs it: every chain adapts its own step size and diagonal inverse mass matrix).
+   * adapt_tab == NULL: none.  Otherwise, when chain c completes transition t it runs, in this order,
+   * the Welford update with its new position if the transition lies in a slow window
+   * (mass_matrix.py:410-435), the dual-averaging update with the transition's acceptance rate
+   * (dual_averaging.py:101-123, step_size.py:144) and, at a window end, the inverse-mass-matrix
+   * update + Welford reset (mass_matrix.py:335-357) and the dual-averaging restart from the averaged
+   * log step size (staged_adaptation.py:233-249) -- then starts transition t + 1 with the new
+   * step size and metric.  The schedule and every scalar that depends only on t are tabulated by the
+   * host: adapt_tab is (n_steps, BJX_NUTS_ADAPT_COLS) floats, columns BJX_NUTS_AT_*.
+   * Requires nuts->eps_per_chain == adapt_step_size and nuts->imm == adapt_imm with imm_stride == D. */
+  const float* adapt_tab;
+  float adapt_target;         /* target acceptance rate */
+  float adapt_reserved;
+  float *adapt_log_x, *adapt_log_x_avg, *adapt_avg_err, *adapt_mu; /* (N,) dual-averaging state, in/out */
+  float* adapt_step_size;     /* (N,) in/out */
+  float *adapt_mean, *adapt_m2; /* (N, D) Welford state, in/out */
+  float* adapt_imm;           /* (N, D) per-chain diagonal inverse mass matrix, in/out */
+  float* out_step_size;       /* optional (n_steps, N): the step size after the update of transition t */
 } bjx_nuts_async_t;
+
+/* columns of adapt_tab */
+enum {
+  BJX_NUTS_AT_FLAGS = 0,      /* 1 = slow window (Welford update), 2 = window end; as a float */
+  BJX_NUTS_AT_DA_REG = 1,     /* dual averaging: step + t0 */
+  BJX_NUTS_AT_DA_INV_REG = 2, /* 1 / (step + t0) */
+  BJX_NUTS_AT_DA_ETA = 3,     /* step^-kappa */
+  BJX_NUTS_AT_DA_COEF = 4,    /* sqrt(step) / gamma */
+  BJX_NUTS_AT_WEL_N = 5,      /* Welford sample size AFTER this transition's update */
+  BJX_NUTS_AT_FIN_NM1 = 6,    /* window end: sample_size - 1 */
+  BJX_NUTS_AT_FIN_BETA_DATA = 7,
+  BJX_NUTS_AT_FIN_BETA_PREV = 8,
+  BJX_NUTS_AT_FIN_REG = 9,
+  BJX_NUTS_ADAPT_COLS = 12
+};
 
 /* One tick for the chains of the compact rows.  logp_f (n_rows,), gf (n_rows, D): callable outputs at
  * qf from the previous tick (ignored by chains in phase 0); qf (n_rows, D): positions whose
