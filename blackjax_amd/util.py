@@ -38,7 +38,7 @@ def stack_history(history):
 def run_inference_algorithm(rng_key, inference_algorithm, num_steps: int, initial_state=None,
                             initial_position=None,
                             transform: Callable = lambda state, info: (state, info),
-                            *, key_layout: str = "step_major"):
+                            *, key_layout: str = "step_major", free_running: bool = False):
     """blackjax/util.py:150-213.  ``keys = split(rng_key, num_steps)``; step ``t`` calls
     ``inference_algorithm.step(keys[t], state)`` which derives chain ``i``'s key as
     ``split(keys[t], N)[i]`` ("step_major", the vmap-inside-scan layout of
@@ -47,6 +47,10 @@ def run_inference_algorithm(rng_key, inference_algorithm, num_steps: int, initia
     step key ``split(chain_key, num_steps)[t]``; tests/mcmc/test_sampling.py:1454-1465).
 
     Returns ``(final_state, history)`` with ``history`` stacked along a leading step axis.
+
+    ``free_running=True`` (algorithms with a ``run`` method, i.e. NUTS): the same transitions, same
+    keys, same draws, driven without lockstep across transitions (``nuts.run_free``); ``transform``
+    is not applied, ``history`` is ``(positions (num_steps, N, D), NUTSRunInfo)``.
     """
     if initial_state is None and initial_position is None:
         raise ValueError("Either `initial_state` or `initial_position` must be provided.")
@@ -58,6 +62,12 @@ def run_inference_algorithm(rng_key, inference_algorithm, num_steps: int, initia
         rng_key, init_key = bjx_random.split(rng_key, 2)
         initial_state = inference_algorithm.init(initial_position, init_key)
     state = initial_state
+    if free_running:
+        run = getattr(inference_algorithm, "run", None)
+        if run is None:
+            raise NotImplementedError("free_running=True needs an algorithm with a run method (blackjax_amd.nuts)")
+        state, positions, info = run(rng_key, state, num_steps, key_layout=key_layout)
+        return state, (positions, info)
     history = []
     if key_layout == "step_major":
         keys = bjx_random.split(rng_key, num_steps)

@@ -109,3 +109,22 @@ def test_free_running_equals_lockstep_steps_at_scale(dev):
     final3, pos3, info3 = alg_g.run(bjx.random.key(9), st0, T)
     assert torch.equal(pos3, positions) and torch.equal(final3.logdensity_grad, final.logdensity_grad)
     assert torch.equal(info3.num_integration_steps, info.num_integration_steps)
+
+
+def test_run_inference_algorithm_free_running_matches_step_loop(dev):
+    """blackjax/util.py:150-213 over nuts.step == the same call with free_running=True."""
+    N, D, T = 40, 12, 9
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    fn = bjx.targets.NealFunnel()
+    alg = bjx.nuts(fn, 0.2, torch.ones(D, device=dev), max_num_doublings=5)
+    q0 = 0.3 * torch.randn(N, D, device=dev, generator=g)
+    for layout in ("step_major", "chain_major"):
+        st_a, (states, infos) = bjx.util.run_inference_algorithm(prng.key(3), alg, T, initial_position=q0,
+                                                                 key_layout=layout)
+        st_b, (positions, rinfo) = bjx.util.run_inference_algorithm(prng.key(3), alg, T, initial_position=q0,
+                                                                    key_layout=layout, free_running=True)
+        assert torch.equal(st_a.position, st_b.position)
+        assert torch.equal(states.position, positions)
+        assert torch.equal(infos.acceptance_rate, rinfo.acceptance_rate)
+        assert torch.equal(infos.is_divergent, rinfo.is_divergent)
