@@ -17,14 +17,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("N,D,T,max_depth", [(48, 8, 130, 5), (33, 256, 40, 4), (16, 12, 19, 3)])
-def test_free_running_warmup_equals_lockstep(dev, N, D, T, max_depth):
+@pytest.mark.parametrize("N,D,T,max_depth,shrink", [(48, 8, 130, 5, 0.0), (33, 256, 40, 4, 0.0),
+                                                     (16, 12, 19, 3, 0.0), (10, 7, 130, 4, 0.0),
+                                                     (21, 20, 150, 4, 2.5)])
+def test_free_running_warmup_equals_lockstep(dev, N, D, T, max_depth, shrink):
     g = torch.Generator(device=dev)
     g.manual_seed(N + D)
     inv_var = (torch.rand(D, device=dev, generator=g) * 3.0 + 0.2).contiguous()
     fn = bjx.targets.DiagGaussian(inv_var)
     q0 = torch.randn(N, D, device=dev, generator=g)
-    kw = dict(initial_step_size=0.7, target_acceptance_rate=0.8, max_num_doublings=max_depth)
+    kw = dict(initial_step_size=0.7, target_acceptance_rate=0.8, max_num_doublings=max_depth,
+              imm_shrinkage_to_previous=shrink)
     warm = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=bjx.adaptation.get_filter_adapt_info_fn(
         set(), {"acceptance_rate", "num_integration_steps"}, {"step_size"}), **kw)
     key = prng.key(11)
