@@ -256,15 +256,32 @@ k_nuts_init(bjx_nuts_t nt, const float* __restrict__ logp0, const float* __restr
 __device__ __forceinline__ int nuts_begin_doubling(const bjx_nuts_t& nt, const StepCtx& cx, int64_t c,
                                                    int32_t depth) {
   const int lane = threadIdx.x & 63;
-  const Key subkey = key_child(integrator_key(cx, c), (uint64_t)depth);  // trajectory.py:645
+  // The transition's integrator key (nuts.py:133) is derived once, at doubling 0, and kept in the
+  // slot table; so are the doubling's leaf-sampling and proposal keys below.  A leaf or a merge then
+  // runs the threefry blocks that depend on its own index only.
+  Key ik;
+  if (depth == 0) {
+    ik = integrator_key(cx, c);
+    if (lane == 0) {
+      IS(BJX_NUTS_I_IK, c) = (int32_t)ik.k0;
+      IS(BJX_NUTS_I_IKB, c) = (int32_t)ik.k1;
+    }
+  } else {
+    ik = Key{(uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_IK, c)),
+             (uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_IKB, c))};
+  }
+  const Key subkey = key_child(ik, (uint64_t)depth);                      // trajectory.py:645
   const Key kd = key_child(subkey, 0);                                    // split(subkey,3)[0]
   const int dir = key_uniform(kd) < 0.5f ? 1 : -1;                        // trajectory.py:650
   // split(subkey,3)[1]: every leaf of this doubling folds its index into this key (trajectory.py:
   // 329-339); kept in the slot table so a leaf derives ONE key instead of the whole chain of five
   const Key kt = key_child(subkey, 1);
+  const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]: progressive_biased_sampling at the merge
   if (lane == 0) {
     IS(BJX_NUTS_I_KT, c) = (int32_t)kt.k0;
     IS(BJX_NUTS_I_KTB, c) = (int32_t)kt.k1;
+    IS(BJX_NUTS_I_KP, c) = (int32_t)kp.k0;
+    IS(BJX_NUTS_I_KPB, c) = (int32_t)kp.k1;
     IS(BJX_NUTS_I_DIR, c) = dir;
     IS(BJX_NUTS_I_SUB_ACTIVE, c) = 1;
     IS(BJX_NUTS_I_SDIV, c) = 0;
@@ -681,8 +698,8 @@ __device__ __forceinline__ bool nuts_merge_chain(const bjx_nuts_t& nt, const Ste
   const Scalars3 sc = scalars3((double)(sw - pw), pslpa, sslpa, pw, sw);
   const float new_pslpa = sc.lae1;
   if (!(sdiv || sturn)) {  // progressive_biased_sampling (proposal.py:146-176)
-    const Key subkey = key_child(integrator_key(kcx, c), (uint64_t)depth);
-    const Key kp = key_child(subkey, 2);  // split(subkey,3)[2]
+    const Key kp{(uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KP, c)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_KPB, c))};  // nuts_begin_doubling
     const float pa = min1_nan(sc.e0);
     take = key_uniform(kp) < pa;
     new_pw = sc.lae2;

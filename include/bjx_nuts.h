@@ -57,7 +57,11 @@ enum {
   BJX_NUTS_I_DEPTH = 9,      /* NUTSInfo.num_trajectory_expansions */
   BJX_NUTS_I_KT = 10,        /* the two words of the current doubling's leaf-sampling key: */
   BJX_NUTS_I_KTB = 11,       /*   split(fold_in(integrator_key, depth), 3)[1], written once per doubling */
-  BJX_NUTS_NI = 12
+  BJX_NUTS_I_KP = 12,        /* likewise the doubling's proposal key split(...)[2] (merge step) */
+  BJX_NUTS_I_KPB = 13,
+  BJX_NUTS_I_IK = 14,        /* the transition's integrator key split(chain_key, 2)[1], written at doubling 0 */
+  BJX_NUTS_I_IKB = 15,
+  BJX_NUTS_NI = 16
 };
 
 typedef struct {
