@@ -14,11 +14,13 @@ All tree arithmetic (progressive sampling, momentum sums, U-turn checkpoints, me
 ``bjx_nuts.hip``.
 
 Two drivers with identical results:
-* eager (default): three launches per leapfrog (pre, callable, post) issued from Python;
-* ``use_graph=True``: chunks of up to 16 leapfrogs are captured once in HIP graphs over a static
-  workspace and replayed; everything that changes between replays (doubling, leaf index, active
-  row count, keys) lives in a small device control block.  This removes the per-launch host cost,
-  which otherwise dominates because a NUTS transition is hundreds of short launches.
+* eager (``use_graph=False``): three launches per leapfrog (pre, callable, post) issued from Python;
+* graph (``use_graph=True``): chunks of up to 16 leapfrogs are captured once in HIP graphs over a
+  static workspace and replayed; everything that changes between replays (doubling, leaf index,
+  active row count, keys) lives in a small device control block.  This removes the per-launch host
+  cost, which otherwise dominates because a NUTS transition is hundreds of short launches.
+The default ``use_graph="auto"`` takes the graph driver and falls back to the eager one for a
+callable that cannot be recorded.
 """
 from __future__ import annotations
 
@@ -158,10 +160,16 @@ class _GraphWorkspace:
 
 
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: int = 1000, *,
-                 recompact_every: int = 16, use_graph: bool = False, graph_sync_every: int = 4):
-    """blackjax/mcmc/nuts.py:77-147.  ``graph_sync_every``: in graph mode the host reads the
-    active-row count back only every that many 16-leapfrog chunks (to stop early / shrink the
-    callable's batch); compaction itself happens on the device every chunk."""
+                 recompact_every: int = 16, use_graph="auto", graph_sync_every: int = 4):
+    """blackjax/mcmc/nuts.py:77-147.  ``use_graph``: ``True`` = the HIP-graph driver, ``False`` =
+    plain launches (three per leaf from Python: host-bound once a leaf is a few microseconds of GPU
+    work), ``"auto"`` (default) = the graph driver unless the log-density callable turns out not to
+    be capturable (it synchronises with the host, say), in which case that callable is driven with
+    plain launches from then on.  ``graph_sync_every``: in graph mode the host reads the active-row
+    count back only every that many 16-leapfrog chunks (to stop early / shrink the callable's
+    batch); compaction itself happens on the device every chunk."""
+    if use_graph not in (True, False, "auto"):
+        raise ValueError("use_graph must be True, False or 'auto'")
     integrators.check_supported(integrator)
     thr = float(divergence_threshold)
     I = _lib.NUTS_I
@@ -308,6 +316,25 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             _lib.call("bjx_nuts_merge", stream, dref, depth, n_doubling, idx_doubling.data_ptr())
         return _make_info(p0, ws.bufs, ws.fs, ws.is_, clone=True)
 
+    not_capturable: set = set()  # ids of callables whose capture failed once
+
+    def kernel_auto(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+                    inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
+        if id(logdensity_fn) not in not_capturable and state.position.shape[0] > 0:
+            try:
+                return kernel_graph(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
+                                    max_num_doublings, chain_offset=chain_offset)
+            except RuntimeError:
+                # recording the callable failed (or the callable itself is broken, in which case the
+                # plain driver below raises the same error again); the transition restarts from
+                # `state`, which the graph driver never modifies
+                not_capturable.add(id(logdensity_fn))
+                torch.cuda.synchronize(state.position.device)
+        return kernel_eager(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
+                            max_num_doublings, chain_offset=chain_offset)
+
+    if use_graph == "auto":
+        return kernel_auto
     return kernel_graph if use_graph else kernel_eager
 
 
@@ -533,7 +560,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
-                     recompact_every: int = 16, use_graph: bool = False,
+                     recompact_every: int = 16, use_graph="auto",
                      graph_sync_every: int = 4, run_use_graph="auto") -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
@@ -557,6 +584,6 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,
                         store_positions=store_positions,
-                        use_graph=True if use_graph else run_use_graph)
+                        use_graph=True if use_graph is True else run_use_graph)
 
     return SamplingAlgorithm(init_fn, step_fn, run_fn)

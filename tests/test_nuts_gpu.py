@@ -148,3 +148,35 @@ def test_nuts_dense_metric_parity(dev, per_chain, use_graph):
         np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(t2n(info_g.momentum), info_o.momentum, rtol=1e-5, atol=1e-6)
+
+
+def test_nuts_default_driver_falls_back_for_a_syncing_callable(dev):
+    """use_graph="auto" (default): an autograd callable is driven through HIP graphs, a callable that
+    synchronises with the host cannot be recorded and is driven with plain launches -- same draws."""
+    N, D = 96, 12
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    iv = torch.linspace(0.5, 2.0, D, device=dev)
+    calls = {"n": 0}
+
+    def plain(q):
+        return -0.5 * (q * q * iv).sum(-1)
+
+    def syncing(q):
+        lp = -0.5 * (q * q * iv).sum(-1)
+        calls["n"] += int(lp.numel() > 0 and float(lp.sum().item()) == float("inf"))  # host sync
+        return lp
+
+    ref = bjx.nuts(plain, 0.3, torch.ones(D, device=dev), max_num_doublings=5, use_graph=False)
+    st = ref.init(q0)
+    keys = prng.split(prng.key(4), 3)
+    for fn in (plain, syncing):
+        alg = bjx.nuts(fn, 0.3, torch.ones(D, device=dev), max_num_doublings=5)  # default driver
+        s_r, s_a = st, st
+        for k in keys:
+            s_r, i_r = ref.step(k, s_r)
+            s_a, i_a = alg.step(k, s_a)
+            assert torch.equal(s_r.position, s_a.position)
+            assert torch.equal(i_r.num_integration_steps, i_a.num_integration_steps)
+            assert torch.equal(i_r.acceptance_rate, i_a.acceptance_rate)
