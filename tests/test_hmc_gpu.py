@@ -357,3 +357,35 @@ def test_full_size_leapfrog_reversibility_and_energy(dev):
     scale = dev_t(sig, dev)
     assert ((q2 - q0).abs() / scale).max().item() < 2e-4
     assert ((p2 + p0).abs() * scale).max().item() < 2e-4
+
+
+def test_hmc_default_driver_graph_and_fallback(dev):
+    """use_graph="auto" (default): small blocks are driven through a HIP graph of the inner loop, a
+    callable that synchronises with the host falls back to plain launches -- same results."""
+    N, D, L = 200, 16, 7
+    g_ = torch.Generator(device=dev)
+    g_.manual_seed(9)
+    q0 = torch.randn(N, D, device=dev, generator=g_)
+    iv = torch.linspace(0.5, 2.0, D, device=dev)
+
+    def plain(q):
+        return -0.5 * (q * q * iv).sum(-1)
+
+    def syncing(q):
+        lp = -0.5 * (q * q * iv).sum(-1)
+        assert float(lp.sum().item()) < float("inf")  # host sync: cannot be recorded
+        return lp
+
+    imm = torch.ones(D, device=dev)
+    ref = bjx.hmc(plain, 0.2, imm, L, use_graph=False)
+    st = ref.init(q0)
+    keys = prng.split(prng.key(6), 3)
+    for fn in (plain, syncing):
+        alg = bjx.hmc(fn, 0.2, imm, L)  # default driver
+        s_r, s_a = st, st
+        for k in keys:
+            s_r, i_r = ref.step(k, s_r)
+            s_a, i_a = alg.step(k, s_a)
+            assert torch.equal(s_r.position, s_a.position)
+            assert torch.equal(i_r.acceptance_rate, i_a.acceptance_rate)
+            assert torch.equal(i_r.proposal.position, i_a.proposal.position)
