@@ -257,6 +257,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         chain_block = _default_chain_block()
     graphs: dict = {}
     not_capturable: set = set()  # ids of callables whose capture failed once ("auto" mode)
+    seen: dict = {}              # "auto" mode: calls per (shape, L, callable)
 
     def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
@@ -300,10 +301,14 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         if (use_graph == "auto" and L >= 2 and N > 0 and metric.kind == "diag" and not general
                 and blk * D <= (1 << 21) and id(vg) not in not_capturable):
             gkey = (min(blk, N), D, L, id(vg), metric.imm_stride != 0, dev.index)
+            # record on the SECOND call with a given shape and trajectory length (a one-off call --
+            # or a caller that varies L from step to step -- should not pay for a recording), and
+            # keep at most 8 recordings per kernel
+            seen[gkey] = seen.get(gkey, 0) + 1
             try:
-                if gkey not in graphs:
+                if gkey not in graphs and seen[gkey] >= 2 and len(graphs) < 8:
                     graphs[gkey] = _GraphedTrajectory(min(blk, N), D, L, vg, metric.imm_stride != 0, dev)
-                graphed = True
+                graphed = gkey in graphs
             except RuntimeError:  # the callable cannot be recorded (or is broken: the plain path re-raises)
                 not_capturable.add(id(vg))
                 torch.cuda.synchronize(dev)
