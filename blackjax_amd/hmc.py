@@ -236,7 +236,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     ``"auto"`` (default): do so when a block is small enough for its launches to be bound by the
     host's launch rate (at most 2^21 elements: a leapfrog launch is then under ~10 us of GPU work;
     at 65 536 x 1 024 graphs measured no faster than plain launches), and fall back to plain
-    launches for a callable that cannot be recorded.
+    launches for a callable that cannot be recorded.  As under ``jax.jit`` in the reference, a
+    recorded callable is replayed as recorded: Python-side state it reads (a minibatch index, say)
+    is frozen at recording time -- pass ``use_graph=False`` for such a callable.
     """
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")

@@ -165,7 +165,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     plain launches (three per leaf from Python: host-bound once a leaf is a few microseconds of GPU
     work), ``"auto"`` (default) = the graph driver unless the log-density callable turns out not to
     be capturable (it synchronises with the host, say), in which case that callable is driven with
-    plain launches from then on.  ``graph_sync_every``: in graph mode the host reads the active-row
+    plain launches from then on.  As under ``jax.jit`` in the reference, a recorded callable is
+    replayed as recorded: Python-side state it reads is frozen at recording time (``use_graph=False``
+    for such a callable).  ``graph_sync_every``: in graph mode the host reads the active-row
     count back only every that many 16-leapfrog chunks (to stop early / shrink the callable's
     batch); compaction itself happens on the device every chunk."""
     if use_graph not in (True, False, "auto"):
