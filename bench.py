@@ -149,6 +149,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    host_enqueue_ms = []  # per measure() call: host time to queue one transition
+    per_step_ms = []      # per measure() call: GPU time of every timed transition (HIP events)
+
     def measure(chain_block, use_graph, collect_draws):
         """W warm-up + K timed transitions in one scheduling mode.  The warm-up runs EXACTLY the
         timed loop's body (bookkeeping torch ops and launch-timer events included) plus one priming
@@ -184,17 +187,25 @@ def main():
             _lib.set_timer(timer)
         acc_sum = torch.zeros((), device=dev)
         draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
+        step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        for ev in step_marks:
+            ev.record()  # HIP events are created at the first record(): do that outside the region
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        step_marks[0].record()
         for t in range(args.warmup, args.warmup + args.steps):
             state, info = alg.step(keys[t], state)
             acc_sum += info.acceptance_rate.mean()
             if collect_draws:
                 draws.append(state.position[:n_sub].clone())
+            step_marks[t - args.warmup + 1].record()
+        t_enq = time.perf_counter() - t0  # the host has queued everything; the GPU may still be working
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        host_enqueue_ms.append(t_enq / max(args.steps, 1) * 1e3)
+        per_step_ms.append([round(a.elapsed_time(b), 3) for a, b in zip(step_marks, step_marks[1:])])
         _lib.set_timer(None)
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -214,6 +225,25 @@ def main():
                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                     "chains_per_launch": min(chain_block, N), "avg_launch_us": avg_s * 1e6,
                     "launches_timed": len(d_ms), "timed_every": every}
+            # What the bracket itself costs: a pair of event records around NOTHING, behind a kernel
+            # of the same kind so the queue is in the same state.  Reported beside the raw figure
+            # (`achieved` / `frac` stay on the raw one); rocprofv3's kernel-trace average for this
+            # kernel (profiles/) should sit near avg_launch_us - event_bracket_overhead_us.
+            try:
+                empties = []
+                probe = torch.zeros(min(chain_block, N), D, device=dev)
+                for _ in range(32):
+                    probe.add_(1.0)
+                    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_ev.record()
+                    e_ev.record()
+                    empties.append((s_ev, e_ev))
+                torch.cuda.synchronize()
+                over_us = float(np.median([a.elapsed_time(b) for a, b in empties[8:]])) * 1e3
+                roof["event_bracket_overhead_us"] = over_us
+                roof["avg_launch_us_net_of_bracket"] = avg_s * 1e6 - over_us
+            except Exception:
+                pass
         return state, dt, roof, float(acc_sum.item()) / max(args.steps, 1), draws
 
     # Scheduling autotune (untimed, part of the warm-up): whether Infinity-Cache blocking beats one
@@ -304,6 +334,8 @@ def main():
                 "chain_block": blk, "hip_graph": bool(args.use_graph),
                 "parallelism": f"chains sharded x{world}, no data-path collective",
             },
+            "gpu_ms_of_each_step": per_step_ms[0],
+            "host_enqueue_ms_per_step": host_enqueue_ms[0],  # close to ms_per_step = the host's launch rate is the limit
             "mean_acceptance": mean_acc,
             "ess": None if ess_min is None else {
                 "min_ess_subset": ess_min, "subset_chains": n_sub, "draws_per_chain": args.steps,
