@@ -25,7 +25,7 @@ from ._util import check_batch
 from .base import AdaptationAlgorithm
 from .random import ChainMajorKey, key_words
 
-__all__ = ["window_adaptation", "build_schedule", "AdaptationResults", "AdaptationInfo",
+__all__ = ["window_adaptation", "build_schedule", "free_running_table", "AdaptationResults", "AdaptationInfo",
            "return_all_adapt_info", "get_filter_adapt_info_fn", "DualAveragingAdaptationState",
            "WelfordAlgorithmState", "MassMatrixAdaptationState", "StagedAdaptationState"]
 
@@ -167,6 +167,38 @@ def _mm_final(mm: MassMatrixAdaptationState, shrinkage: float) -> MassMatrixAdap
     return MassMatrixAdaptationState(imm, WelfordAlgorithmState(mean0, torch.zeros_like(m2), 0))
 
 
+def free_running_table(num_steps: int, imm_shrinkage_to_previous: float = 0.0) -> "np.ndarray":
+    """Host table for a free-running warm-up (``bjx_nuts_async_t.adapt_tab``, include/bjx_nuts.h):
+    one row per warm-up step with the schedule flags and every fp32 scalar that depends on the step
+    index only, evaluated exactly as the lockstep entry points evaluate them on the host
+    (``bjx_da_update``: ``step + t0``, its reciprocal, ``step^-kappa``, ``sqrt(step)/gamma``;
+    ``bjx_welford_final_diag``: ``n - 1`` and the blend coefficients of mass_matrix.py:339-343)."""
+    f32 = np.float32
+    tab = np.zeros((num_steps, _lib.NUTS_ADAPT_COLS), f32)
+    AT = _lib.NUTS_AT
+    da_step, wel = 1, 0
+    shrink = f32(imm_shrinkage_to_previous)
+    for t, (stage, is_window_end) in enumerate(build_schedule(num_steps)):
+        tab[t, AT["FLAGS"]] = (1 if stage == 1 else 0) | (2 if is_window_end else 0)
+        if stage == 1:
+            wel += 1
+            tab[t, AT["WEL_N"]] = wel
+        reg = f32(da_step) + f32(_DA_T0)
+        tab[t, AT["DA_REG"]] = reg
+        tab[t, AT["DA_INV_REG"]] = f32(1.0) / reg
+        tab[t, AT["DA_ETA"]] = f32(float(da_step) ** (-float(f32(_DA_KAPPA))))
+        tab[t, AT["DA_COEF"]] = np.sqrt(f32(da_step)) / f32(_DA_GAMMA)
+        da_step += 1
+        if is_window_end:
+            denom = f32(wel + 5) + shrink
+            tab[t, AT["FIN_NM1"]] = f32(wel - 1)
+            tab[t, AT["FIN_BETA_DATA"]] = f32(wel) / denom
+            tab[t, AT["FIN_BETA_PREV"]] = shrink / denom
+            tab[t, AT["FIN_REG"]] = (f32(5.0) / denom) * f32(1e-3)
+            wel, da_step = 0, 1
+    return tab
+
+
 def _stack_history(history):
     """Stack per-step records along a new leading axis, like the ``lax.scan`` output of the
     reference (staged_adaptation.py:870-874)."""
@@ -235,31 +267,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         div_thr = float(extra.pop("divergence_threshold", 1000))
         if extra:
             raise TypeError(f"unexpected parameters for a free-running NUTS warm-up: {sorted(extra)}")
-        # everything that depends on the step index only: schedule flags and the fp32 scalars the
-        # lockstep entry points (bjx_da_update, bjx_welford_final_diag) evaluate on the host
-        f32 = np.float32
-        tab = np.zeros((num_steps, _lib.NUTS_ADAPT_COLS), f32)
-        AT = _lib.NUTS_AT
-        da_step, wel = 1, 0
-        shrink = f32(imm_shrinkage_to_previous)
-        for t, (stage, is_window_end) in enumerate(build_schedule(num_steps)):
-            tab[t, AT["FLAGS"]] = (1 if stage == 1 else 0) | (2 if is_window_end else 0)
-            if stage == 1:
-                wel += 1
-                tab[t, AT["WEL_N"]] = wel
-            reg = f32(da_step) + f32(_DA_T0)
-            tab[t, AT["DA_REG"]] = reg
-            tab[t, AT["DA_INV_REG"]] = f32(1.0) / reg
-            tab[t, AT["DA_ETA"]] = f32(float(da_step) ** (-float(f32(_DA_KAPPA))))
-            tab[t, AT["DA_COEF"]] = np.sqrt(f32(da_step)) / f32(_DA_GAMMA)
-            da_step += 1
-            if is_window_end:
-                denom = f32(wel + 5) + shrink
-                tab[t, AT["FIN_NM1"]] = f32(wel - 1)
-                tab[t, AT["FIN_BETA_DATA"]] = f32(wel) / denom
-                tab[t, AT["FIN_BETA_PREV"]] = shrink / denom
-                tab[t, AT["FIN_REG"]] = (f32(5.0) / denom) * f32(1e-3)
-                wel, da_step = 0, 1
+        tab = free_running_table(num_steps, imm_shrinkage_to_previous)
         imm_pc = (imm if imm.ndim == 2 else imm.expand(n, d)).contiguous().clone()
         ad = {"tab": tab, "target": float(target_acceptance_rate), "log_x": ss.log_step_size.clone(),
               "log_x_avg": ss.log_step_size_avg.clone(), "avg_err": ss.avg_error.clone(), "mu": ss.mu.clone(),
