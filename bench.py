@@ -20,8 +20,13 @@ two untimed transitions in each mode, the faster one is benchmarked and named in
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (fused kick+drift leapfrog): ALGORITHMIC bytes per launch
                   (20 B x D x chains per launch: read p,g,q; write p,q) / mean launch duration
-                  measured with HIP events on the launch stream inside the timed region (every 4th
-                  launch is bracketed when a transition has >= 100 launches); peak 8000 GB/s.
+                  measured with HIP events on the launch stream inside the timed region (every 16th
+                  launch is bracketed when a transition has >= 100 launches, events from a pool
+                  recorded before the region; the cost of an empty bracket is reported beside it);
+                  peak 8000 GB/s.
+Also reported: gpu_ms_of_each_step (HIP events around every timed transition) and
+host_enqueue_ms_per_step -- a run in which the host fell behind shows as long steps at unchanged
+kernel durations.
   cpu_baseline -- the oracle's C/OpenMP port of the same transition timed on the host cores on a
                   bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
 """
