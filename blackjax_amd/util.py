@@ -80,3 +80,67 @@ def run_inference_algorithm(rng_key, inference_algorithm, num_steps: int, initia
             state, info = inference_algorithm.step(bjx_random.ChainMajorKey(run_key, t), state)
             history.append(transform(state, info))
     return state, stack_history(history)
+
+
+# ------------------------------------------------------------------------------- pytree positions
+def _tree_leaves(tree, path=()):
+    """Leaves of a dict / list / tuple tree of tensors in jax.tree_util order (dict keys sorted)."""
+    if isinstance(tree, dict):
+        for k in sorted(tree):
+            yield from _tree_leaves(tree[k], path + (k,))
+    elif isinstance(tree, (list, tuple)):
+        for i, v in enumerate(tree):
+            yield from _tree_leaves(v, path + (i,))
+    else:
+        yield path, tree
+
+
+def _tree_build(tree, leaves_iter):
+    if isinstance(tree, dict):
+        built = {k: _tree_build(tree[k], leaves_iter) for k in sorted(tree)}
+        return type(tree)((k, built[k]) for k in tree) if type(tree) is not dict else {k: built[k] for k in tree}
+    if isinstance(tree, tuple) and hasattr(tree, "_fields"):  # namedtuple
+        return type(tree)(*[_tree_build(v, leaves_iter) for v in tree])
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_tree_build(v, leaves_iter) for v in tree)
+    return next(leaves_iter)
+
+
+def ravel_chain_pytree(tree):
+    """The engine's positions are one ``(N, D)`` tensor; the reference accepts any pytree of arrays
+    (a dict of parameters, say) and flattens it with ``jax.flatten_util.ravel_pytree`` where it
+    needs a vector (adaptation/mass_matrix.py:288-291, util.py:66-91).  This is the batched
+    counterpart: ``tree`` is a dict / list / tuple tree whose leaves are ``(N, ...)`` tensors (chain
+    axis first); returns ``(flat, unravel)`` with ``flat`` the ``(N, D)`` float32 tensor of the leaves
+    concatenated in ``jax.tree_util`` order (dict keys sorted) and ``unravel(x)`` mapping any
+    ``(M, D)`` tensor back to a tree of ``(M, ...)`` views of it (differentiable)."""
+    import torch
+
+    leaves = [leaf for _, leaf in _tree_leaves(tree)]
+    if not leaves:
+        raise ValueError("ravel_chain_pytree: the tree has no leaves")
+    n = leaves[0].shape[0]
+    for path, leaf in _tree_leaves(tree):
+        if not isinstance(leaf, torch.Tensor) or leaf.ndim < 1 or leaf.shape[0] != n:
+            raise ValueError(f"leaf {path} must be a tensor with the chain axis ({n}) first")
+    shapes = [tuple(leaf.shape[1:]) for leaf in leaves]
+    sizes = [int(torch.Size(s).numel()) if s else 1 for s in shapes]
+    flat = torch.cat([leaf.reshape(n, -1).to(torch.float32) for leaf in leaves], dim=1).contiguous()
+
+    def unravel(x):
+        if x.ndim != 2 or x.shape[1] != sum(sizes):
+            raise ValueError(f"expected a (M, {sum(sizes)}) tensor, got {tuple(x.shape)}")
+        parts = torch.split(x, sizes, dim=1)
+        return _tree_build(tree, iter(p.reshape((x.shape[0],) + s) for p, s in zip(parts, shapes)))
+
+    return flat, unravel
+
+
+def flat_logdensity(logdensity_fn: Callable, unravel: Callable) -> Callable:
+    """``logdensity_fn`` over a pytree of ``(N, ...)`` tensors -> the ``(N, D) -> (N,)`` callable the
+    samplers take (gradient by autograd through ``unravel``)."""
+
+    def fn(q):
+        return logdensity_fn(unravel(q))
+
+    return fn
