@@ -93,8 +93,10 @@ def cpu_baseline(D, L, eps, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # 40 timed transitions = 0.6 s: a single host/driver hiccup (one 28 ms step among 14.5 ms ones was
+    # seen in 1 of 8 back-to-back runs) moves a 10-step region by 8 %, a 40-step region by 2 %
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--leapfrogs", type=int, default=50)
