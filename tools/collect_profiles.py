@@ -24,7 +24,7 @@ def is_kernel(name):
 
 def counter_avg(sub, counter):
     """-> (mean counter value per launch of KERNEL, number of launches, grid size of those launches)"""
-    f = sorted(glob.glob(os.path.join(SRC, sub, "*", "*counter_collection.csv")))[-1]
+    f = max(glob.glob(os.path.join(SRC, sub, "*", "*counter_collection.csv")), key=os.path.getmtime)  # newest run
     vals, grids = [], set()
     for r in csv.DictReader(open(f)):
         if is_kernel(r["Kernel_Name"]) and r["Counter_Name"] == counter:
@@ -42,7 +42,7 @@ def main():
     json.dump(bench, open(os.path.join(out_dir, f"bench_c2_default_{tag}.json"), "w"), indent=1)
     if bench.get("roofline"):
         KERNEL = bench["roofline"]["kernel"]
-    stats = sorted(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")))[-1]
+    stats = max(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)  # newest run
     shutil.copy(stats, os.path.join(out_dir, f"bench_c2_kernel_stats_{tag}.csv"))
     fetch_kb, n_f, grid_f = counter_avg("fetch", "FETCH_SIZE")
     write_kb, n_w, grid_w = counter_avg("write", "WRITE_SIZE")
