@@ -76,6 +76,47 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
   }
 }
 
+// Short rows (D <= 128): G = 16 or 32 lanes per row, 64 / G rows per wave, so a row of 64 floats
+// does not leave 48 of the 64 lanes idle in this VALU-bound kernel (threefry + erf_inv per element).
+// Same per-element arithmetic and the same per-lane accumulation order as k_momentum_diag<4>; the
+// fp64 partial sums are combined by a butterfly inside the lane group.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_momentum_diag_short(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
+                      int64_t imm_stride, float* __restrict__ p_out, float* __restrict__ ke_out) {
+  constexpr int R = BJX_WAVE / G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  for (int64_t r0 = wave_row0() * R; r0 < N; r0 += wave_row_stride() * R) {
+    const int64_t r = r0 + sub;
+    const bool valid = r < N;
+    double acc = 0.0;
+    if (valid) {
+      const Key kc = chain_key(key, (uint64_t)(r + off), fold);
+      const Key km = key_child(kc, 0);  // split(kc, 2)[0]
+      const float* im = imm + r * imm_stride;
+      float* pr = p_out + r * D;
+      for (int64_t j = (int64_t)gl * 4; j < D; j += G * 4) {
+        const F4 t = ld4(im + j);
+        const float m[4] = {t.x, t.y, t.z, t.w};
+        float pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
+          const float ms = 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
+          pv[e] = ms * z;
+          const float v = m[e] * pv[e];
+          acc += (double)v * (double)pv[e];
+        }
+        st4(pr + j, F4{pv[0], pv[1], pv[2], pv[3]});
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, BJX_WAVE);
+    if (valid && gl == 0) ke_out[r] = 0.5f * (float)acc;
+  }
+}
+
 // ------------------------------------------------------------------------------ leapfrog
 // p' = fma(h,g,p) [twice if KICKS==2] ; v = imm*p' ; q' = fma(eps, v, q)
 template <int VEC, int KICKS>
@@ -187,6 +228,48 @@ k_leapfrog_diag_flat(int64_t D, int bpr, float eps_s, const float* __restrict__ 
   const float h = eps * kick_a, h2 = eps * kick_b, ed = eps * drift;
   const F4 pp = ld4(p_in + at), gg = ld4(g + at), qq = ld4(q_in + at);
   const F4 mm = ld4(imm + r * imm_stride + j);
+  F4 pn, qn;
+  pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
+  pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
+  if constexpr (KICKS == 2) {
+    pn.x = fmaf(h2, gg.x, pn.x); pn.y = fmaf(h2, gg.y, pn.y);
+    pn.z = fmaf(h2, gg.z, pn.z); pn.w = fmaf(h2, gg.w, pn.w);
+  }
+  qn.x = fmaf(ed, mm.x * pn.x, qq.x); qn.y = fmaf(ed, mm.y * pn.y, qq.y);
+  qn.z = fmaf(ed, mm.z * pn.z, qq.z); qn.w = fmaf(ed, mm.w * pn.w, qq.w);
+  st4(p_out + at, pn);
+  st4(q_out + at, qn);
+}
+
+// The same one-piece-per-lane stage for ANY row length that is a multiple of 4 floats: lane i of
+// the launch owns the i-th 16-byte piece of the (N, D) arrays, row = i / (D/4).  With one row per
+// wave a row of D = 64 floats keeps 16 of 64 lanes busy (measured: 49 % of the HBM peak at
+// 524 288 x 64, 84 % at D = 100); here every lane works whatever D is.  32-bit index arithmetic
+// (the host checks N * D / 4 < 2^31).
+template <int KICKS>
+__global__ void __launch_bounds__(kBlock)
+k_leapfrog_diag_flat_any(uint32_t total4, uint32_t D4, float eps_s, const float* __restrict__ eps_pc,
+                         const float* __restrict__ imm, uint32_t imm_stride4, const float* q_in,
+                         const float* p_in, const float* __restrict__ g, float* q_out, float* p_out,
+                         const int32_t* __restrict__ n_steps, int32_t step_idx, float kick_a,
+                         float kick_b, float drift) {
+  const uint32_t b = BJX_REVERSE_ROWS ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const uint32_t i = b * kBlock + threadIdx.x;
+  if (i >= total4) return;
+  const uint32_t r = i / D4;
+  const uint32_t j4 = i - r * D4;
+  const int64_t at = (int64_t)i * 4;
+  if (n_steps && step_idx >= n_steps[r]) {
+    if (q_out != q_in) {
+      st4(q_out + at, ld4(q_in + at));
+      st4(p_out + at, ld4(p_in + at));
+    }
+    return;
+  }
+  const float eps = eps_pc ? eps_pc[r] : eps_s;
+  const float h = eps * kick_a, h2 = eps * kick_b, ed = eps * drift;
+  const F4 pp = ld4(p_in + at), gg = ld4(g + at), qq = ld4(q_in + at);
+  const F4 mm = ld4(imm + ((int64_t)r * imm_stride4 + j4) * 4);
   F4 pn, qn;
   pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
   pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
@@ -474,7 +557,17 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
-  if (bjx_vec4_ok(D, imm, p_out))
+  if (bjx_vec4_ok(D, imm, p_out) && D <= 128) {
+    if (D <= 64) {
+      const dim3 g4(bjx_row_grid((N + 3) / 4, kWavesPerBlock));
+      hipLaunchKernelGGL(k_momentum_diag_short<16>, g4, block, 0, (hipStream_t)stream, key, chain_offset,
+                         step_fold, N, D, imm, imm_stride, p_out, ke_out);
+    } else {
+      const dim3 g2(bjx_row_grid((N + 1) / 2, kWavesPerBlock));
+      hipLaunchKernelGGL(k_momentum_diag_short<32>, g2, block, 0, (hipStream_t)stream, key, chain_offset,
+                         step_fold, N, D, imm, imm_stride, p_out, ke_out);
+    }
+  } else if (bjx_vec4_ok(D, imm, p_out))
     hipLaunchKernelGGL(k_momentum_diag<4>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
                        step_fold, N, D, imm, imm_stride, p_out, ke_out);
   else
@@ -514,6 +607,18 @@ int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, floa
     else
       hipLaunchKernelGGL(k_leapfrog_diag_flat<2>, fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm,
                          imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
+  } else if (flat_ok && (D / 4) % 64 != 0 && N * (D / 4) < ((int64_t)1 << 31) &&
+             bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
+    // rows that do not fill whole waves: one 16-byte piece per lane over the flattened arrays
+    const uint32_t D4 = (uint32_t)(D / 4), total4 = (uint32_t)(N * (D / 4));
+    const dim3 fgrid((total4 + kBlock - 1) / kBlock);
+    const uint32_t is4 = imm_stride ? D4 : 0u;
+    if (n_kicks == 1)
+      hipLaunchKernelGGL(k_leapfrog_diag_flat_any<1>, fgrid, block, 0, s, total4, D4, eps, eps_per_chain,
+                         imm, is4, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
+    else
+      hipLaunchKernelGGL(k_leapfrog_diag_flat_any<2>, fgrid, block, 0, s, total4, D4, eps, eps_per_chain,
+                         imm, is4, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
   } else if (bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     if (n_kicks == 1) BJX_LF(4, 1); else BJX_LF(4, 2);
   } else {
