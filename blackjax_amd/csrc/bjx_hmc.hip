@@ -374,6 +374,76 @@ k_hmc_finish_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, floa
   }
 }
 
+// short rows (D <= 128, D % 4 == 0): G lanes per row, 64 / G rows per wave -- the per-row scalar chain
+// (three threefry blocks, one exp) is then paid once per 2 or 4 rows of vector issue instead of once per
+// row.  Same arithmetic and per-lane accumulation order as k_hmc_finish_diag<4>.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_hmc_finish_diag_short(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, float eps_s,
+                        const float* __restrict__ eps_pc, const float* __restrict__ imm,
+                        int64_t imm_stride, float thr, const float* __restrict__ q0,
+                        const float* __restrict__ logp0, const float* __restrict__ g0,
+                        const float* __restrict__ ke0, const float* __restrict__ q1,
+                        const float* __restrict__ logp1, const float* __restrict__ g1, const float* p,
+                        float* p_end, float* __restrict__ q_out, float* __restrict__ logp_out,
+                        float* __restrict__ g_out, float* __restrict__ acc_rate_out,
+                        uint8_t* __restrict__ is_acc_out, uint8_t* __restrict__ is_div_out,
+                        float* __restrict__ energy_out, float kick_coef) {
+  constexpr int R = BJX_WAVE / G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  for (int64_t r0 = wave_row0() * R; r0 < N; r0 += wave_row_stride() * R) {
+    const int64_t r = r0 + sub;
+    const bool valid = r < N;
+    const int64_t rr = valid ? r : N - 1;  // idle groups shadow the last row and write nothing
+    const float eps = eps_pc ? eps_pc[rr] : eps_s;
+    const float h = eps * kick_coef;
+    const int64_t base = rr * D;
+    const float* im = imm + rr * imm_stride;
+    double acc = 0.0;
+    for (int64_t j = (int64_t)gl * 4; j < D; j += G * 4) {
+      const F4 pp = ld4(p + base + j), gg = ld4(g1 + base + j), mm = ld4(im + j);
+      F4 pn;
+      pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
+      pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
+      acc += (double)(mm.x * pn.x) * (double)pn.x;
+      acc += (double)(mm.y * pn.y) * (double)pn.y;
+      acc += (double)(mm.z * pn.z) * (double)pn.z;
+      acc += (double)(mm.w * pn.w) * (double)pn.w;
+      if (p_end && valid) st4(p_end + base + j, F4{-1.0f * pn.x, -1.0f * pn.y, -1.0f * pn.z, -1.0f * pn.w});
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, BJX_WAVE);
+    const float ke1 = 0.5f * (float)acc;
+    const float lp0 = logp0[rr], lp1 = logp1[rr];
+    const float H0 = -lp0 + ke0[rr];
+    const float H1 = -lp1 + ke1;
+    float delta = H0 - H1;
+    if (delta != delta) delta = -__builtin_inff();
+    const bool is_div = (-delta) > thr;
+    const float p_acc = fminf(exp_cr(delta), 1.0f);
+    const Key kc = chain_key(key, (uint64_t)(rr + off), fold);
+    const Key ki = key_child(kc, 1);
+    const float u = key_uniform(ki);
+    const bool accept = u < p_acc;
+    if (!valid) continue;
+    if (gl == 0) {
+      logp_out[r] = accept ? lp1 : lp0;
+      acc_rate_out[r] = p_acc;
+      is_acc_out[r] = accept ? 1 : 0;
+      is_div_out[r] = is_div ? 1 : 0;
+      energy_out[r] = H1;
+    }
+    const float* qs = accept ? q1 : q0;
+    const float* gs = accept ? g1 : g0;
+    for (int64_t j = (int64_t)gl * 4; j < D; j += G * 4) {
+      const F4 a = ld4(qs + base + j), b = ld4(gs + base + j);
+      st4(q_out + base + j, a);
+      st4(g_out + base + j, b);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ multinomial HMC
 // One step of static_progressive_integration (trajectory.py:214-225) fused with the opening half of
 // the next leapfrog.  Input: p = momentum after the OPENING half kick of step i, g = gradient at the
@@ -719,7 +789,16 @@ int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                      eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0,  \
                      q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out, acceptance_rate_out,  \
                      is_accepted_out, is_divergent_out, energy_out, kick_coef)
-  if (bjx_vec4_ok(D, imm, q0, g0, q1, g1, p, p_end_out, q_out, g_out)) BJX_FIN(4);
+  if (bjx_vec4_ok(D, imm, q0, g0, q1, g1, p, p_end_out, q_out, g_out) && D <= 128) {
+#define BJX_FIN_SHORT(G_, GRID)                                                                       \
+  hipLaunchKernelGGL(k_hmc_finish_diag_short<G_>, GRID, block, 0, s, key, chain_offset, step_fold, N, \
+                     D, eps, eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0, \
+                     q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out, acceptance_rate_out,        \
+                     is_accepted_out, is_divergent_out, energy_out, kick_coef)
+    if (D <= 64) BJX_FIN_SHORT(16, dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)));
+    else BJX_FIN_SHORT(32, dim3(bjx_row_grid((N + 1) / 2, kWavesPerBlock)));
+#undef BJX_FIN_SHORT
+  } else if (bjx_vec4_ok(D, imm, q0, g0, q1, g1, p, p_end_out, q_out, g_out)) BJX_FIN(4);
   else BJX_FIN(1);
 #undef BJX_FIN
   return bjx_check_launch("bjx_hmc_finish_diag");

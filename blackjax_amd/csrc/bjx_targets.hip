@@ -67,6 +67,36 @@ k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float*
   }
 }
 
+// short rows (D <= 128, D % 4 == 0): G lanes per row, 64 / G rows per wave (see k_momentum_diag_short)
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_diag_gaussian_short(int64_t N, int64_t D, const float* __restrict__ iv, const float* __restrict__ q,
+                      float* __restrict__ logp, float* __restrict__ g) {
+  constexpr int R = BJX_WAVE / G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  for (int64_t r0 = wave_row0() * R; r0 < N; r0 += wave_row_stride() * R) {
+    const int64_t r = r0 + sub;
+    const bool valid = r < N;
+    double acc = 0.0;
+    if (valid) {
+      const int64_t base = r * D;
+      for (int64_t j = (int64_t)gl * 4; j < D; j += G * 4) {
+        const F4 qq = ld4(q + base + j), vv = ld4(iv + j);
+        const F4 gg{-(qq.x * vv.x), -(qq.y * vv.y), -(qq.z * vv.z), -(qq.w * vv.w)};
+        acc += (double)qq.x * (double)gg.x;
+        acc += (double)qq.y * (double)gg.y;
+        acc += (double)qq.z * (double)gg.z;
+        acc += (double)qq.w * (double)gg.w;
+        st4(g + base + j, gg);
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, BJX_WAVE);
+    if (valid && gl == 0) logp[r] = (float)(0.5 * acc);
+  }
+}
+
 // Neal's funnel (tests/fixtures.py:81-98 of the reference), y = q[0], v = q[1:]
 __global__ void __launch_bounds__(kBlock)
 k_neal_funnel(int64_t N, int64_t D, const float* __restrict__ q, float* __restrict__ logp,
@@ -129,7 +159,13 @@ int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* in
   if (N == 0) return 0;  // an empty batch has no buffers to check
   BJX_CHECK_ARG(inv_var && q && logp_out && g_out, "bjx_target_diag_gaussian: bad arguments");
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
-  if (bjx_vec4_ok(D, inv_var, q, g_out))
+  if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 64)
+    hipLaunchKernelGGL(k_diag_gaussian_short<16>, dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
+  else if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 128)
+    hipLaunchKernelGGL(k_diag_gaussian_short<32>, dim3(bjx_row_grid((N + 1) / 2, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
+  else if (bjx_vec4_ok(D, inv_var, q, g_out))
     hipLaunchKernelGGL(k_diag_gaussian<4>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
                        logp_out, g_out);
   else
