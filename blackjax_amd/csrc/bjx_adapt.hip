@@ -109,6 +109,28 @@ k_welford_update_diag(int64_t N, int64_t D, float n, const float* __restrict__ x
   }
 }
 
+// the same update over the flattened arrays (purely element-wise): used when a row does not fill
+// whole waves, where one wave per row would idle most lanes
+__global__ void __launch_bounds__(kBlock)
+k_welford_update_flat(int64_t total4, float n, const float* __restrict__ x, const float* mean_in,
+                      const float* m2_in, float* mean_out, float* m2_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const F4 xv = ld4(x + 4 * i), mv = ld4(mean_in + 4 * i), sv = ld4(m2_in + 4 * i);
+    F4 mo, so;
+#define BJX_W(c)                                   \
+  {                                                \
+    const float d = xv.c - mv.c;                   \
+    mo.c = mv.c + d / n;                           \
+    so.c = fmaf(d, xv.c - mo.c, sv.c);             \
+  }
+    BJX_W(x) BJX_W(y) BJX_W(z) BJX_W(w)
+#undef BJX_W
+    st4(mean_out + 4 * i, mo);
+    st4(m2_out + 4 * i, so);
+  }
+}
+
 // mass_matrix.py:335-357 (diagonal): cov = m2/(n-1) ; imm = fma(beta_prev, prev, beta_data*cov) + reg
 __global__ void __launch_bounds__(kBlock)
 k_welford_final_diag(int64_t total, int64_t D, float nm1, float beta_data, float beta_prev,
@@ -181,7 +203,13 @@ int bjx_welford_update_diag(void* stream, int64_t N, int64_t D, int64_t sample_s
   if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const float n = (float)sample_size_new;
-  if (bjx_vec4_ok(D, value, mean_in, m2_in, mean_out, m2_out))
+  if (bjx_vec4_ok(D, value, mean_in, m2_in, mean_out, m2_out) && (D / 4) % 64 != 0) {
+    const int64_t total4 = N * (D / 4);
+    int64_t blocks = (total4 + kBlock - 1) / kBlock;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_welford_update_flat, dim3((unsigned)blocks), block, 0, (hipStream_t)stream, total4,
+                       n, value, mean_in, m2_in, mean_out, m2_out);
+  } else if (bjx_vec4_ok(D, value, mean_in, m2_in, mean_out, m2_out))
     hipLaunchKernelGGL(k_welford_update_diag<4>, grid, block, 0, (hipStream_t)stream, N, D, n, value,
                        mean_in, m2_in, mean_out, m2_out);
   else
