@@ -863,8 +863,13 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
   return stop || last;
 }
 
+// occupancy hint of the leaf kernel (122 VGPRs): A/B on one box at C3 -- 3: 111.2, 4: 110.7, 5 (84 B of
+// spills): 98.7, 6 (148 B): 88.5 M/s
+#ifndef BJX_LEAF_WAVES
+#define BJX_LEAF_WAVES 4
+#endif
 template <int VEC, int NI, bool GROUPED>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_LEAF_WAVES)))
 k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                   const float* __restrict__ gf) {
   async_for_each_chain<GROUPED>(ax, 1, 1, [&](int64_t c, int64_t b, int) {
