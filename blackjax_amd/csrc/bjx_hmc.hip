@@ -76,7 +76,7 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
   }
 }
 
-// Short rows (D <= 128): G = 16 or 32 lanes per row, 64 / G rows per wave, so a row of 64 floats
+// Short rows (D <= 128): G = 4 ... 32 lanes per row, 64 / G rows per wave, so a row of 64 floats
 // does not leave 48 of the 64 lanes idle in this VALU-bound kernel (threefry + erf_inv per element).
 // Same per-element arithmetic and the same per-lane accumulation order as k_momentum_diag<4>; the
 // fp64 partial sums are combined by a butterfly inside the lane group.
@@ -628,15 +628,16 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
   if (bjx_vec4_ok(D, imm, p_out) && D <= 128) {
-    if (D <= 64) {
-      const dim3 g4(bjx_row_grid((N + 3) / 4, kWavesPerBlock));
-      hipLaunchKernelGGL(k_momentum_diag_short<16>, g4, block, 0, (hipStream_t)stream, key, chain_offset,
-                         step_fold, N, D, imm, imm_stride, p_out, ke_out);
-    } else {
-      const dim3 g2(bjx_row_grid((N + 1) / 2, kWavesPerBlock));
-      hipLaunchKernelGGL(k_momentum_diag_short<32>, g2, block, 0, (hipStream_t)stream, key, chain_offset,
-                         step_fold, N, D, imm, imm_stride, p_out, ke_out);
-    }
+    // G lanes per row = the smallest power of two with G * 4 >= D (at least 4): 64 / G rows per wave
+#define BJX_MOM_SHORT(G_)                                                                             \
+  hipLaunchKernelGGL(k_momentum_diag_short<G_>, dim3(bjx_row_grid((N * G_ + 63) / 64, kWavesPerBlock)), \
+                     block, 0, (hipStream_t)stream, key, chain_offset, step_fold, N, D, imm, imm_stride, \
+                     p_out, ke_out)
+    if (D <= 16) BJX_MOM_SHORT(4);
+    else if (D <= 32) BJX_MOM_SHORT(8);
+    else if (D <= 64) BJX_MOM_SHORT(16);
+    else BJX_MOM_SHORT(32);
+#undef BJX_MOM_SHORT
   } else if (bjx_vec4_ok(D, imm, p_out))
     hipLaunchKernelGGL(k_momentum_diag<4>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
                        step_fold, N, D, imm, imm_stride, p_out, ke_out);
@@ -795,7 +796,9 @@ int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                      D, eps, eps_per_chain, imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0, \
                      q1, logp1, g1, p, p_end_out, q_out, logp_out, g_out, acceptance_rate_out,        \
                      is_accepted_out, is_divergent_out, energy_out, kick_coef)
-    if (D <= 64) BJX_FIN_SHORT(16, dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)));
+    if (D <= 16) BJX_FIN_SHORT(4, dim3(bjx_row_grid((N + 15) / 16, kWavesPerBlock)));
+    else if (D <= 32) BJX_FIN_SHORT(8, dim3(bjx_row_grid((N + 7) / 8, kWavesPerBlock)));
+    else if (D <= 64) BJX_FIN_SHORT(16, dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)));
     else BJX_FIN_SHORT(32, dim3(bjx_row_grid((N + 1) / 2, kWavesPerBlock)));
 #undef BJX_FIN_SHORT
   } else if (bjx_vec4_ok(D, imm, q0, g0, q1, g1, p, p_end_out, q_out, g_out)) BJX_FIN(4);

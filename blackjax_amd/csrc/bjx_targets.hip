@@ -159,7 +159,13 @@ int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* in
   if (N == 0) return 0;  // an empty batch has no buffers to check
   BJX_CHECK_ARG(inv_var && q && logp_out && g_out, "bjx_target_diag_gaussian: bad arguments");
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
-  if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 64)
+  if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 16)
+    hipLaunchKernelGGL(k_diag_gaussian_short<4>, dim3(bjx_row_grid((N + 15) / 16, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
+  else if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 32)
+    hipLaunchKernelGGL(k_diag_gaussian_short<8>, dim3(bjx_row_grid((N + 7) / 8, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
+  else if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 64)
     hipLaunchKernelGGL(k_diag_gaussian_short<16>, dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
                        (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
   else if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 128)

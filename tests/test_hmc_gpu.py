@@ -63,7 +63,7 @@ def test_rng_normal_large_sample_bit_exact(dev):
 
 
 @pytest.mark.parametrize("N,D,per_chain_imm", [(64, 1024, False), (5, 100, False), (9, 256, True), (3, 7, True),
-                                               (37, 64, False), (11, 16, True), (6, 128, True), (1, 4, False)])
+                                               (37, 64, False), (11, 16, True), (6, 128, True), (1, 4, False), (70, 32, True), (19, 8, False)])
 def test_momentum_diag(dev, N, D, per_chain_imm):
     rng = np.random.default_rng(0)
     imm = rng.uniform(0.1, 4.0, size=(N, D) if per_chain_imm else (D,)).astype(np.float32)
