@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void k_chees_weights(int64_t N, int64_t D, con
   }
 }
 
-template <int VEC, bool WHITEN>
+// G lanes per chain row (64 = one wave per row; 4 ... 32 for rows of at most 16 ... 128 floats, VEC == 4)
+template <int VEC, bool WHITEN, int G = 64>
 __global__ __launch_bounds__(256) void k_chees_criterion(
     int64_t N, int64_t D, const float* __restrict__ qp, const float* __restrict__ pp,
     const float* __restrict__ qi, const float* __restrict__ pm, const float* __restrict__ im,
@@ -302,10 +303,14 @@ __global__ __launch_bounds__(256) void k_chees_criterion(
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t n = wave; n < N; n += nwaves) {
-    const int64_t base = n * D;
+  constexpr int R = 64 / G;
+  const int sub = lane / G, gl = lane % G;
+  for (int64_t n0 = wave * R; n0 < N; n0 += nwaves * R) {
+    const int64_t n = n0 + sub;
+    const bool valid = n < N;
+    const int64_t base = (valid ? n : N - 1) * D;  // idle groups shadow the last row, write nothing
     double s_pp = 0.0, s_ii = 0.0, s_pv = 0.0;
-    for (int64_t c = (int64_t)lane * VEC; c < D; c += 64 * VEC) {
+    for (int64_t c = (int64_t)gl * VEC; c < D; c += G * VEC) {
       float a[VEC], b[VEC], m[VEC], ma[VEC], mb[VEC];
       ld_vec<VEC>(qp + base + c, a);
       ld_vec<VEC>(qi + base + c, b);
@@ -332,10 +337,13 @@ __global__ __launch_bounds__(256) void k_chees_criterion(
         s_pv += (double)pc * (double)vel;
       }
     }
-    s_pp = wave_sum(s_pp);
-    s_ii = wave_sum(s_ii);
-    s_pv = wave_sum(s_pv);
-    if (lane == 0) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+      s_pp += __shfl_xor(s_pp, o, 64);
+      s_ii += __shfl_xor(s_ii, o, 64);
+      s_pv += __shfl_xor(s_pv, o, 64);
+    }
+    if (valid && gl == 0) {
       const float diff = (float)s_pp - (float)s_ii;
       crit[n] = diff * (float)s_pv;
     }
@@ -524,11 +532,25 @@ int bjx_chees_criterion(hipStream_t stream, int64_t N, int64_t D, const float* q
 #define BJX_LAUNCH_CRIT(V, W)                                                                         \
   hipLaunchKernelGGL((k_chees_criterion<V, W>), dim3(grid), dim3(256), 0, stream, N, D, q_prop,       \
                      p_prop, q_init, proposals_mean, initials_mean, imm, inv_sqrt_imm, crit)
-  if (imm != nullptr) {
+#define BJX_LAUNCH_CRIT_G(W, G_)                                                                          \
+  hipLaunchKernelGGL((k_chees_criterion<4, W, G_>), dim3(bjx_row_grid((N * G_ + 63) / 64, 4)), dim3(256), 0, \
+                     stream, N, D, q_prop, p_prop, q_init, proposals_mean, initials_mean, imm, inv_sqrt_imm, crit)
+#define BJX_LAUNCH_CRIT_SHORT(W)              \
+  do {                                        \
+    if (D <= 16) BJX_LAUNCH_CRIT_G(W, 4);     \
+    else if (D <= 32) BJX_LAUNCH_CRIT_G(W, 8); \
+    else if (D <= 64) BJX_LAUNCH_CRIT_G(W, 16); \
+    else BJX_LAUNCH_CRIT_G(W, 32);            \
+  } while (0)
+  if (v4 && D > 0 && D <= 128) {  // short rows: several chains per wave
+    if (imm != nullptr) BJX_LAUNCH_CRIT_SHORT(true); else BJX_LAUNCH_CRIT_SHORT(false);
+  } else if (imm != nullptr) {
     if (v4) BJX_LAUNCH_CRIT(4, true); else BJX_LAUNCH_CRIT(1, true);
   } else {
     if (v4) BJX_LAUNCH_CRIT(4, false); else BJX_LAUNCH_CRIT(1, false);
   }
+#undef BJX_LAUNCH_CRIT_SHORT
+#undef BJX_LAUNCH_CRIT_G
 #undef BJX_LAUNCH_CRIT
   return bjx_check_launch("bjx_chees_criterion");
 }

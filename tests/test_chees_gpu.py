@@ -51,7 +51,7 @@ def _oracle_sums(props, moms, inits, acc, div, imm, whiten, scale):
     return w, crit, sums
 
 
-@pytest.mark.parametrize("N,D", [(37, 6), (64, 8), (130, 257), (1000, 64), (3, 1)])
+@pytest.mark.parametrize("N,D", [(37, 6), (64, 8), (130, 257), (1000, 64), (3, 1), (77, 20), (41, 100), (9, 128)])
 @pytest.mark.parametrize("whiten", [False, True])
 @pytest.mark.parametrize("poison", [False, True])
 def test_pool_kernels_vs_oracle(dev, N, D, whiten, poison):
