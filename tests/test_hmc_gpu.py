@@ -390,3 +390,38 @@ def test_hmc_default_driver_graph_and_fallback(dev):
             assert torch.equal(s_r.position, s_a.position)
             assert torch.equal(i_r.acceptance_rate, i_a.acceptance_rate)
             assert torch.equal(i_r.proposal.position, i_a.proposal.position)
+
+
+_SWEEP = [(n, d, l, pc) for (n, d, l, pc) in [
+    (7, 4, 3, False), (19, 8, 2, True), (33, 12, 4, False), (65, 16, 3, True), (9, 20, 5, True),
+    (130, 32, 2, False), (5, 36, 3, True), (70, 64, 4, True), (3, 68, 2, False), (41, 100, 3, True),
+    (17, 128, 2, False), (6, 132, 3, True), (11, 200, 2, False), (4, 256, 3, True), (13, 300, 2, True),
+    (2, 1000, 2, False), (5, 1024, 3, True), (3, 1028, 2, True), (2, 2048, 2, False), (1, 5, 2, True),
+    (8, 7, 3, False), (6, 63, 2, True), (3, 1023, 2, False), (257, 48, 2, True)]]
+
+
+@pytest.mark.parametrize("N,D,L,per_chain", _SWEEP)
+def test_hmc_shape_sweep(dev, N, D, L, per_chain):
+    """Every row-length variant of the diagonal-metric kernels (scalar rows, 4 ... 32 lanes per row, flat
+    leapfrog for rows that do not fill whole waves, one wave per row, flat rows of a multiple of 1 024)
+    against the oracle, with shared and per-chain step sizes / metrics: accept bits and positions."""
+    rng = np.random.default_rng(N * 1000 + D)
+    inv_var = rng.uniform(0.5, 2.0, D).astype(np.float32)
+    if per_chain:
+        imm = rng.uniform(0.5, 2.0, (N, D)).astype(np.float32)
+        eps = rng.uniform(0.05, 0.3, N).astype(np.float32)
+    else:
+        imm = rng.uniform(0.5, 2.0, D).astype(np.float32)
+        eps = np.float32(0.2)
+    fn_o = otargets.diag_gaussian(inv_var)
+    fn_g = bjx.targets.DiagGaussian(dev_t(inv_var, dev))
+    q0 = prng.normal(prng.key(D), (N, D)).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    imm_g = bjx.metrics.PerChainDiag(dev_t(imm, dev)) if per_chain else dev_t(imm, dev)
+    alg = bjx.hmc(fn_g, dev_t(eps, dev) if per_chain else float(eps), imm_g, L, chain_offset=3)
+    st_g = alg.init(dev_t(q0, dev))
+    for k in prng.split(prng.key(N), 3):
+        st_o, info_o = ohmc.kernel(k, st_o, fn_o, eps, imm, L, chain_offset=3)
+        st_g, info_g = alg.step(k, st_g)
+        _check_step(st_o, info_o, st_g, info_g)
+        assert np.array_equal(t2n(st_g.position), st_o.position)
