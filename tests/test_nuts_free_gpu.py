@@ -128,3 +128,30 @@ def test_run_inference_algorithm_free_running_matches_step_loop(dev):
         assert torch.equal(states.position, positions)
         assert torch.equal(infos.acceptance_rate, rinfo.acceptance_rate)
         assert torch.equal(infos.is_divergent, rinfo.is_divergent)
+
+
+def test_free_running_is_shard_invariant(dev):
+    """Chains sharded over ranks (contiguous blocks, chain_offset = first global chain index) give the
+    draws of the unsharded run: free-running NUTS and the free-running warm-up need no exchange."""
+    N, D, T = 48, 10, 6
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    q0 = 0.4 * torch.randn(N, D, device=dev, generator=g)
+    fn = bjx.targets.NealFunnel()
+    imm = torch.ones(D, device=dev)
+    for layout in ("step_major", "chain_major"):
+        full = bjx.nuts(fn, 0.25, imm, max_num_doublings=5)
+        st, pos, info = full.run(prng.key(21), full.init(q0), T, key_layout=layout)
+        parts = []
+        for lo, hi in ((0, 20), (20, 48)):
+            shard = bjx.nuts(fn, 0.25, imm, max_num_doublings=5, chain_offset=lo)
+            _, p, i = shard.run(prng.key(21), shard.init(q0[lo:hi].contiguous()), T, key_layout=layout)
+            parts.append((p, i))
+        assert torch.equal(torch.cat([p for p, _ in parts], dim=1), pos)
+        assert torch.equal(torch.cat([i.num_integration_steps for _, i in parts], dim=1), info.num_integration_steps)
+    warm = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=None, initial_step_size=0.3, max_num_doublings=5)
+    (s_full, p_full), _ = warm.run(prng.key(5), q0, 40, free_running=True)
+    outs = [warm.run(prng.key(5), q0[lo:hi].contiguous(), 40, chain_offset=lo, free_running=True)[0]
+            for lo, hi in ((0, 20), (20, 48))]
+    assert torch.equal(torch.cat([o.state.position for o in outs]), s_full.position)
+    assert torch.equal(torch.cat([o.parameters["step_size"] for o in outs]), p_full["step_size"])
