@@ -294,6 +294,33 @@ __global__ __launch_bounds__(256) void k_chees_weights(int64_t N, int64_t D, con
   }
 }
 
+// weights for short rows (D <= 128, D % 4 == 0): G lanes per row, 64 / G rows per wave
+template <int G>
+__global__ __launch_bounds__(256) void k_chees_weights_short(int64_t N, int64_t D, const float* __restrict__ qp,
+                                                             const float* __restrict__ acc,
+                                                             const uint8_t* __restrict__ is_div,
+                                                             float* __restrict__ w) {
+  constexpr int R = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, gl = lane % G;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t n0 = wave * R; n0 < N; n0 += nwaves * R) {
+    const int64_t n = n0 + sub;
+    const bool valid = n < N;
+    int bad = 0;
+    if (valid)
+      for (int64_t c = (int64_t)gl * 4; c < D; c += G * 4) {
+        float x[4];
+        ld_vec<4>(qp + n * D + c, x);
+        bad |= !isfinite(x[0]) | !isfinite(x[1]) | !isfinite(x[2]) | !isfinite(x[3]);
+      }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+    if (valid && gl == 0) w[n] = (is_div[n] || bad) ? 0.0f : acc[n];
+  }
+}
+
 // G lanes per chain row (64 = one wave per row; 4 ... 32 for rows of at most 16 ... 128 floats, VEC == 4)
 template <int VEC, bool WHITEN, int G = 64>
 __global__ __launch_bounds__(256) void k_chees_criterion(
@@ -488,7 +515,16 @@ int bjx_chees_weights(hipStream_t stream, int64_t N, int64_t D, const float* q_p
   if (N == 0) return 0;
   BJX_CHECK_ARG((q_prop || D == 0) && acc && is_divergent && w, "bjx_chees_weights: null pointer");
   const unsigned grid = bjx_row_grid((N + 3) / 4, 4);  // 4 rows per wave, 4 waves per block
-  if (bjx_vec4_ok(D, q_prop))
+  if (bjx_vec4_ok(D, q_prop) && D > 0 && D <= 128) {
+#define BJX_W_SHORT(G_)                                                                                \
+  hipLaunchKernelGGL(k_chees_weights_short<G_>, dim3(bjx_row_grid((N * G_ + 63) / 64, 4)), dim3(256), 0, \
+                     stream, N, D, q_prop, acc, is_divergent, w)
+    if (D <= 16) BJX_W_SHORT(4);
+    else if (D <= 32) BJX_W_SHORT(8);
+    else if (D <= 64) BJX_W_SHORT(16);
+    else BJX_W_SHORT(32);
+#undef BJX_W_SHORT
+  } else if (bjx_vec4_ok(D, q_prop))
     hipLaunchKernelGGL(k_chees_weights<4>, dim3(grid), dim3(256), 0, stream, N, D, q_prop, acc,
                        is_divergent, w);
   else
