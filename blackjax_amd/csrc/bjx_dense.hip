@@ -186,13 +186,17 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
     // LDS operand reads for the whole K-tile are issued up front (32 VGPRs) so the MFMAs below
     // run back to back instead of waiting on an LDS round trip before every pair.
     float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
+    // MFMA step u pairs k = u (lanes 0-31) with k = 8 + u (lanes 32-63): the SAME summation order as
+    // k_dense_gemm_tn below, so every shared-matrix product of the engine is one fp32 fmaf chain
+    // per output element in the order 0,8,1,9,...,7,15 within each K-tile, whatever kernel a shape
+    // dispatches to (oracle/fp.py::mfma_k_order restates it; parity tests are bit-exact).
 #pragma unroll
     for (int u = 0; u < BK / 2; ++u) {
-      const int kk = 2 * u;
-      fa0[u] = as[(kk + lk) * LDA + wm * 64 + lm];
-      fa1[u] = as[(kk + lk) * LDA + wm * 64 + 32 + lm];
-      fb0[u] = bs[(kk + lk) * LDB + wn * 64 + lm];
-      fb1[u] = bs[(kk + lk) * LDB + wn * 64 + 32 + lm];
+      const int kk = u + lk * (BK / 2);
+      fa0[u] = as[kk * LDA + wm * 64 + lm];
+      fa1[u] = as[kk * LDA + wm * 64 + 32 + lm];
+      fb0[u] = bs[kk * LDB + wn * 64 + lm];
+      fb1[u] = bs[kk * LDB + wn * 64 + 32 + lm];
     }
 #pragma unroll
     for (int u = 0; u < BK / 2; ++u) {

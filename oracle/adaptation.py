@@ -186,13 +186,17 @@ def adapt_update(ws: StagedAdaptationState, stage, is_window_end, position, acce
 def window_adaptation_run(rng_key, position, logdensity_fn, num_steps, num_integration_steps,
                           is_mass_matrix_diagonal=True, initial_step_size=1.0,
                           target_acceptance_rate=0.8, initial_inverse_mass_matrix=None,
-                          imm_shrinkage_to_previous=0.0, chain_offset=0, kernel_fn=None):
+                          imm_shrinkage_to_previous=0.0, chain_offset=0, kernel_fn=None,
+                          chain_keys_override=None):
     """window_adaptation(hmc, ...).run (window_adaptation.py:296-444 ->
-    staged_adaptation.py:860-876,968-981), batched per chain, chain-major keys."""
+    staged_adaptation.py:860-876,968-981), batched per chain, chain-major keys.
+    ``chain_keys_override``: the chain keys ``c_i`` of an arbitrary subset of global chain indices
+    (chains are independent, so any subset of a big run can be checked on its own)."""
     N, D = position.shape
     state = ohmc.init(position, logdensity_fn)
     ws = adapt_init(N, D, initial_step_size, is_mass_matrix_diagonal, initial_inverse_mass_matrix)
-    chain_keys = prng.split(rng_key, N, offset=chain_offset)  # c_i
+    chain_keys = (prng.split(rng_key, N, offset=chain_offset) if chain_keys_override is None
+                  else np.asarray(chain_keys_override, np.uint32))  # c_i
     schedule = build_schedule(num_steps)
     history = []
     for t, (stage, is_end) in enumerate(schedule):

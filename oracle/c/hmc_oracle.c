@@ -107,13 +107,63 @@ static inline float target_diag_gaussian(int64_t D, const float* iv, const float
   return (float)(0.5 * acc);
 }
 
-/* One HMC transition for N chains (in place on q/logp/g).  Returns 0. */
+/* One HMC transition of ONE chain (in place on q0/g0/logp): the body shared by the two entry
+ * points below.  imm is that chain's (D,) inverse mass diagonal, eps its step size, kc its key. */
+static inline void hmc_chain(key_t2 kc, int64_t D, int L, float eps, const float* imm,
+                             const float* inv_var, float thr, float* q0, float* logp, float* g0,
+                             float* acc_rate, uint8_t* is_acc, uint8_t* is_div, float* qw, float* pw,
+                             float* gw) {
+  const float h = eps * 0.5f;
+  const key_t2 km = key_child(kc, 0), ki = key_child(kc, 1);
+  double acc = 0.0;
+  for (int64_t j = 0; j < D; ++j) {
+    const float z = normal_from_bits(key_bits32(km, (uint64_t)j));
+    const float ms = 1.0f / sqrtf(imm[j]);
+    const float p = ms * z;
+    pw[j] = p;
+    acc += (double)(imm[j] * p) * (double)p;
+    qw[j] = q0[j];
+    gw[j] = g0[j];
+  }
+  const float ke0 = 0.5f * (float)acc;
+  float lp = *logp;
+  for (int l = 0; l < L; ++l) {
+    for (int64_t j = 0; j < D; ++j) {
+      const float pn = fmaf(h, gw[j], pw[j]);
+      pw[j] = pn;
+      qw[j] = fmaf(eps, imm[j] * pn, qw[j]);
+    }
+    lp = target_diag_gaussian(D, inv_var, qw, gw);
+    for (int64_t j = 0; j < D; ++j) pw[j] = fmaf(h, gw[j], pw[j]);
+  }
+  acc = 0.0;
+  for (int64_t j = 0; j < D; ++j) acc += (double)(imm[j] * pw[j]) * (double)pw[j];
+  const float ke1 = 0.5f * (float)acc;
+  const float H0 = -(*logp) + ke0;
+  const float H1 = -lp + ke1;
+  float delta = H0 - H1;
+  if (delta != delta) delta = -INFINITY;
+  const int div = (-delta) > thr;
+  const float p_acc = fminf((float)exp((double)delta), 1.0f);
+  const float u = fmaxf(0.0f, unit_float(key_bits32(ki, 0)));
+  const int accept = u < p_acc;
+  if (accept) {
+    memcpy(q0, qw, sizeof(float) * D);
+    memcpy(g0, gw, sizeof(float) * D);
+    *logp = lp;
+  }
+  *acc_rate = p_acc;
+  *is_acc = (uint8_t)accept;
+  *is_div = (uint8_t)div;
+}
+
+/* One HMC transition for N chains (in place on q/logp/g), shared step size and inverse mass
+ * diagonal, chain r keyed by split(key, .)[r + chain_offset].  Returns 0. */
 int bjx_oracle_hmc_diag_gaussian(uint32_t key0, uint32_t key1, int64_t chain_offset, int64_t N,
                                  int64_t D, int L, float eps, const float* imm,
                                  const float* inv_var, float thr, float* q, float* logp, float* g,
                                  float* acc_rate, uint8_t* is_acc, uint8_t* is_div, int nthreads) {
   const key_t2 key = {key0, key1};
-  const float h = eps * 0.5f;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -124,54 +174,67 @@ int bjx_oracle_hmc_diag_gaussian(uint32_t key0, uint32_t key1, int64_t chain_off
     float* gw = (float*)malloc(sizeof(float) * D);
 #pragma omp for schedule(static)
     for (int64_t r = 0; r < N; ++r) {
-      float* q0 = q + r * D;
-      float* g0 = g + r * D;
       const key_t2 kc = key_child(key, (uint64_t)(r + chain_offset));
-      const key_t2 km = key_child(kc, 0), ki = key_child(kc, 1);
-      double acc = 0.0;
-      for (int64_t j = 0; j < D; ++j) {
-        const float z = normal_from_bits(key_bits32(km, (uint64_t)j));
-        const float ms = 1.0f / sqrtf(imm[j]);
-        const float p = ms * z;
-        pw[j] = p;
-        acc += (double)(imm[j] * p) * (double)p;
-        qw[j] = q0[j];
-        gw[j] = g0[j];
-      }
-      const float ke0 = 0.5f * (float)acc;
-      float lp = logp[r];
-      for (int l = 0; l < L; ++l) {
-        for (int64_t j = 0; j < D; ++j) {
-          const float pn = fmaf(h, gw[j], pw[j]);
-          pw[j] = pn;
-          qw[j] = fmaf(eps, imm[j] * pn, qw[j]);
-        }
-        lp = target_diag_gaussian(D, inv_var, qw, gw);
-        for (int64_t j = 0; j < D; ++j) pw[j] = fmaf(h, gw[j], pw[j]);
-      }
-      acc = 0.0;
-      for (int64_t j = 0; j < D; ++j) acc += (double)(imm[j] * pw[j]) * (double)pw[j];
-      const float ke1 = 0.5f * (float)acc;
-      const float H0 = -logp[r] + ke0;
-      const float H1 = -lp + ke1;
-      float delta = H0 - H1;
-      if (delta != delta) delta = -INFINITY;
-      const int div = (-delta) > thr;
-      const float p_acc = fminf((float)exp((double)delta), 1.0f);
-      const float u = fmaxf(0.0f, unit_float(key_bits32(ki, 0)));
-      const int accept = u < p_acc;
-      if (accept) {
-        memcpy(q0, qw, sizeof(float) * D);
-        memcpy(g0, gw, sizeof(float) * D);
-        logp[r] = lp;
-      }
-      acc_rate[r] = p_acc;
-      is_acc[r] = (uint8_t)accept;
-      is_div[r] = (uint8_t)div;
+      hmc_chain(kc, D, L, eps, imm, inv_var, thr, q + r * D, logp + r, g + r * D, acc_rate + r,
+                is_acc + r, is_div + r, qw, pw, gw);
     }
     free(qw);
     free(pw);
     free(gw);
+  }
+  return 0;
+}
+
+/* The same transition with everything PER CHAIN: explicit chain keys (N, 2) -- any subset of the
+ * global chain indices, either key layout --, step sizes (N,) and inverse mass diagonals with row
+ * stride imm_stride (0 = one shared (D,) vector).  What a vmapped window_adaptation runs. */
+int bjx_oracle_hmc_diag_gaussian_pc(const uint32_t* chain_keys, int64_t N, int64_t D, int L,
+                                    const float* eps, const float* imm, int64_t imm_stride,
+                                    const float* inv_var, float thr, float* q, float* logp, float* g,
+                                    float* acc_rate, uint8_t* is_acc, uint8_t* is_div, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    float* qw = (float*)malloc(sizeof(float) * D);
+    float* pw = (float*)malloc(sizeof(float) * D);
+    float* gw = (float*)malloc(sizeof(float) * D);
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < N; ++r) {
+      const key_t2 kc = {chain_keys[2 * r], chain_keys[2 * r + 1]};
+      hmc_chain(kc, D, L, eps[r], imm + r * imm_stride, inv_var, thr, q + r * D, logp + r,
+                g + r * D, acc_rate + r, is_acc + r, is_div + r, qw, pw, gw);
+    }
+    free(qw);
+    free(pw);
+    free(gw);
+  }
+  return 0;
+}
+
+/* fp32 GEMM as a k-ordered fmaf chain: C[m][n] = chain over k (in the order k_order[0..K-1]) of
+ * acc = fmaf(A[m][k], B[k*sbk + n*sbn], acc), acc starting at +0.  This is what a sequence of
+ * v_mfma_f32_32x32x2_f32 instructions computes bit for bit (one rounding per product-accumulate,
+ * no wider internal accumulation) and what a "precision=highest" fp32 dot computes for that
+ * summation order (blackjax/util.py:23-61).  Used by the oracle's dense-metric "f32 chain" mode. */
+int bjx_oracle_gemm_f32chain(int64_t M, int64_t K, int64_t Nn, const float* A, const float* B,
+                             int64_t sbk, int64_t sbn, const int32_t* k_order, float* C,
+                             int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < M; ++m) {
+    const float* a = A + m * K;
+    for (int64_t n = 0; n < Nn; ++n) {
+      float acc = 0.0f;
+      for (int64_t i = 0; i < K; ++i) {
+        const int64_t k = k_order[i];
+        acc = fmaf(a[k], B[k * sbk + n * sbn], acc);
+      }
+      C[m * Nn + n] = acc;
+    }
   }
   return 0;
 }

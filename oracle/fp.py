@@ -94,3 +94,35 @@ def expit_cr(x):
     x = np.asarray(x, dtype=f32).astype(f64)
     with np.errstate(over="ignore"):
         return (1.0 / (1.0 + np.exp(-x))).astype(f32)
+
+
+def mfma_k_order(K: int, tile: int = 16):
+    """Summation order of the engine's fp32 MFMA GEMMs (blackjax_amd/csrc/bjx_dense.hip): K is
+    walked in tiles of 16; inside a tile the MFMA step u = 0..7 accumulates k = u and then
+    k = 8 + u (v_mfma_f32_32x32x2_f32: lanes 0-31 carry the first k of the pair, lanes 32-63 the
+    second).  Indices >= K (zero padding of the last tile) are dropped: fma(0, b, acc) == acc."""
+    order = []
+    for t0 in range(0, K, tile):
+        for u in range(tile // 2):
+            for k in (t0 + u, t0 + tile // 2 + u):
+                if k < K:
+                    order.append(k)
+    return np.asarray(order, dtype=np.int32)
+
+
+def gemm_f32chain(a, b_kn, k_order=None):
+    """NumPy statement of an fp32 dot evaluated as ONE fmaf chain per output element in a given k
+    order: C[m][n] = fma(a[m][k_last], b[k_last][n], ... fma(a[m][k_0], b[k_0][n], +0)).  The
+    reference's dense products are ``jnp.dot(..., precision="highest")`` in fp32
+    (blackjax/util.py:23-61) whose summation order is implementation-defined; this is that
+    arithmetic for the order the engine's MFMA kernels use.  Slow (one vectorised fma32 per k):
+    the C port (oracle/cport.py::gemm_f32chain) is the fast twin, checked against this one."""
+    a = np.asarray(a, dtype=f32)
+    b_kn = np.asarray(b_kn, dtype=f32)
+    K = a.shape[1]
+    if k_order is None:
+        k_order = mfma_k_order(K)
+    acc = np.zeros((a.shape[0], b_kn.shape[1]), f32)
+    for k in k_order:
+        acc = fma32(a[:, k:k + 1], b_kn[k:k + 1, :], acc)
+    return acc

@@ -60,9 +60,14 @@ class Metric(NamedTuple):
     inverse_mass_matrix: np.ndarray  # (D,), (N, D) or (D, D)
     mass_matrix_sqrt: np.ndarray  # diag: 1/sqrt(imm) ; dense: L^{-T}
     is_dense: bool
+    # how a SHARED dense matrix is applied: "f64" = fp64-accumulated dot rounded once (order
+    # independent); "f32chain" = fp32 fmaf chain in the k order of the engine's MFMA GEMMs
+    # (fp.mfma_k_order) -- the arithmetic of an fp32 "precision=highest" dot for that order
+    dense_accum: str = "f64"
 
 
-def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False) -> Metric:
+def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False,
+                   dense_accum="f64", mass_matrix_sqrt=None) -> Metric:
     """metrics.py:180-218 -> gaussian_euclidean 221-346 -> _format_covariance 701-729.
 
     diag: ``inv_cov_sqrt = sqrt(imm)``, ``mass_matrix_sqrt = 1/inv_cov_sqrt``
@@ -70,7 +75,9 @@ def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False) -> 
     square is a per-chain diagonal (the vmapped-warmup case).  dense:
     ``L = cholesky(imm, lower)``, ``mass_matrix_sqrt = solve_triangular(L, I,
     lower=True, trans=True) = L^{-T}`` (711-715); factorised in fp64 and rounded
-    once to fp32.
+    once to fp32.  ``mass_matrix_sqrt`` (dense only) overrides the factor: two fp64 LAPACK
+    builds may round a handful of the D^2 entries of L^{-T} differently, so a bit-exact
+    comparison hands both sides the SAME fp32 factor (checked to be within 1 ulp of this one).
     """
     imm = np.asarray(inverse_mass_matrix, dtype=f32)
     if imm.ndim == 1 or (imm.ndim == 2 and per_chain_diag) or (
@@ -79,9 +86,10 @@ def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False) -> 
         inv_sqrt = np.sqrt(imm)
         return Metric(imm, (f32(1.0) / inv_sqrt).astype(f32), False)
     if imm.ndim == 2 and imm.shape[0] == imm.shape[1]:
-        L = np.linalg.cholesky(imm.astype(f64))
-        mass_sqrt = np.linalg.solve(L.T, np.eye(L.shape[0]))  # L^{-T}
-        return Metric(imm, mass_sqrt.astype(f32), True)
+        if mass_matrix_sqrt is None:
+            L = np.linalg.cholesky(imm.astype(f64))
+            mass_matrix_sqrt = np.linalg.solve(L.T, np.eye(L.shape[0]))  # L^{-T}
+        return Metric(imm, np.asarray(mass_matrix_sqrt).astype(f32), True, dense_accum)
     if imm.ndim == 3 and imm.shape[1] == imm.shape[2]:
         # one dense matrix PER CHAIN (what a vmapped dense window_adaptation produces)
         L = np.linalg.cholesky(imm.astype(f64))
@@ -101,6 +109,11 @@ def linear_map(metric: Metric, mat, x):
         return (mat * x).astype(f32)
     if mat.ndim == 3:  # per-chain matrices
         return np.einsum("nij,nj->ni", mat.astype(f64), x.astype(f64)).astype(f32)
+    if metric.dense_accum == "f32chain":  # y[n] = fmaf chain over k of x[k] * mat[n][k]
+        from . import cport
+        from .fp import mfma_k_order
+
+        return cport.gemm_f32chain(x, np.ascontiguousarray(mat, dtype=f32).T, mfma_k_order(mat.shape[1]))
     return (x.astype(f64) @ mat.astype(f64).T).astype(f32)
 
 
@@ -161,10 +174,13 @@ def chain_keys(rng_key, n, chain_offset=0):
 
 def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
            num_integration_steps: int, divergence_threshold: float = 1000.0,
-           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False):
-    """hmc.py:279-312 with hmc_proposal.generate 153-176, batched over chains."""
+           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None):
+    """hmc.py:279-312 with hmc_proposal.generate 153-176, batched over chains.  ``metric``: a
+    prepared ``Metric`` (e.g. ``default_metric(..., dense_accum="f32chain")``) instead of
+    classifying ``inverse_mass_matrix`` again."""
     N, D = state.position.shape
-    metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
+    if metric is None:
+        metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
     keys = chain_keys(rng_key, N, chain_offset) if chain_keys_override is None else chain_keys_override
     kk = prng.split(keys, 2)  # hmc.py:299
     key_momentum, key_integrator = kk[:, 0], kk[:, 1]

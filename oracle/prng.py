@@ -95,6 +95,17 @@ def split(k, n: int = 2, offset: int = 0) -> np.ndarray:
     return np.stack([o0, o1], axis=-1)
 
 
+def split_at(k, indices) -> np.ndarray:
+    """Rows ``indices`` of ``jax.random.split(k, n)`` for any n > max(indices): child keys of ONE
+    key at arbitrary (64-bit) positions -- the per-chain keys of a subset of global chain indices."""
+    k = as_key(k)
+    idx = np.asarray(indices, dtype=np.uint64)
+    hi = (idx >> np.uint64(32)).astype(u32)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(u32)
+    o0, o1 = threefry2x32(k[0], k[1], hi, lo)
+    return np.stack([o0, o1], axis=-1)
+
+
 def fold_in(k, data) -> np.ndarray:
     """jax.random.fold_in(key, data): threefry(key, (0, data)); batched over keys/data."""
     k = as_key(k)
