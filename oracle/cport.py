@@ -103,9 +103,6 @@ def gemm_f32chain(a, b_kn, k_order, nthreads=0):
     sbk, sbn = b_kn.strides[0] // 4, b_kn.strides[1] // 4
     order = np.ascontiguousarray(k_order, dtype=np.int32)
     assert sorted(order.tolist()) == list(range(K))
-    base = b_kn
-    while base.base is not None:  # keep the owner of the memory alive and find its first element
-        base = base.base
     c = np.empty((M, Nn), np.float32)
     ptr = ctypes.cast(b_kn.ctypes.data, ctypes.POINTER(ctypes.c_float))
     rc = lib.bjx_oracle_gemm_f32chain(M, K, Nn, _fp(a), ptr, sbk, sbn,

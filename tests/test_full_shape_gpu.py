@@ -98,23 +98,27 @@ def test_c2_full_shape_all_chains_vs_c_port_and_subset_vs_numpy(dev):
 
 # ------------------------------------------------------------------------------------------- C3
 def test_c3_full_shape_nuts_subset_vs_numpy(dev):
-    """configs[2]: NUTS (max_depth = 10) on the 256-dim funnel, 32 768 chains.  Three transitions,
-    once as lockstep ``step`` calls and once as a free-running ``run``: tree sizes, depths, flags
-    exact and positions equal for 80+ chains against the NumPy oracle."""
-    N, D, T, eps, depth = 32768, 256, 3, 0.1, 10
+    """configs[2]: NUTS (max_depth = 10) on the 256-dim funnel, 32 768 chains.  Five transitions,
+    once as a free-running ``run`` and once as lockstep ``step`` calls: tree sizes, depths, flags
+    exact and positions equal against the NumPy oracle for 80+ chains spread over the batch PLUS
+    the chains that built the deepest trees of the run (picked from the engine's own record --
+    only the choice of indices depends on it, the oracle recomputes them from scratch)."""
+    N, D, T, eps, depth = 32768, 256, 5, 0.1, 10
     rng = np.random.default_rng(5)
     q0 = (f32(0.1) * rng.standard_normal((N, D), dtype=f32)).astype(f32)
     imm = np.ones(D, f32)
     fn_o = otargets.neal_funnel()
-    idx = spread_indices(N, (16384, 8192), 50, seed=6)
-    assert len(idx) >= 64
-    st_s = ohmc.init(q0[idx], fn_o)
 
     alg = bjx.nuts(bjx.targets.NealFunnel(), eps, dev_t(imm, dev), max_num_doublings=depth)
     st0 = alg.init(dev_t(q0, dev))
     run_key = prng.key(11)
     keys = prng.split(run_key, T)
     final, positions, rinfo = alg.run(run_key, st0, T)  # free-running chains, step-major keys
+    total_leaves = rinfo.num_integration_steps.sum(0)
+    deepest = t2n(torch.topk(total_leaves, 8).indices)
+    idx = np.unique(np.concatenate([spread_indices(N, (16384, 8192), 50, seed=6), deepest]))
+    assert len(idx) >= 64
+    st_s = ohmc.init(q0[idx], fn_o)
     st_g = st0
     depths = []
     for t in range(T):
@@ -137,6 +141,9 @@ def test_c3_full_shape_nuts_subset_vs_numpy(dev):
         depths += list(info_s.num_trajectory_expansions)
     assert torch.equal(final.position, st_g.position)
     assert len(set(depths)) >= 3  # trees of several depths among the compared chains
+    assert max(depths) == int(rinfo.num_trajectory_expansions.max())  # incl. the deepest tree of the run
+    print(f"C3 parity: {len(idx)} chains, tree depths {sorted(set(int(d) for d in depths))}, "
+          f"largest tree {int(rinfo.num_integration_steps.max())} leapfrogs")
 
 
 # ------------------------------------------------------------------------------------------- C4
