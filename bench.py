@@ -1,40 +1,54 @@
 #!/usr/bin/env python
 """Headline benchmark: chain-leapfrog-steps/sec of batched diagonal-mass HMC on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): 65 536 chains x 1 024-dim
-diagonal Gaussian (sigma_i = 10^(-1+2i/(D-1))), inverse mass = sigma^2, eps = 0.25,
-L = 50 leapfrog steps per transition, fp32.  A "step" is one HMC transition of every
-chain (momentum draw, L leapfrogs each followed by the log-density callable, Metropolis
-accept).  Chains shard over GPUs with no data-path collective (weak scaling: 65 536
-chains PER GPU); per-chain keys come from the global chain index.
+``--config c2`` (default; BASELINE.json configs[1], SURVEY.md section 8d "C2"): 65 536 chains x
+1 024-dim diagonal Gaussian (sigma_i = 10^(-1+2i/(D-1))), inverse mass = sigma^2, eps = 0.25,
+L = 50 leapfrog steps per transition, fp32.  A "step" is one HMC transition of every chain
+(momentum draw, L leapfrogs each followed by the log-density callable, Metropolis accept).
+``--config c4`` (configs[3]): ``window_adaptation(hmc, L = 50)`` on the 4 096-dim ill-conditioned
+Gaussian, 32 768 chains PER GPU (262 144 on 8 GPUs) with per-chain step size and per-chain inverse
+mass matrix; a "step" is one warm-up step (transition + dual averaging + Welford) of every chain.
+Chains shard over GPUs with no data-path collective (weak scaling); per-chain keys come from the
+global chain index (``chain_offset = rank * chains_per_gpu``).
 
-Scheduling of a transition (``--chain-block``): chains are independent, so the engine may run a
-transition block by block over chains -- same kernels, same results bit for bit.  A block whose
-q, p, g fit the 256 MiB Infinity Cache (16 384 chains at D = 1 024) re-reads its state from the cache
-across the L steps; whether that beats one launch for all chains (pure HBM streaming) depends on the
-box (+13 % ... -3 % measured across the pool).  The default (-1) therefore AUTOTUNES during warm-up:
-two untimed transitions in each mode, the faster one is benchmarked and named in
-``config.chain_block``; the other mode is timed afterwards and reported as ``alternate_mode``.
-``--chain-block 0`` / ``n`` force one launch for all chains / blocks of n chains.
+Launching: ``python bench.py --gpus N`` with N > 1 and no torchrun environment re-executes itself
+under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU over RCCL) and
+REFUSES to run when fewer than N GPUs are visible -- it never reports fewer ranks than asked for.
+Under torchrun (RANK / WORLD_SIZE set) ``--gpus`` must equal WORLD_SIZE.  Rank 0 prints ONE JSON
+line with ``n_gpus`` = the ranks RCCL saw, every rank's device and time, and the max over ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (fused kick+drift leapfrog): ALGORITHMIC bytes per launch
-                  (20 B x D x chains per launch: read p,g,q; write p,q) / mean launch duration
-                  measured with HIP events on the launch stream inside the timed region (every 16th
-                  launch is bracketed when a transition has >= 100 launches, events from a pool
-                  recorded before the region; the cost of an empty bracket is reported beside it);
-                  peak 8000 GB/s.
-Also reported: gpu_ms_of_each_step (HIP events around every timed transition) and
-host_enqueue_ms_per_step -- a run in which the host fell behind shows as long steps at unchanged
-kernel durations.
-  cpu_baseline -- the oracle's C/OpenMP port of the same transition timed on the host cores on a
-                  bounded sample (rank 0, N=1 only).  A reported baseline, not the target.
+Scheduling of a C2 transition (``--chain-block``): chains are independent, so the engine may run
+a transition block by block over chains -- same kernels, same results bit for bit.  A block whose
+q, p, g fit the 256 MiB Infinity Cache (16 384 chains at D = 1 024) re-reads its state from the
+cache across the L steps.  The default autotunes in the warm-up (two untimed transitions per
+candidate: cache blocks with plain launches, cache blocks with the inner loop as a HIP graph when
+the host's launch rate is close to the GPU's pace, all chains per launch), the fastest candidate
+is THE timed region; the others are measured afterwards for the roofline object.
+
+JSON extras (contract in the task statement):
+  roofline      dominant kernel = fused kick+drift leapfrog, ALGORITHMIC bytes per launch
+                (20 B x D x chains per launch: read p,g,q; write p,q) / mean launch duration measured
+                with HIP events on the launch stream inside a timed region.  ``frac`` is the
+                HBM-STREAMING measurement (all chains per launch: every launch moves 1.3 GB through
+                HBM); ``cache_assisted_frac`` is the same kernel on Infinity-Cache blocks, where
+                part of the traffic never reaches HBM -- it can exceed what HBM alone delivers and
+                is reported under that name only.  ``traffic`` comes from the committed PMC summary
+                (``traffic_source`` says so; it is not measured in this run).
+  torch_callable_mode   the same workload with the user log-density as a plain PyTorch function
+                (autograd), the path north_star names, with its own bytes/element estimate.
+  ess / ess_nonresonant   min-ESS per second on the contract parameters (eps*L = 12.5 ~ 4 pi: a
+                resonant trajectory length, every transition returns near its start) and on
+                eps = 0.21 (same cost per transition, non-resonant).
+  cpu_baseline  BlackJAX on JAX-CPU when ``import jax, blackjax`` works on this box ("reference"),
+                else the oracle's C/OpenMP port ("port"); bounded sample, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,12 +62,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def sigma_ladder(D):
-    return (10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32)
+def sigma_ladder(D, lo=-1.0, hi=1.0):
+    return (10.0 ** (lo + (hi - lo) * np.arange(D) / (D - 1))).astype(np.float32)
 
 
-def cpu_baseline(D, L, eps, target_seconds=15.0):
-    """Time the oracle's C port (all host cores) on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline_port(D, L, eps, target_seconds):
+    """The oracle's C port (all host cores) on a bounded sample of the same workload."""
     from oracle import cport, prng
 
     sig = sigma_ladder(D)
@@ -62,15 +77,10 @@ def cpu_baseline(D, L, eps, target_seconds=15.0):
     threads = cport.num_threads()
     n = 8 * threads
     rng = np.random.default_rng(0)
-
-    def make(n):
-        q = (sig * rng.standard_normal((n, D))).astype(np.float32)
-        g = -(q * inv_var)
-        logp = (0.5 * np.sum(q.astype(np.float64) * g, axis=-1)).astype(np.float32)
-        return q, logp, g.astype(np.float32)
-
     n_big = 2048 * threads
-    q, logp, g = make(n_big)
+    q = (sig * rng.standard_normal((n_big, D))).astype(np.float32)
+    g = (-(q * inv_var)).astype(np.float32)
+    logp = (0.5 * np.sum(q.astype(np.float64) * g, axis=-1)).astype(np.float32)
     cport.hmc_diag_gaussian_step(prng.key(0), q[:n], logp[:n], g[:n], eps, imm, inv_var, L)  # warm
     keys = prng.split(prng.key(1), 1000)
     done = 0
@@ -80,71 +90,228 @@ def cpu_baseline(D, L, eps, target_seconds=15.0):
         done += 1
     dt = time.perf_counter() - t0
     return {
-        "value": n_big * L * done / dt,
-        "unit": "chain-leapfrog-steps/s",
-        "cores": threads,
+        "value": n_big * L * done / dt, "unit": "chain-leapfrog-steps/s", "cores": threads,
         "kind": "port",
-        "sample": f"{n_big} chains x {D} dims, L={L}, {done} transitions "
-                  f"({dt:.1f} s) -- C/OpenMP port of the oracle (CPU restatement of BlackJAX "
-                  "arithmetic, NOT JAX: no jax wheel on this box)",
+        "sample": f"{n_big} chains x {D} dims, L={L}, {done} transitions ({dt:.1f} s) -- C/OpenMP "
+                  "port of the oracle (a CPU restatement of BlackJAX's arithmetic, NOT JAX)",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # 40 timed transitions = 0.6 s: a single host/driver hiccup (one 28 ms step among 14.5 ms ones was
-    # seen in 1 of 8 back-to-back runs) moves a 10-step region by 8 %, a 40-step region by 2 %
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=65536, help="chains PER GPU")
-    ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--leapfrogs", type=int, default=50)
-    ap.add_argument("--eps", type=float, default=0.25)
-    ap.add_argument("--chain-block", type=int, default=-1,
-                    help="chains per launch: -1 = auto (block sized for the Infinity Cache), "
-                         "0 = all chains at once, n = n chains")
-    ap.add_argument("--use-graph", action="store_true",
-                    help="capture each block's inner leapfrog/callable loop in a HIP graph")
-    ap.add_argument("--no-plain-mode", action="store_true",
-                    help="skip the extra all-chains-at-once (HBM streaming) measurement")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-launch-timing", action="store_true")
-    ap.add_argument("--time-every", type=int, default=0,
-                    help="bracket every k-th leapfrog launch with HIP events (0 = 16 for short launches, else 1)")
-    args = ap.parse_args()
+def cpu_baseline_jax(D, L, eps, target_seconds):
+    """BlackJAX itself on JAX-CPU: jit(scan(vmap(kernel.step))) -- only when both import here."""
+    os.environ.setdefault("JAX_PLATFORMS", "cpu")
+    import blackjax  # noqa: F401  (ImportError -> the caller falls back to the port)
+    import jax
+    import jax.numpy as jnp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    sig = jnp.asarray(sigma_ladder(D))
+    imm = sig * sig
+    inv_var = 1.0 / imm
+
+    def logdensity(q):
+        return -0.5 * jnp.sum(q * q * inv_var)
+
+    alg = blackjax.hmc(logdensity, eps, imm, L)
+    cores = os.cpu_count() or 1
+    n, T = 64 * cores, 4
+    q0 = sig * jax.random.normal(jax.random.key(1), (n, D), dtype=jnp.float32)
+    states = jax.vmap(alg.init)(q0)
+
+    @jax.jit
+    def run(states, key):
+        def body(st, k):
+            st, info = jax.vmap(alg.step)(jax.random.split(k, n), st)
+            return st, info.acceptance_rate.mean()
+
+        return jax.lax.scan(body, states, jax.random.split(key, T))
+
+    states, _ = run(states, jax.random.key(0))
+    jax.block_until_ready(states)
+    done = 0
+    t0 = time.perf_counter()
+    while done < 1 or time.perf_counter() - t0 < target_seconds:
+        states, acc = run(states, jax.random.key(2 + done))
+        jax.block_until_ready(states)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * L * T * done / dt, "unit": "chain-leapfrog-steps/s", "cores": cores,
+        "kind": "reference",
+        "sample": f"blackjax {getattr(blackjax, '__version__', '?')} on jax {jax.__version__} (CPU), "
+                  f"jit(scan(vmap(step))): {n} chains x {D} dims, L={L}, {T * done} transitions "
+                  f"({dt:.1f} s), mean acceptance {float(acc[-1]):.3f}",
+    }
+
+
+def cpu_baseline(D, L, eps, target_seconds=15.0):
+    """First try the real thing, then the port; say which and why."""
+    try:
+        return cpu_baseline_jax(D, L, eps, target_seconds)
+    except Exception as e:  # ImportError on a box without jax/blackjax wheels, or any runtime failure
+        out = cpu_baseline_port(D, L, eps, target_seconds)
+        out["jax_baseline"] = f"unavailable on this box ({type(e).__name__}: {e})"
+        return out
+
+
+# ------------------------------------------------------------------------------------ launching
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """``--gpus N`` without a torchrun environment: re-execute under torch.distributed.run, one
+    rank per GPU.  Fails loudly when the box cannot give N ranks their own GPU."""
+    n = args.gpus
+    backend = os.environ.get("BJX_BENCH_BACKEND", "nccl")
+    if not args.selftest_control_flow and backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.exit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this box -- refusing to run "
+                     f"(a {n}-GPU figure needs {n} GPUs; nothing is reported instead of n_gpus < {n})")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Ctx:
+    """Rank / device / collectives of this process."""
+
+    def __init__(self, args):
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # One rank per GPU over RCCL (backend "nccl").  BJX_BENCH_BACKEND=gloo exists only so the
-        # multi-rank control flow can be exercised on a single-GPU box (ranks then share cuda:0).
-        backend = os.environ.get("BJX_BENCH_BACKEND", "nccl")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.cpu_only = bool(args.selftest_control_flow)
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with "
+                             f"--nproc-per-node {args.gpus} (or drop the torchrun environment and let "
+                             "bench.py spawn its ranks)")
+        self.backend = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # One rank per GPU over RCCL (backend "nccl").  BJX_BENCH_BACKEND=gloo exists only so the
+            # multi-rank control flow can be exercised on a single-GPU or GPU-less box.
+            self.backend = "gloo" if self.cpu_only else os.environ.get("BJX_BENCH_BACKEND", "nccl")
+        if self.cpu_only:
+            self.dev = torch.device("cpu")
         else:
-            dist.init_process_group(backend)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (blackjax_amd has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+            assert torch.cuda.is_available(), "bench.py needs a GPU (blackjax_amd has no CPU fallback)"
+            n_dev = torch.cuda.device_count()
+            if self.backend == "nccl" and n_dev < self.world:
+                raise SystemExit(f"bench.py: {self.world} ranks but {n_dev} GPU(s) visible")
+            self.local_rank %= max(n_dev, 1)
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
 
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def sync(self):
+        if not self.cpu_only:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        """-> (max, [per-rank values])"""
+        if self.world == 1:
+            return dt, [dt]
+        t = torch.tensor([dt], device=self.coll_dev, dtype=torch.float64)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        per = [float(o.item()) for o in out]
+        return max(per), per
+
+    def ranks_seen(self):
+        me = {"rank": self.rank, "local_rank": self.local_rank, "device": str(self.dev),
+              "name": "cpu" if self.cpu_only else torch.cuda.get_device_name(self.dev),
+              "pid": os.getpid()}
+        if self.world == 1:
+            return [me]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, me)
+        return out
+
+    @property
+    def coll_dev(self):
+        """Device the collectives run on: the GPU under RCCL; gloo gathers go through host memory."""
+        return self.dev if self.backend == "nccl" else torch.device("cpu")
+
+    def gather_rows(self, x):
+        if self.world == 1:
+            return x
+        x = x.to(self.coll_dev).contiguous()
+        out = [torch.empty_like(x) for _ in range(self.world)]
+        self.dist.all_gather(out, x)
+        return torch.cat(out, 0)
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed_region(ctx, step_fn, steps):
+    """The contract's timing: barrier + synchronize, EXACTLY ``steps`` calls of ``step_fn(i)``,
+    synchronize + barrier; returns (max over ranks of the wall time, per-rank times, this rank's
+    host enqueue time)."""
+    ctx.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(i)
+    t_enq = time.perf_counter() - t0
+    ctx.sync()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    mx, per = ctx.max_over_ranks(dt)
+    return mx, per, t_enq
+
+
+def selftest_control_flow(args, ctx):
+    """CPU-only exercise of this file's multi-rank control flow (spawn, rendezvous, barriers,
+    max-over-ranks timing, gather, one JSON line from rank 0) with a sleep in place of the GPU step.
+    NOT a measurement: ``value`` is null and the metric says so."""
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    dt, per, _ = timed_region(ctx, lambda i: time.sleep(0.002 * (1 + ctx.rank)), args.steps)
+    rows = ctx.gather_rows(torch.full((2, 3), float(ctx.rank)))
+    seen = ctx.ranks_seen()
+    if ctx.rank == 0:
+        print(json.dumps({
+            "metric": "control-flow self-test (no GPU work; NOT a measurement)", "value": None,
+            "unit": None, "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per],
+            "ranks_seen": seen, "backend": ctx.backend, "gathered_rows": list(rows.shape),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}), flush=True)
+
+
+# ------------------------------------------------------------------------------------ C2
+def bench_c2(args, ctx):
     import blackjax_amd as bjx
     from blackjax_amd import _lib
     from blackjax_amd.hmc import auto_chain_block
 
-    N, D, L = args.chains, args.dim, args.leapfrogs
-    blk = auto_chain_block(N, D) if args.chain_block < 0 else (args.chain_block or N)
-    blk = min(blk, N)
-    n_blocks = (N + blk - 1) // blk
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    N, D, L = args.chains or 65536, args.dim or 1024, args.leapfrogs
+    blk_auto = min(auto_chain_block(N, D), N)
     sig = torch.as_tensor(sigma_ladder(D), device=dev)
     imm = (sig * sig).contiguous()
-    target = bjx.targets.DiagGaussian((1.0 / imm).contiguous())
+    inv_var = (1.0 / imm).contiguous()
+    target = bjx.targets.DiagGaussian(inv_var)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     q_init = sig * torch.randn(N, D, device=dev, generator=gen)
@@ -152,28 +319,22 @@ def main():
     n_sub = min(1024, N)
     timed_kernel = "bjx_leapfrog_diag"
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    host_enqueue_ms = []  # per measure() call: host time to queue one transition
-    per_step_ms = []      # per measure() call: GPU time of every timed transition (HIP events)
-
-    def measure(chain_block, use_graph, collect_draws):
+    def measure(chain_block, use_graph, collect_draws, steps=None, fn=None, eps=None, timing=True):
         """W warm-up + K timed transitions in one scheduling mode.  The warm-up runs EXACTLY the
         timed loop's body (bookkeeping torch ops and launch-timer events included) plus one priming
         pass: on a fresh box the first use of any kernel pages its code object in from disk, which
         must not land in the timed region."""
-        alg = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=chain_block,
-                      use_graph=use_graph)
+        steps = args.steps if steps is None else steps
+        alg = bjx.hmc(target if fn is None else fn, args.eps if eps is None else eps, imm, L,
+                      chain_offset=rank * N, chain_block=chain_block, use_graph=use_graph)
         state = alg.init(q_init)
         launches = L * ((N + chain_block - 1) // chain_block)
         # Sampling rate of the HIP-event brackets.  A bracket costs host time and drains the
         # queue around the launch; at ~50 us launches, bracketing every 4th one slowed the whole
-        # timed region by 13 % (16.4 vs 14.5 ms per transition), so short launches are sampled sparsely.
+        # timed region by 13 %, so short launches are sampled sparsely.
         every = args.time_every or (16 if launches >= 100 else 1)
-        timing = not args.no_launch_timing and not use_graph  # events cannot be recorded inside a graph
-        cap = (launches // every + 1) * (max(args.steps, args.warmup + 1))
+        timing = timing and not args.no_launch_timing and not use_graph  # no events inside a graph
+        cap = (launches // every + 1) * (max(steps, args.warmup + 1))
         warm_timer = _lib.LaunchTimer([timed_kernel], every, cap) if timing else None
         _lib.set_timer(warm_timer)
         warm_acc = torch.zeros((), device=dev)
@@ -194,176 +355,344 @@ def main():
             _lib.set_timer(timer)
         acc_sum = torch.zeros((), device=dev)
         draws = []  # retained draws of a fixed chain subset for ESS/sec (4 MiB per step at C2)
-        step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-        for ev in step_marks:
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        for ev in marks:
             ev.record()  # HIP events are created at the first record(): do that outside the region
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        step_marks[0].record()
-        for t in range(args.warmup, args.warmup + args.steps):
-            state, info = alg.step(keys[t], state)
-            acc_sum += info.acceptance_rate.mean()
+        box = {"state": state}
+
+        def one(i):
+            if i == 0:
+                marks[0].record()
+            st, info = alg.step(keys[(args.warmup + i) % len(keys)], box["state"])
+            box["state"] = st
+            acc_sum.add_(info.acceptance_rate.mean())
             if collect_draws:
-                draws.append(state.position[:n_sub].clone())
-            step_marks[t - args.warmup + 1].record()
-        t_enq = time.perf_counter() - t0  # the host has queued everything; the GPU may still be working
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        host_enqueue_ms.append(t_enq / max(args.steps, 1) * 1e3)
-        per_step_ms.append([round(a.elapsed_time(b), 3) for a, b in zip(step_marks, step_marks[1:])])
+                draws.append(st.position[:n_sub].clone())
+            marks[i + 1].record()
+
+        dt, per, t_enq = timed_region(ctx, one, steps)
         _lib.set_timer(None)
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        roof = None
+        res = {"chain_block": chain_block, "hip_graph": bool(use_graph), "dt": dt, "per_rank_dt": per,
+               "steps": steps, "ms_per_step": dt / steps * 1e3,
+               "value": world * N * L * steps / dt,
+               "host_enqueue_ms_per_step": t_enq / max(steps, 1) * 1e3,
+               "gpu_ms_of_each_step": [round(a.elapsed_time(b), 3) for a, b in zip(marks, marks[1:])],
+               "mean_acceptance": float(acc_sum.item()) / max(steps, 1), "draws": draws,
+               "state": box["state"], "launch": None}
         if timer is not None:
             d_ms = timer.durations_ms(timed_kernel)
             avg_s = float(np.mean(d_ms)) * 1e-3
             alg_bytes = 20.0 * D * min(chain_block, N)  # read p,g,q ; write p,q (imm (D,) is shared and cached)
-            achieved = alg_bytes / avg_s / 1e9
-            # bjx_leapfrog_diag dispatches rows of a multiple of 1 024 floats to the flat kernel
-            flat = D % 1024 == 0 and os.environ.get("BJX_LF_FLAT", "1") != "0"
-            roof = {"bound": "hbm", "kernel": "k_leapfrog_diag_flat<2>" if flat else "k_leapfrog_diag<4,2>",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                    "chains_per_launch": min(chain_block, N), "avg_launch_us": avg_s * 1e6,
-                    "launches_timed": len(d_ms), "timed_every": every}
-            # What the bracket itself costs: a pair of event records around NOTHING, behind a kernel
-            # of the same kind so the queue is in the same state.  Reported beside the raw figure
-            # (`achieved` / `frac` stay on the raw one); rocprofv3's kernel-trace average for this
-            # kernel (profiles/) should sit near avg_launch_us - event_bracket_overhead_us.
+            res["launch"] = {"chains_per_launch": min(chain_block, N), "avg_launch_us": avg_s * 1e6,
+                             "algorithmic_bytes_per_launch": alg_bytes,
+                             "achieved": alg_bytes / avg_s / 1e9, "launches_timed": len(d_ms),
+                             "timed_every": every}
+        return res
+
+    # ---- scheduling autotune (untimed, part of the warm-up)
+    candidates = [(blk_auto, False)]
+    if args.chain_block >= 0:
+        candidates = [(min(args.chain_block or N, N), bool(args.use_graph))]
+    elif blk_auto < N:
+        candidates += [(blk_auto, True), (N, False)]
+    tuning = {}
+    if len(candidates) > 1:
+        for cb, gr in candidates:
             try:
-                empties = []
-                probe = torch.zeros(min(chain_block, N), D, device=dev)
-                for _ in range(32):
-                    probe.add_(1.0)
-                    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s_ev.record()
-                    e_ev.record()
-                    empties.append((s_ev, e_ev))
+                alg_t = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=cb, use_graph=gr)
+                st_t = alg_t.init(q_init)
+                for kk in bjx.random.split(bjx.random.key(777), 2):  # priming (and graph recording)
+                    st_t, _ = alg_t.step(kk, st_t)
                 torch.cuda.synchronize()
-                over_us = float(np.median([a.elapsed_time(b) for a, b in empties[8:]])) * 1e3
-                roof["event_bracket_overhead_us"] = over_us
-                roof["avg_launch_us_net_of_bracket"] = avg_s * 1e6 - over_us
-            except Exception:
-                pass
-        return state, dt, roof, float(acc_sum.item()) / max(args.steps, 1), draws
+                t_t = time.perf_counter()
+                for kk in bjx.random.split(bjx.random.key(778), 2):
+                    st_t, _ = alg_t.step(kk, st_t)
+                torch.cuda.synchronize()
+                tuning[(cb, gr)] = (time.perf_counter() - t_t) / 2 * 1e3
+                del alg_t, st_t
+            except Exception as e:  # a mode that cannot run here is simply not a candidate
+                tuning[(cb, gr)] = float("inf")
+                if rank == 0:
+                    print(f"bench.py: candidate chain_block={cb} hip_graph={gr} failed: {e!r}", file=sys.stderr)
+        if world > 1:  # every rank must benchmark the same mode
+            t = torch.tensor([tuning[c] for c in candidates], device=ctx.coll_dev, dtype=torch.float64)
+            ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+            tuning = {c: float(v) for c, v in zip(candidates, t.tolist())}
+        best = min(candidates, key=lambda c: tuning[c])
+    else:
+        best = candidates[0]
 
-    # Scheduling autotune (untimed, part of the warm-up): whether Infinity-Cache blocking beats one
-    # launch for all chains depends on the box (+13 % ... -3 % across the pool), so with the default
-    # --chain-block -1 both are tried for two transitions each and the faster one is benchmarked.
-    tuning = None
-    if args.chain_block < 0 and n_blocks > 1:
-        tuning = {}
-        for cb in (blk, N):
-            alg_t = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=cb)
-            st_t = alg_t.init(q_init)
-            st_t, _ = alg_t.step(bjx.random.key(777), st_t)
-            torch.cuda.synchronize()
-            t_t = time.perf_counter()
-            for kk in bjx.random.split(bjx.random.key(778), 2):
-                st_t, _ = alg_t.step(kk, st_t)
-            torch.cuda.synchronize()
-            tuning[cb] = (time.perf_counter() - t_t) / 2 * 1e3
-        del alg_t, st_t
-        if tuning[N] < tuning[blk]:
-            blk, n_blocks = N, 1
-    other_blk = None
-    if args.chain_block < 0 and tuning is not None:
-        other_blk = N if blk != N else min(auto_chain_block(N, D), N)
+    head = measure(best[0], best[1], True)  # THE timed region
+    final_draws = ctx.gather_rows(head["state"].position[:256])  # the only thing that crosses xGMI
 
-    state, dt, roofline, mean_acc, draws = measure(blk, args.use_graph, True)
-    if roofline is not None:
+    # ---- extra regions (rank 0 timing only matters; all ranks run them so barriers line up)
+    extras = not args.headline_only
+    stream_m = cache_m = None
+    if head["launch"] is not None:
+        if head["chain_block"] >= N:
+            stream_m = head
+        else:
+            cache_m = head
+    if extras and not args.no_launch_timing:
+        if stream_m is None:
+            stream_m = measure(N, False, False)
+        if cache_m is None and blk_auto < N:
+            cache_m = measure(blk_auto, False, False)
+
+    roofline = None
+    if rank == 0 and (stream_m or cache_m):
+        flat = D % 1024 == 0 and os.environ.get("BJX_LF_FLAT", "1") != "0"
+        src = stream_m or cache_m
+        la = src["launch"]
+        roofline = {"bound": "hbm", "kernel": "k_leapfrog_diag_flat<2>" if flat else "k_leapfrog_diag<4,2>",
+                    "achieved": la["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": la["achieved"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                    "mode": ("hbm streaming: all chains per launch" if stream_m else
+                             "Infinity-Cache blocks (no streaming measurement in this run)"),
+                    **{k: la[k] for k in ("algorithmic_bytes_per_launch", "chains_per_launch",
+                                          "avg_launch_us", "launches_timed", "timed_every")},
+                    "region_ms_per_step": src["ms_per_step"]}
+        if cache_m is not None and stream_m is not None:
+            lc = cache_m["launch"]
+            roofline["cache_assisted_achieved"] = lc["achieved"]
+            roofline["cache_assisted_frac"] = lc["achieved"] / HBM_PEAK_GBS
+            roofline["cache_assisted"] = {
+                **lc, "region_ms_per_step": cache_m["ms_per_step"],
+                "note": "same kernel on chain blocks whose q/p/g stay in the 256 MiB Infinity Cache across "
+                        "the L steps: part of these bytes never reach HBM, so this figure may exceed what "
+                        "HBM alone can deliver and is NOT the HBM roofline fraction"}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if (tj.get("chains") == N and tj.get("dim") == D
-                        and tj.get("chains_per_launch", N) == roofline["chains_per_launch"]):
-                    roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+                if tj.get("chains") == N and tj.get("dim") == D:
+                    per_chain = tj.get("hbm_bytes_per_launch") / tj.get("chains_per_launch", N)
+                    roofline["traffic"] = per_chain * roofline["chains_per_launch"]
+                    roofline["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc passes of an "
+                                                  "earlier run, committed; scaled per chain; NOT measured in "
+                                                  "this run; counters sit at the L2 memory-side interface and "
+                                                  "include Infinity-Cache hits)")
             except Exception:
                 pass
-        if n_blocks > 1:
-            roofline["note"] = ("chain-block scheduling: a block's q/p/g stay resident in the 256 MiB Infinity "
-                                "Cache across the L steps, so part of this kernel's traffic never reaches "
-                                "HBM; alternate_mode.roofline is the same kernel streaming from HBM")
+        # what an empty event bracket costs, behind a kernel of the same kind
+        try:
+            empties = []
+            probe = torch.zeros(roofline["chains_per_launch"], D, device=dev)
+            for _ in range(32):
+                probe.add_(1.0)
+                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_ev.record()
+                e_ev.record()
+                empties.append((s_ev, e_ev))
+            torch.cuda.synchronize()
+            roofline["event_bracket_overhead_us"] = float(np.median([a.elapsed_time(b) for a, b in empties[8:]])) * 1e3
+        except Exception:
+            pass
 
-    if world > 1:
-        # final draws / statistics are the only thing that crosses xGMI (RCCL all-gather)
-        sub = state.position[:256].contiguous()
-        gathered = [torch.empty_like(sub) for _ in range(world)]
-        dist.all_gather(gathered, sub)
-        final_draws = torch.cat(gathered, 0)
-    else:
-        final_draws = state.position[:256]
+    # ---- the user log-density as a plain PyTorch function (autograd): the path north_star names
+    torch_mode = None
+    if extras and not args.no_torch_callable:
+        def torch_logdensity(q):
+            return -0.5 * (q * q * inv_var).sum(-1)
 
-    # Extra, separately reported region: the same workload with all chains in one launch (every
-    # leapfrog launch streams its 1.3 GB from HBM).
-    plain_mode = None
-    if other_blk is None and n_blocks > 1:
-        other_blk = N  # an explicit --chain-block: still show the all-at-once mode beside it
-    if not args.no_plain_mode and other_blk is not None and other_blk != blk:
-        _, dt_p, roof_p, _, _ = measure(other_blk, False, False)
-        plain_mode = {"chain_block": other_blk, "value": world * N * L * args.steps / dt_p,
-                      "unit": "chain-leapfrog-steps/s", "ms_per_step": dt_p / args.steps * 1e3,
-                      "roofline": roof_p}
+        k_t = max(2, args.steps // 4)
+        m = measure(blk_auto, False, False, steps=k_t, fn=torch_logdensity, timing=False)
+        # elementwise autograd passes (fp32 words per element): q*q r1 w1, *inv_var r1 w1, sum r1,
+        # backward through sum/mul/mul r3 w3 (+ accumulation) -> ~12 words vs 2 for a fused callable
+        torch_mode = {"value": m["value"], "unit": "chain-leapfrog-steps/s", "ms_per_step": m["ms_per_step"],
+                      "steps": k_t, "chain_block": blk_auto,
+                      "logdensity": "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad)",
+                      "callable_bytes_per_element_estimate": 48,
+                      "engine_bytes_per_element": 20,
+                      "frac_of_68B_roofline": m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D)),
+                      "mean_acceptance": m["mean_acceptance"]}
 
-    # ESS/sec (second half of BASELINE.json's metric): min over dimensions of
-    # effective_sample_size (blackjax/diagnostics.py:157-304) on the retained subset / wall time
-    ess_min = None
-    if args.steps >= 4:
-        ess = bjx.diagnostics.effective_sample_size(torch.stack(draws, dim=1))  # (n_sub, T, D)
-        ess_min = float(ess.min().item())
+    # ---- ESS/sec (second half of BASELINE.json's metric)
+    def ess_of(draws, dt):
+        if len(draws) < 4:
+            return None
+        e = float(bjx.diagnostics.effective_sample_size(torch.stack(draws, dim=1)).min().item())
+        return {"min_ess_subset": e, "subset_chains": n_sub, "draws_per_chain": len(draws),
+                "min_ess_per_sec_subset": e / dt,
+                "min_ess_per_sec_all_chains": e / dt * (world * N / n_sub)}
 
-    if rank == 0:
-        value = world * N * L * args.steps / dt
-        out = {
-            "metric": "chain-leapfrog-steps/sec (whole node), 65 536 chains x 1 024-dim diag-mass HMC",
-            "value": value,
-            "unit": "chain-leapfrog-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
-                            f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
-                "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
-                "chain_block": blk, "hip_graph": bool(args.use_graph),
-                "parallelism": f"chains sharded x{world}, no data-path collective",
-            },
-            "gpu_ms_of_each_step": per_step_ms[0],
-            "host_enqueue_ms_per_step": host_enqueue_ms[0],  # close to ms_per_step = the host's launch rate is the limit
-            "mean_acceptance": mean_acc,
-            "ess": None if ess_min is None else {
-                "min_ess_subset": ess_min, "subset_chains": n_sub, "draws_per_chain": args.steps,
-                "min_ess_per_sec_subset": ess_min / dt,
-                "min_ess_per_sec_all_chains": ess_min / dt * (world * N / n_sub),
-                "note": "rank-0 subset of chains, min over the D dimensions"},
-            "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
-            "final_draws_gathered": list(final_draws.shape),
-            "scheduling_autotune_ms_per_step": (None if tuning is None else
-                                                {str(k): v for k, v in tuning.items()}),
-            "alternate_mode": plain_mode,
-            "roofline": roofline,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(D, L, args.eps)
-            except Exception as e:  # the baseline is a reported extra; never fail the GPU number
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ess = ess_of(head["draws"], head["dt"])
+    if ess is not None:
+        ess["note"] = ("contract parameters: eps*L = 12.5 is within 0.3 % of 4*pi for the ideal mass matrix "
+                       "(leapfrog phase 50 * 2*asin(0.125) = 12.533), so every transition returns each chain "
+                       "almost to its start -- this ESS does not grow with the number of draws; see "
+                       "ess_nonresonant for a meaningful figure")
+    ess_nr = None
+    if extras and not args.no_ess_nonresonant and args.steps >= 4:
+        m = measure(head["chain_block"], head["hip_graph"], True, eps=0.21, timing=False)
+        ess_nr = ess_of(m["draws"], m["dt"])
+        if ess_nr is not None:
+            ess_nr.update({"eps": 0.21, "leapfrogs": L, "ms_per_step": m["ms_per_step"],
+                           "mean_acceptance": m["mean_acceptance"],
+                           "note": "same kernels and cost per transition with eps = 0.21: trajectory phase "
+                                   "50 * 2*asin(0.105) = 10.5 rad, not a multiple of 2*pi"})
+
+    if rank != 0:
+        return None
+    value = head["value"]
+    out = {
+        "metric": "chain-leapfrog-steps/sec (whole node), 65 536 chains x 1 024-dim diag-mass HMC",
+        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"C2: HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
+                        f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
+            "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
+            "chain_block": head["chain_block"], "hip_graph": head["hip_graph"],
+            "parallelism": f"chains sharded x{world}, no data-path collective",
+        },
+        "per_rank_ms_per_step": [p / args.steps * 1e3 for p in head["per_rank_dt"]],
+        "gpu_ms_of_each_step": head["gpu_ms_of_each_step"],
+        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+        "mean_acceptance": head["mean_acceptance"],
+        "ess": ess, "ess_nonresonant": ess_nr,
+        "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
+        "final_draws_gathered": list(final_draws.shape),
+        "scheduling_autotune_ms_per_step": {f"chain_block={cb},hip_graph={gr}": v
+                                            for (cb, gr), v in tuning.items()} or None,
+        "torch_callable_mode": torch_mode,
+        "roofline": roofline,
+    }
+    return out
+
+
+# ------------------------------------------------------------------------------------ C4
+def bench_c4(args, ctx):
+    """configs[3]: window_adaptation(hmc) with per-chain step size and per-chain diagonal inverse
+    mass matrix.  W untimed + K timed warm-up steps = two ``run`` calls (the Stan schedule is a
+    function of the run's length, so the timed run is a complete K-step warm-up of its own)."""
+    import blackjax_amd as bjx
+    from blackjax_amd import _lib
+    from blackjax_amd.hmc import auto_chain_block
+
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    N, D, L = args.chains or 32768, args.dim or 4096, args.leapfrogs
+    sig = torch.as_tensor(sigma_ladder(D, -1.5, 1.5), device=dev)
+    target = bjx.targets.DiagGaussian((1.0 / (sig * sig)).contiguous())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    q0 = torch.randn(N, D, device=dev, generator=gen)
+    keep = bjx.adaptation.get_filter_adapt_info_fn(info_keys={"acceptance_rate"})
+    warm = bjx.window_adaptation(bjx.hmc, target, num_integration_steps=L, adaptation_info_fn=keep)
+    blk = min(auto_chain_block(N, D, 4), N)
+    timed_kernel = "bjx_leapfrog_diag"
+
+    if args.warmup > 0:
+        warm.run(bjx.random.key(1), q0, args.warmup, chain_offset=rank * N)
+    torch.cuda.synchronize()
+    launches = L * ((N + blk - 1) // blk)
+    every = args.time_every or (16 if launches >= 100 else 1)
+    timer = None
+    if rank == 0 and not args.no_launch_timing:
+        timer = _lib.LaunchTimer([timed_kernel], every, (launches // every + 1) * args.steps)
+        torch.cuda.synchronize()
+        _lib.set_timer(timer)
+    box = {}
+
+    def whole_run(i):
+        box["res"] = warm.run(bjx.random.key(2), q0, args.steps, chain_offset=rank * N)
+
+    dt, per, t_enq = timed_region(ctx, whole_run, 1)
+    _lib.set_timer(None)
+    (state, params), info = box["res"]
+    acc = info.info.acceptance_rate  # (K, N)
+    eps_final = params["step_size"]
+    pooled = ctx.gather_rows(torch.stack([eps_final.mean(), eps_final.min(), eps_final.max(),
+                                          acc[-1].mean()]).reshape(1, 4))
+    if rank != 0:
+        return None
+    roofline = None
+    if timer is not None:
+        d_ms = timer.durations_ms(timed_kernel)
+        avg_s = float(np.mean(d_ms)) * 1e-3
+        alg_bytes = 24.0 * D * min(blk, N)  # read p,g,q,imm (per chain) ; write p,q
+        roofline = {"bound": "hbm", "kernel": "k_leapfrog_diag_flat<2> (per-chain inverse mass)",
+                    "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "chains_per_launch": min(blk, N),
+                    "avg_launch_us": avg_s * 1e6, "launches_timed": len(d_ms), "timed_every": every,
+                    "mode": ("Infinity-Cache blocks (chain_block='auto'): part of the traffic is served by "
+                             "the cache" if blk < N else "hbm streaming")}
+    value = world * N * L * args.steps / dt
+    return {
+        "metric": "chain-leapfrog-steps/sec (whole node), window_adaptation HMC warm-up, "
+                  "32 768 chains/GPU x 4 096-dim",
+        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"C4: window_adaptation(hmc, L={L}) on the {D}-dim ill-conditioned Gaussian "
+                        f"(sigma 10^-1.5..10^1.5), {N} chains/GPU, per-chain step size and inverse mass "
+                        f"matrix, {args.steps}-step Stan schedule",
+            "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
+            "chain_block": blk, "parallelism": f"chains sharded x{world}, no data-path collective",
+        },
+        "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per],
+        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "end_to_end_frac_of_32B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (32.0 * D)),
+        "adapted": {"per_rank_[mean_eps,min_eps,max_eps,last_step_mean_acceptance]": pooled.tolist()},
+        "roofline": roofline,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    # 40 timed transitions = 0.6 s: a single host/driver hiccup (one 28 ms step among 14.5 ms ones was
+    # seen in 1 of 8 back-to-back runs) moves a 10-step region by 8 %, a 40-step region by 2 %
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2")
+    ap.add_argument("--chains", type=int, default=0, help="chains PER GPU (0 = the config's: 65 536 / 32 768)")
+    ap.add_argument("--dim", type=int, default=0, help="0 = the config's: 1 024 / 4 096")
+    ap.add_argument("--leapfrogs", type=int, default=50)
+    ap.add_argument("--eps", type=float, default=0.25)
+    ap.add_argument("--chain-block", type=int, default=-1,
+                    help="chains per launch: -1 = autotune, 0 = all chains at once, n = n chains")
+    ap.add_argument("--use-graph", action="store_true",
+                    help="with an explicit --chain-block: the block's inner loop as a HIP graph")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only THE timed region (no roofline/torch-callable/ESS extra regions)")
+    ap.add_argument("--no-torch-callable", action="store_true")
+    ap.add_argument("--no-ess-nonresonant", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="bracket every k-th leapfrog launch with HIP events (0 = 16 for short launches, else 1)")
+    ap.add_argument("--selftest-control-flow", action="store_true",
+                    help="CPU-only exercise of the multi-rank control flow (no GPU work, no measurement)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.steps < 1:
+        ap.error("--steps must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # does not return
+    ctx = Ctx(args)
+    try:
+        if args.selftest_control_flow:
+            selftest_control_flow(args, ctx)
+            return
+        seen = ctx.ranks_seen()
+        out = bench_c2(args, ctx) if args.config == "c2" else bench_c4(args, ctx)
+        if ctx.rank == 0:
+            out["ranks_seen"] = seen
+            out["backend"] = ctx.backend
+            if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.dim or 1024, args.leapfrogs, args.eps)
+                except Exception as e:  # the baseline is a reported extra; never fail the GPU number
+                    out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            print(json.dumps(out), flush=True)
+    finally:
+        ctx.finish()
 
 
 if __name__ == "__main__":

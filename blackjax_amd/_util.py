@@ -57,6 +57,36 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
     return vg
 
 
+class _Capturable:
+    """Wrapper for callables that cannot carry attributes (bound methods, builtins)."""
+
+    _bjx_capturable = True
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self, q):
+        return self._fn(q)
+
+
+def capturable(logdensity_fn: Callable) -> Callable:
+    """Declare a log-density callable safe to RECORD in a HIP graph and replay (what ``jax.jit`` does
+    to the reference's ``logdensity_fn``): static shapes, no host synchronisation, and no Python-side
+    state that changes between calls (a minibatch index, a tempering ``beta`` held as a float ...),
+    because a replay re-runs the recorded kernels, not the Python code.  The default drivers
+    (``use_graph="auto"``) record only callables declared this way -- ``blackjax_amd.targets`` are --
+    and drive every other callable with plain launches; ``use_graph=True`` records regardless."""
+    try:
+        logdensity_fn._bjx_capturable = True
+        return logdensity_fn
+    except AttributeError:
+        return _Capturable(logdensity_fn)
+
+
+def is_capturable(logdensity_fn) -> bool:
+    return bool(getattr(logdensity_fn, "_bjx_capturable", False))
+
+
 def check_batch(x: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(x)}")

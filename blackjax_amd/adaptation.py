@@ -230,7 +230,16 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                       integrator=integrators.velocity_verlet, **extra_parameters) -> AdaptationAlgorithm:
     """blackjax/adaptation/window_adaptation.py:296-444.  ``algorithm`` is ``blackjax_amd.hmc`` or
     ``blackjax_amd.nuts``; ``extra_parameters`` are forwarded to its kernel (e.g.
-    ``num_integration_steps=...``).  ``adaptation_info_fn=None`` records nothing."""
+    ``num_integration_steps=...``).  ``adaptation_info_fn=None`` records nothing.
+
+    ``run(rng_key, position, num_steps)`` returns ``(AdaptationResults, AdaptationInfo)`` as in the
+    reference.  ``run(..., free_running=True)`` (NUTS, diagonal metric, default integrator) returns
+    ``(AdaptationResults, NUTSRunInfo)`` instead: the chains adapt inside the free-running kernels,
+    so there is no per-step hook for ``adaptation_info_fn`` -- combining the flag with a custom
+    ``adaptation_info_fn`` or integrator raises rather than silently ignoring them.
+    ``parameters["inverse_mass_matrix"]`` is a ``metrics.PerChainDiagTensor`` (an ``(N, D)`` tensor
+    tagged as per-chain diagonals) so that ``algorithm(logdensity_fn, **parameters)`` is
+    unambiguous even when ``N == D``."""
     if initial_inverse_mass_matrix is not None:
         imm0 = torch.as_tensor(initial_inverse_mass_matrix)
         if is_mass_matrix_diagonal:
@@ -260,6 +269,11 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             raise NotImplementedError("free_running=True is implemented for blackjax_amd.nuts")
         if not is_mass_matrix_diagonal:
             raise NotImplementedError("free_running=True needs a diagonal mass matrix")
+        if adaptation_info_fn not in (None, return_all_adapt_info):
+            raise ValueError("free_running=True records a NUTSRunInfo, not adaptation_info_fn's output: "
+                             "pass adaptation_info_fn=None (or the default) with it")
+        if integrator is not integrators.velocity_verlet:
+            raise NotImplementedError("free_running=True is implemented for velocity_verlet only")
         n, d = state.position.shape
         dev = state.position.device
         extra = dict(extra_parameters)
@@ -279,7 +293,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             store_positions=False, adaptation=ad)
         step_size = torch.empty_like(ad["log_x_avg"])
         _lib.call("bjx_exp", _lib.current_stream(), n, ad["log_x_avg"].data_ptr(), step_size.data_ptr())
-        parameters = {"step_size": step_size, "inverse_mass_matrix": imm_pc, **extra_parameters}
+        parameters = {"step_size": step_size,
+                      "inverse_mass_matrix": metrics.PerChainDiagTensor.tag(imm_pc), **extra_parameters}
         return AdaptationResults(state, parameters), run_info
 
     def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0,
@@ -340,6 +355,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             imm_final = imm_final.expand(n, d).contiguous()
         elif not is_mass_matrix_diagonal and imm_final.ndim == 2:
             imm_final = imm_final.expand(n, d, d).contiguous()
+        if is_mass_matrix_diagonal:  # (N, D) per-chain diagonals, tagged so N == D is not read as dense
+            imm_final = metrics.PerChainDiagTensor.tag(imm_final)
         parameters = {"step_size": step_size, "inverse_mass_matrix": imm_final, **extra_parameters}
         return AdaptationResults(state, parameters), _stack_history(history)
 

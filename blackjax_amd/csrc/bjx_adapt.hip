@@ -156,7 +156,6 @@ int bjx_da_init(void* stream, int64_t N, int from_log_avg, const float* x_in, fl
   BJX_CHECK_ARG(N >= 0 && x_in && log_x_out && log_x_avg_out && avg_error_out && mu_out &&
                     step_size_out,
                 "bjx_da_init: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_da_init, dim3(flat_grid(N)), dim3(kBlock), 0, (hipStream_t)stream, N,
                      from_log_avg, x_in, log_x_out, log_x_avg_out, avg_error_out, mu_out,
                      step_size_out);
@@ -173,7 +172,6 @@ int bjx_da_update(void* stream, int64_t N, int64_t step, float target, float t0,
                     avg_error_in && mu && log_x_out && log_x_avg_out && avg_error_out &&
                     step_size_out,
                 "bjx_da_update: bad arguments");
-  if (N == 0) return 0;
   // wave-uniform scalars of dual_averaging.py:117-122, evaluated once on the host
   const float reg = (float)step + t0;
   const float inv_reg = 1.0f / reg;
@@ -188,7 +186,6 @@ int bjx_da_update(void* stream, int64_t N, int64_t step, float target, float t0,
 int bjx_exp(void* stream, int64_t N, const float* x, float* y) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && x && y, "bjx_exp: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_exp, dim3(flat_grid(N)), dim3(kBlock), 0, (hipStream_t)stream, N, x, y);
   return bjx_check_launch("bjx_exp");
 }
@@ -200,7 +197,6 @@ int bjx_welford_update_diag(void* stream, int64_t N, int64_t D, int64_t sample_s
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size_new >= 1 && value && mean_in && m2_in && mean_out &&
                     m2_out,
                 "bjx_welford_update_diag: bad arguments");
-  if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const float n = (float)sample_size_new;
   if (bjx_vec4_ok(D, value, mean_in, m2_in, mean_out, m2_out) && (D / 4) % 64 != 0) {
@@ -226,7 +222,6 @@ int bjx_welford_final_diag(void* stream, int64_t N, int64_t D, int64_t sample_si
                 "bjx_welford_final_diag: bad arguments");
   BJX_CHECK_ARG(imm_prev_stride == 0 || imm_prev_stride == D,
                 "bjx_welford_final_diag: imm_prev_stride must be 0 or D");
-  if (N == 0) return 0;
   // mass_matrix.py:339-343 scalars (fp32, as the reference evaluates them)
   const float denom = (float)(sample_size + 5) + imm_shrinkage_to_previous;
   const float beta_data = (float)sample_size / denom;

@@ -690,7 +690,6 @@ extern "C" {
 int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && A && B && C, "bjx_dense_matmul: bad arguments");
-  if (N == 0) return 0;
   GemmArgs ga{N, D, A, nullptr, 0, 0.0f, nullptr, nullptr, B, C, nullptr, nullptr};
   return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
 }
@@ -702,7 +701,6 @@ int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t c
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out,
                 "bjx_hmc_momentum_dense: bad arguments");
-  if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 rgrid(bjx_row_grid(N, kWavesPerBlock)), rblock(kBlock);
   hipLaunchKernelGGL(k_dense_z, rgrid, rblock, 0, s, Key{key0, key1}, chain_offset, step_fold, N, D,
@@ -725,7 +723,6 @@ int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float ep
                 "bjx_leapfrog_dense: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense: n_kicks must be 1 or 2");
   BJX_CHECK_ARG(p_out != p_in, "bjx_leapfrog_dense: p_out must not alias p_in");
-  if (N == 0) return 0;
   GemmArgs ga{N, D, p_in, g, n_kicks, eps, eps_per_chain, p_out, imm, nullptr, q_in, q_out};
   ga.b_symmetric = true;
   return launch_gemm((hipStream_t)stream, EPI_DRIFT, ga);
@@ -745,7 +742,6 @@ int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t cha
                     is_accepted_out && is_divergent_out && energy_out,
                 "bjx_hmc_finish_dense: bad arguments");
   BJX_CHECK_ARG(p1_work != p, "bjx_hmc_finish_dense: p1_work must not alias p");
-  if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   // closing half kick fused into the GEMM prologue: p1 = p + (eps/2) g1 ; v1 = imm p1
   GemmArgs ga{N, D, p, g1, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
@@ -764,7 +760,6 @@ int bjx_pc_matvec_t(void* stream, int64_t N, int64_t D, const float* M, int64_t 
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && M && x && y && (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_pc_matvec_t: bad arguments");
-  if (N == 0) return 0;
   PcArgs pa{N, D, M, matrix_stride, x, nullptr, 0, 0.0f, nullptr, nullptr, y, nullptr, nullptr};
   return launch_pc((hipStream_t)stream, EPI_STORE, pa);
 }
@@ -777,7 +772,6 @@ int bjx_hmc_momentum_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_
   BJX_CHECK_ARG(N >= 0 && D > 0 && mass_sqrt_t && imm && z_work && v_work && p_out && ke_out &&
                     (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_hmc_momentum_dense_pc: bad arguments");
-  if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 rgrid(bjx_row_grid(N, kWavesPerBlock)), rblock(kBlock);
   hipLaunchKernelGGL(k_dense_z, rgrid, rblock, 0, s, Key{key0, key1}, chain_offset, step_fold, N, D,
@@ -800,7 +794,6 @@ int bjx_leapfrog_dense_pc(void* stream, int64_t N, int64_t D, int n_kicks, float
                     (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_leapfrog_dense_pc: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense_pc: n_kicks must be 1 or 2");
-  if (N == 0) return 0;
   PcArgs pa{N, D, imm, matrix_stride, p_in, g, n_kicks, eps, eps_per_chain, p_out, nullptr, q_in, q_out};
   return launch_pc((hipStream_t)stream, EPI_DRIFT, pa);
 }
@@ -820,7 +813,6 @@ int bjx_hmc_finish_dense_pc(void* stream, uint32_t key0, uint32_t key1, int64_t 
                     is_accepted_out && is_divergent_out && energy_out &&
                     (matrix_stride == 0 || matrix_stride == D * D),
                 "bjx_hmc_finish_dense_pc: bad arguments");
-  if (N == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   PcArgs pa{N, D, imm, matrix_stride, p, g1, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
   if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;  // p1 = p + (eps/2) g1 ; v1 = imm p1
@@ -838,7 +830,6 @@ int bjx_welford_update_dense(void* stream, int64_t N, int64_t D, int64_t sample_
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size_new >= 1 && value && mean_in && m2_in && mean_out &&
                     m2_out,
                 "bjx_welford_update_dense: bad arguments");
-  if (N == 0) return 0;
   const size_t lds = (size_t)kWavesPerBlock * 2 * D * sizeof(float);
   BJX_CHECK_ARG(lds <= 64 * 1024, "bjx_welford_update_dense: D too large for the LDS staging buffer");
   hipLaunchKernelGGL(k_welford_update_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), lds,
@@ -853,7 +844,6 @@ int bjx_welford_final_dense(void* stream, int64_t N, int64_t D, int64_t sample_s
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && sample_size >= 0 && m2 && imm_prev && imm_out,
                 "bjx_welford_final_dense: bad arguments");
-  if (N == 0) return 0;
   const float denom = (float)(sample_size + 5) + imm_shrinkage_to_previous;
   const float beta_data = (float)sample_size / denom;
   const float beta_prev = imm_shrinkage_to_previous / denom;

@@ -612,7 +612,6 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
                     float* u_out) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && (N == 0 || u_out), "bjx_rng_uniform: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_rng_uniform, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, Key{key0, key1}, chain_offset, N, u_out);
   return bjx_check_launch("bjx_rng_uniform");
@@ -624,7 +623,6 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && imm && p_out && ke_out, "bjx_hmc_momentum_diag: bad arguments");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_momentum_diag: imm_stride must be 0 or D");
-  if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
   if (bjx_vec4_ok(D, imm, p_out) && D <= 128) {
@@ -657,7 +655,6 @@ int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, floa
                 "bjx_leapfrog_diag: bad arguments");
   BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_diag: n_kicks must be 1 or 2");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_leapfrog_diag: imm_stride must be 0 or D");
-  if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
 #define BJX_LF(V, K)                                                                          \
@@ -749,7 +746,6 @@ int bjx_keys_child(void* stream, int64_t N, const uint32_t* keys_in, uint32_t ch
                    uint32_t* keys_out) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && keys_in && keys_out, "bjx_keys_child: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_keys_child, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, keys_in, child, keys_out);
   return bjx_check_launch("bjx_keys_child");
@@ -759,7 +755,6 @@ int bjx_keys_randint(void* stream, int64_t N, const uint32_t* keys, int32_t minv
                      int32_t* out) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && keys && out, "bjx_keys_randint: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_keys_randint, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, keys, minval, maxval, out);
   return bjx_check_launch("bjx_keys_randint");
@@ -780,7 +775,6 @@ int bjx_hmc_finish_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                     is_divergent_out && energy_out,
                 "bjx_hmc_finish_diag: bad arguments");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_finish_diag: imm_stride must be 0 or D");
-  if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
   hipStream_t s = (hipStream_t)stream;
@@ -835,7 +829,6 @@ int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain
                     prop_g && prop_logp && prop_energy,
                 "bjx_mhmc_step_diag: bad arguments");
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_mhmc_step_diag: imm_stride must be 0 or D");
-  if (N == 0) return 0;
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
   hipStream_t s = (hipStream_t)stream;
@@ -860,7 +853,6 @@ int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_
                     sum_log_p_accept && prop_q && prop_p && prop_g && prop_logp && prop_energy &&
                     acceptance_rate_out,
                 "bjx_mhmc_finish: bad arguments");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(k_mhmc_finish, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, D, (float)num_integration_steps, q0, p0, g0, logp0, ke0,
                      ever_accepted, sum_log_p_accept, prop_q, prop_p, prop_g, prop_logp, prop_energy,

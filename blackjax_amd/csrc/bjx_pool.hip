@@ -481,14 +481,16 @@ __global__ __launch_bounds__(256) void k_pool_center(int64_t N, int64_t D, const
 
 __global__ void k_halton_steps(int64_t N, const int32_t* __restrict__ arg, int max_bits, float ja, float jb,
                                float num_leapfrog, int32_t* __restrict__ steps) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const uint32_t i = (uint32_t)arg[n] + 1u;
-  float h = 0.0f;
-  for (int k = 0; k < max_bits; ++k)
-    if ((i >> k) & 1u) h += ldexpf(0.5f, -k);  // exact: distinct powers of two, max_bits <= 24
-  const float jitter = h * ja + jb;
-  steps[n] = (int32_t)ceilf(jitter * num_leapfrog);
+  // grid-stride: flat_grid caps the launch at 65 536 workgroups (16.7 M chains per sweep)
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N;
+       n += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)arg[n] + 1u;
+    float h = 0.0f;
+    for (int k = 0; k < max_bits; ++k)
+      if ((i >> k) & 1u) h += ldexpf(0.5f, -k);  // exact: distinct powers of two, max_bits <= 24
+    const float jitter = h * ja + jb;
+    steps[n] = (int32_t)ceilf(jitter * num_leapfrog);
+  }
 }
 
 inline unsigned flat_grid(int64_t n, int block) {

@@ -17,7 +17,7 @@ from typing import Callable, NamedTuple
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
+from ._util import check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad
 from .base import SamplingAlgorithm
 from .random import key_spec
 
@@ -183,8 +183,9 @@ class _GraphedTrajectory:
     otherwise dominate once a block is small enough to live in the Infinity Cache.
     """
 
-    def __init__(self, n, D, L, vg, imm_per_chain, device):
+    def __init__(self, n, D, L, vg, imm_per_chain, device, owner=None):
         self.n, self.D, self.L = n, D, L
+        self.owner = owner  # the user's callable: held so that id(owner) in the graph key stays unique
         self.Wq = torch.empty((n, D), dtype=torch.float32, device=device)
         self.Wp = torch.empty((n, D), dtype=torch.float32, device=device)
         self.eps = torch.ones(n, dtype=torch.float32, device=device)
@@ -233,12 +234,14 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
 
     ``use_graph``: capture the per-block inner loop (the user's callable included) in a HIP
     graph (diagonal metric; the callable must be capturable: static shapes, no host sync).
-    ``"auto"`` (default): do so when a block is small enough for its launches to be bound by the
-    host's launch rate (at most 2^21 elements: a leapfrog launch is then under ~10 us of GPU work;
-    at 65 536 x 1 024 graphs measured no faster than plain launches), and fall back to plain
-    launches for a callable that cannot be recorded.  As under ``jax.jit`` in the reference, a
-    recorded callable is replayed as recorded: Python-side state it reads (a minibatch index, say)
-    is frozen at recording time -- pass ``use_graph=False`` for such a callable.
+    ``"auto"`` (default): do so for callables DECLARED recordable (``blackjax_amd.targets``, or any
+    callable passed through ``blackjax_amd.capturable``) when a block is small enough for its
+    launches to be bound by the host's launch rate (at most 2^21 elements: a leapfrog launch is
+    then under ~10 us of GPU work; at 65 536 x 1 024 graphs measured no faster than plain
+    launches), with a fall-back to plain launches if the recording fails; every other callable
+    is driven with plain launches.  ``True`` records whatever the callable is.  As under
+    ``jax.jit`` in the reference, a recorded callable is replayed as recorded: Python-side state
+    it reads (a minibatch index, say) is frozen at recording time.
     """
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
@@ -258,7 +261,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     if chain_block is None:
         chain_block = _default_chain_block()
     graphs: dict = {}
-    not_capturable: set = set()  # ids of callables whose capture failed once ("auto" mode)
+    not_capturable: dict = {}    # id -> callable whose capture failed once ("auto" mode; the
+    #                              reference keeps the id from being reused by another object)
     seen: dict = {}              # "auto" mode: calls per (shape, L, callable)
 
     def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
@@ -300,19 +304,22 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                   if metric.kind == "diag" else N)
         blk = N if not cb or cb >= N else int(cb)
         n_blocks = (N + blk - 1) // blk if N else 0
+        fn_id = id(logdensity_fn)  # graphs are keyed on the USER's callable (and hold it)
         if (use_graph == "auto" and L >= 2 and N > 0 and metric.kind == "diag" and not general
-                and blk * D <= (1 << 21) and id(vg) not in not_capturable):
-            gkey = (min(blk, N), D, L, id(vg), metric.imm_stride != 0, dev.index)
+                and blk * D <= (1 << 21) and is_capturable(logdensity_fn)
+                and fn_id not in not_capturable):
+            gkey = (min(blk, N), D, L, fn_id, metric.imm_stride != 0, dev.index)
             # record on the SECOND call with a given shape and trajectory length (a one-off call --
             # or a caller that varies L from step to step -- should not pay for a recording), and
             # keep at most 8 recordings per kernel
             seen[gkey] = seen.get(gkey, 0) + 1
             try:
                 if gkey not in graphs and seen[gkey] >= 2 and len(graphs) < 8:
-                    graphs[gkey] = _GraphedTrajectory(min(blk, N), D, L, vg, metric.imm_stride != 0, dev)
+                    graphs[gkey] = _GraphedTrajectory(min(blk, N), D, L, vg, metric.imm_stride != 0, dev,
+                                                      owner=logdensity_fn)
                 graphed = gkey in graphs
             except RuntimeError:  # the callable cannot be recorded (or is broken: the plain path re-raises)
-                not_capturable.add(id(vg))
+                not_capturable[fn_id] = logdensity_fn
                 torch.cuda.synchronize(dev)
         single = n_blocks <= 1 and not graphed
         # end-of-trajectory state (HMCInfo.proposal): per-block work buffers are copied out
@@ -346,10 +353,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 q, p, logp, g = q0[sl], p0[sl], logp0[sl], g0[sl]
                 eps_fin, eps_pc_fin = 0.0, None
             elif graphed:
-                gkey = (n, D, L, id(vg), m.imm_stride != 0, dev.index)
+                gkey = (n, D, L, fn_id, m.imm_stride != 0, dev.index)
                 ctx = graphs.get(gkey)
                 if ctx is None:
-                    ctx = graphs[gkey] = _GraphedTrajectory(n, D, L, vg, m.imm_stride != 0, dev)
+                    ctx = graphs[gkey] = _GraphedTrajectory(n, D, L, vg, m.imm_stride != 0, dev,
+                                                            owner=logdensity_fn)
                 if eb is None:
                     ctx.eps.fill_(eps)
                 else:

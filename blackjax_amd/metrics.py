@@ -35,6 +35,9 @@ def default_metric(inverse_mass_matrix, n_chains: int, dim: int, device) -> Metr
     if isinstance(inverse_mass_matrix, PerChainDiag):
         inverse_mass_matrix = inverse_mass_matrix.imm
         per_chain = True
+    if isinstance(inverse_mass_matrix, PerChainDiagTensor):  # what window_adaptation returns
+        inverse_mass_matrix = inverse_mass_matrix.as_subclass(torch.Tensor)
+        per_chain = True
     imm = torch.as_tensor(inverse_mass_matrix, dtype=torch.float32, device=device)
     if imm.ndim == 1:
         if imm.shape[0] != dim:
@@ -67,6 +70,20 @@ class PerChainDiag:
 
     def __init__(self, imm):
         self.imm = imm
+
+
+class PerChainDiagTensor(torch.Tensor):
+    """An ``(N, D)`` tensor TAGGED as "one inverse-mass diagonal per chain".  ``window_adaptation``
+    returns ``parameters["inverse_mass_matrix"]`` as this type, so the reference idiom
+    ``nuts(logdensity_fn, **parameters)`` round-trips unambiguously even when ``N == D`` (where a
+    plain square 2-d array means a dense matrix, metrics.py:180-218).  It is an ordinary tensor in
+    every other respect (indexing, ``.cpu()``, arithmetic keep working)."""
+
+    @staticmethod
+    def tag(imm: torch.Tensor) -> "PerChainDiagTensor":
+        if imm.ndim != 2:
+            raise ValueError(f"per-chain diagonals must be (N, D), got {tuple(imm.shape)}")
+        return imm.as_subclass(PerChainDiagTensor)
 
 
 def _dense_metric(imm: torch.Tensor) -> Metric:

@@ -30,7 +30,7 @@ from typing import Callable, NamedTuple, Optional
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
+from ._util import check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad
 from .base import SamplingAlgorithm
 from .hmc import HMCState, IntegratorState, init
 from .random import key_spec
@@ -90,8 +90,9 @@ class _GraphWorkspace:
     MAX_CHUNK = 16
     MIN_BUCKET = 256
 
-    def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device):
+    def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device, owner=None):
         self.N, self.D, self.max_depth, self.vg = N, D, max_depth, vg
+        self.owner = owner  # the user's callable: held so that id(owner) in the workspace key stays unique
         f32 = dict(dtype=torch.float32, device=device)
         self.bufs = {n: torch.empty((N, D), **f32) for n in _BUFS}
         self.ck_r = torch.empty((N, max(max_depth, 1), D), **f32)
@@ -163,9 +164,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                  recompact_every: int = 16, use_graph="auto", graph_sync_every: int = 4):
     """blackjax/mcmc/nuts.py:77-147.  ``use_graph``: ``True`` = the HIP-graph driver, ``False`` =
     plain launches (three per leaf from Python: host-bound once a leaf is a few microseconds of GPU
-    work), ``"auto"`` (default) = the graph driver unless the log-density callable turns out not to
-    be capturable (it synchronises with the host, say), in which case that callable is driven with
-    plain launches from then on.  As under ``jax.jit`` in the reference, a recorded callable is
+    work), ``"auto"`` (default) = the graph driver for callables DECLARED recordable
+    (``blackjax_amd.targets``, or anything passed through ``blackjax_amd.capturable``) -- with a
+    fall-back to plain launches should the recording fail -- and plain launches for every other
+    callable.  As under ``jax.jit`` in the reference, a recorded callable is
     replayed as recorded: Python-side state it reads is frozen at recording time (``use_graph=False``
     for such a callable).  ``graph_sync_every``: in graph mode the host reads the active-row
     count back only every that many 16-leapfrog chunks (to stop early / shrink the callable's
@@ -272,11 +274,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
          v0) = _common(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, chain_offset)
         max_depth = int(max_num_doublings)
         off = int(chain_offset)
-        wkey = (N, D, max_depth, id(vg), metric.kind, tuple(metric.imm.shape), q0.device.index)
+        wkey = (N, D, max_depth, id(logdensity_fn), metric.kind, tuple(metric.imm.shape), q0.device.index)
         ws = workspaces.get(wkey)
         if ws is None:
             ws = workspaces[wkey] = _GraphWorkspace(N, D, max_depth, vg, tuple(metric.imm.shape),
-                                                    metric.kind, thr, q0.device)
+                                                    metric.kind, thr, q0.device, owner=logdensity_fn)
         if eps_pc is None:
             ws.eps.fill_(eps)
         else:
@@ -318,11 +320,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             _lib.call("bjx_nuts_merge", stream, dref, depth, n_doubling, idx_doubling.data_ptr())
         return _make_info(p0, ws.bufs, ws.fs, ws.is_, clone=True)
 
-    not_capturable: set = set()  # ids of callables whose capture failed once
+    not_capturable: dict = {}  # id -> callable whose capture failed once (the reference pins the id)
 
     def kernel_auto(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
                     inverse_mass_matrix, max_num_doublings: int = 10, *, chain_offset: int = 0):
-        if id(logdensity_fn) not in not_capturable and state.position.shape[0] > 0:
+        if (is_capturable(logdensity_fn) and id(logdensity_fn) not in not_capturable
+                and state.position.shape[0] > 0):
             try:
                 return kernel_graph(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                                     max_num_doublings, chain_offset=chain_offset)
@@ -330,7 +333,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                 # recording the callable failed (or the callable itself is broken, in which case the
                 # plain driver below raises the same error again); the transition restarts from
                 # `state`, which the graph driver never modifies
-                not_capturable.add(id(logdensity_fn))
+                not_capturable[id(logdensity_fn)] = logdensity_fn
                 torch.cuda.synchronize(state.position.device)
         return kernel_eager(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                             max_num_doublings, chain_offset=chain_offset)
@@ -507,7 +510,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
     graph = None  # (CUDAGraph, static logp_f, static gf) for the current batch
-    graph_ok = use_graph is not False
+    graph_ok = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
     eager_chunks = 0  # plain chunks since the batch last changed (they warm kernels and allocator)
     ticks_left = max_ticks
     while ticks_left > 0:

@@ -1,0 +1,100 @@
+"""bench.py's launcher and multi-rank control flow (`--gpus N` must really run N ranks
+or fail loudly).  CPU part: the refusal, the torchrun-environment check and a 2-rank gloo run of the
+whole control flow (spawn -> rendezvous -> barriers -> max-over-ranks timing -> gather -> one JSON
+line) with a sleep in place of the GPU step.  GPU part: the real bench on tiny shapes, one rank and
+two gloo ranks sharing cuda:0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_refuses_instead_of_running_fewer_ranks():
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    r = _run(["--gpus", str(max(n, 2))])
+    assert r.returncode != 0
+    assert "refusing to run" in r.stderr and "{" not in r.stdout
+
+
+def test_gpus_flag_must_match_the_torchrun_world():
+    r = _run(["--gpus", "2", "--selftest-control-flow"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_two_rank_control_flow_over_gloo():
+    r = _run(["--gpus", "2", "--selftest-control-flow", "--steps", "4", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] is None and "NOT a measurement" in j["metric"]
+    assert [x["rank"] for x in j["ranks_seen"]] == [0, 1]
+    assert len({x["pid"] for x in j["ranks_seen"]}) == 2  # two processes
+    assert len(j["per_rank_ms_per_step"]) == 2
+    assert abs(j["ms_per_step"] - max(j["per_rank_ms_per_step"])) < 1e-9  # max over ranks
+    assert j["ms_per_step"] >= 4.0  # rank 1 sleeps 4 ms per step: the slowest rank sets the time
+    assert j["gathered_rows"] == [4, 3] and j["backend"] == "gloo"
+
+
+TINY = ["--chains", "4096", "--dim", "256", "--leapfrogs", "6", "--steps", "4", "--warmup", "1"]
+
+
+@pytest.mark.gpu
+def test_bench_c2_tiny_single_rank_json_contract():
+    r = _run(TINY)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["chains_per_launch"] == 4096 and "streaming" in roof["mode"]
+    assert roof["traffic_source"] is None or "NOT measured in this run" in roof["traffic_source"]
+    assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["value"] > 0
+    tc = j["torch_callable_mode"]
+    assert tc["value"] > 0 and "autograd" in tc["logdensity"]
+    assert j["ess"] is not None and j["ess_nonresonant"]["eps"] == 0.21
+    assert 0.3 < j["mean_acceptance"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_two_gloo_ranks_share_one_gpu():
+    """The real bench under its own launcher with 2 ranks (gloo, both on cuda:0 of a 1-GPU box):
+    n_gpus = 2, twice the chains, both ranks seen."""
+    r = _run(["--gpus", "2", "--no-cpu-baseline"] + TINY, {"BJX_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["global_chains"] == 8192
+    assert [x["rank"] for x in j["ranks_seen"]] == [0, 1] and len(j["per_rank_ms_per_step"]) == 2
+    assert j["final_draws_gathered"] == [512, 256]
+    assert "cpu_baseline" not in j
+
+
+@pytest.mark.gpu
+def test_bench_c4_tiny():
+    r = _run(["--config", "c4", "--chains", "1024", "--dim", "512", "--leapfrogs", "5", "--steps", "24",
+              "--warmup", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert "window_adaptation" in j["metric"] and j["config"]["workload"].startswith("C4")
+    assert j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] == 24.0 * 512 * 1024

@@ -115,7 +115,8 @@ def test_c3_full_shape_nuts_subset_vs_numpy(dev):
     keys = prng.split(run_key, T)
     final, positions, rinfo = alg.run(run_key, st0, T)  # free-running chains, step-major keys
     total_leaves = rinfo.num_integration_steps.sum(0)
-    deepest = t2n(torch.topk(total_leaves, 8).indices)
+    deepest = np.concatenate([t2n(torch.topk(total_leaves, 8).indices),
+                              t2n(torch.topk(rinfo.num_integration_steps.max(0).values, 8).indices)])
     idx = np.unique(np.concatenate([spread_indices(N, (16384, 8192), 50, seed=6), deepest]))
     assert len(idx) >= 64
     st_s = ohmc.init(q0[idx], fn_o)

@@ -361,8 +361,10 @@ def test_full_size_leapfrog_reversibility_and_energy(dev):
 
 
 def test_hmc_default_driver_graph_and_fallback(dev):
-    """use_graph="auto" (default): small blocks are driven through a HIP graph of the inner loop, a
-    callable that synchronises with the host falls back to plain launches -- same results."""
+    """use_graph="auto" (default): for a callable declared recordable (blackjax_amd.capturable) small
+    blocks are driven through a HIP graph of the inner loop; a callable that then turns out to
+    synchronise with the host falls back to plain launches; an undeclared callable is never
+    recorded -- same results in all cases."""
     N, D, L = 200, 16, 7
     g_ = torch.Generator(device=dev)
     g_.manual_seed(9)
@@ -381,7 +383,10 @@ def test_hmc_default_driver_graph_and_fallback(dev):
     ref = bjx.hmc(plain, 0.2, imm, L, use_graph=False)
     st = ref.init(q0)
     keys = prng.split(prng.key(6), 3)
-    for fn in (plain, syncing):
+    def undeclared(q):
+        return -0.5 * (q * q * iv).sum(-1)
+
+    for fn in (bjx.capturable(plain), bjx.capturable(syncing), undeclared):
         alg = bjx.hmc(fn, 0.2, imm, L)  # default driver
         s_r, s_a = st, st
         for k in keys:

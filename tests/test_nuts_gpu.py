@@ -151,8 +151,9 @@ def test_nuts_dense_metric_parity(dev, per_chain, use_graph):
 
 
 def test_nuts_default_driver_falls_back_for_a_syncing_callable(dev):
-    """use_graph="auto" (default): an autograd callable is driven through HIP graphs, a callable that
-    synchronises with the host cannot be recorded and is driven with plain launches -- same draws."""
+    """use_graph="auto" (default): an autograd callable declared recordable (blackjax_amd.capturable)
+    is driven through HIP graphs; one that then synchronises with the host cannot be recorded and
+    falls back to plain launches; an undeclared callable is never recorded -- same draws."""
     N, D = 96, 12
     g = torch.Generator(device=dev)
     g.manual_seed(2)
@@ -171,7 +172,10 @@ def test_nuts_default_driver_falls_back_for_a_syncing_callable(dev):
     ref = bjx.nuts(plain, 0.3, torch.ones(D, device=dev), max_num_doublings=5, use_graph=False)
     st = ref.init(q0)
     keys = prng.split(prng.key(4), 3)
-    for fn in (plain, syncing):
+    def undeclared(q):
+        return -0.5 * (q * q * iv).sum(-1)
+
+    for fn in (bjx.capturable(plain), bjx.capturable(syncing), undeclared):
         alg = bjx.nuts(fn, 0.3, torch.ones(D, device=dev), max_num_doublings=5)  # default driver
         s_r, s_a = st, st
         for k in keys:

@@ -4,7 +4,7 @@ evidence under profiles/: the rocprofv3 kernel-stats summary, the PMC traffic of
 (FETCH_SIZE and WRITE_SIZE from SEPARATE --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
 prescribes for gfx950) and the default bench line.
 
-usage: python tools/collect_profiles.py <tag>      e.g. v4  -> profiles/r01/bench_c2_*_v4.*
+usage: python tools/collect_profiles.py <tag> [round]      e.g. v1 r02 -> profiles/r02/bench_c2_*_v1.*
 """
 import csv
 import glob
@@ -36,39 +36,48 @@ def counter_avg(sub, counter):
 def main():
     global KERNEL
     tag = sys.argv[1]
-    out_dir = os.path.join(ROOT, "profiles", "r01")
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+    out_dir = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(out_dir, exist_ok=True)
     bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(out_dir, f"bench_c2_default_{tag}.json"), "w"), indent=1)
-    if bench.get("roofline"):
-        KERNEL = bench["roofline"]["kernel"]
-    stats = max(glob.glob(os.path.join(SRC, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)  # newest run
-    shutil.copy(stats, os.path.join(out_dir, f"bench_c2_kernel_stats_{tag}.csv"))
+    roof = bench["roofline"]
+    KERNEL = roof["kernel"]
+    cfg = bench["config"]
+    N = cfg["chains_per_gpu"]
+    stats = {}
+    for mode in ("stream", "cache"):
+        found = glob.glob(os.path.join(SRC, f"kt_{mode}", "*", "*kernel_stats.csv"))
+        if not found:
+            continue
+        f = max(found, key=os.path.getmtime)  # newest run
+        shutil.copy(f, os.path.join(out_dir, f"bench_c2_kernel_stats_{mode}_{tag}.csv"))
+        for r in csv.DictReader(open(f)):
+            if is_kernel(r["Name"]):
+                stats[mode] = {"avg_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"])}
+    # PMC passes were taken in the streaming mode: all chains per launch
     fetch_kb, n_f, grid_f = counter_avg("fetch", "FETCH_SIZE")
     write_kb, n_w, grid_w = counter_avg("write", "WRITE_SIZE")
-    cfg = bench["config"]
-    cpl = bench["roofline"]["chains_per_launch"] if bench.get("roofline") else cfg["chain_block"]
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-    alg = 20.0 * cfg["dim"] * cpl
+    alg = 20.0 * cfg["dim"] * N
     pmc = {
-        "chains": cfg["chains_per_gpu"], "dim": cfg["dim"], "chains_per_launch": cpl,
+        "chains": N, "dim": cfg["dim"], "chains_per_launch": N,
         "kernel": KERNEL, "fetch_size_KB_raw": fetch_kb, "write_size_KB_raw": write_kb,
         "launches": {"fetch_pass": n_f, "write_pass": n_w, "grid_sizes": sorted(set(grid_f + grid_w))},
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for wide coalesced reads, "
                       "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; separate --pmc passes",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": hbm / alg,
-        "note": "FETCH_SIZE/WRITE_SIZE are taken at the L2 memory-side interface and include Infinity-Cache "
-                "hits (MI355X_MICROARCH.md HBM section): they bound wasted re-reads, they do not separate "
-                "Infinity-Cache hits from HBM accesses",
-        "source": f"profiles/r01/bench_c2_pmc_{tag}.json",
+        "note": "streaming mode (all chains per launch, 1.34 GB per launch >> the 256 MiB Infinity Cache); "
+                "FETCH_SIZE/WRITE_SIZE are taken at the L2 memory-side interface",
+        "rocprofv3_kernel_trace": stats,
+        "bench_hip_events": {"stream_avg_us": roof.get("avg_launch_us"),
+                             "cache_avg_us": (roof.get("cache_assisted") or {}).get("avg_launch_us")},
+        "source": f"profiles/{rnd}/bench_c2_pmc_{tag}.json",
     }
     json.dump(pmc, open(os.path.join(out_dir, f"bench_c2_pmc_{tag}.json"), "w"), indent=1)
     json.dump(pmc, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
-    # kernel-trace average of the dominant kernel, to set beside the bench's HIP-event figure
-    for r in csv.DictReader(open(stats)):
-        if is_kernel(r["Name"]):
-            print("rocprofv3 avg us:", float(r["AverageNs"]) / 1e3, "calls", r["Calls"])
-    print("bench avg us:", bench["roofline"]["avg_launch_us"], "value M/s:", bench["value"] / 1e6)
+    print("rocprofv3 kernel-trace:", stats)
+    print("bench HIP events:", pmc["bench_hip_events"], "value M/s:", bench["value"] / 1e6)
     print("traffic ratio:", pmc["ratio"])
 
 
