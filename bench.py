@@ -100,9 +100,9 @@ def cpu_baseline_port(D, L, eps, target_seconds):
 def cpu_baseline_jax(D, L, eps, target_seconds):
     """BlackJAX itself on JAX-CPU: jit(scan(vmap(kernel.step))) -- only when both import here."""
     os.environ.setdefault("JAX_PLATFORMS", "cpu")
-    import blackjax  # noqa: F401  (ImportError -> the caller falls back to the port)
-    import jax
+    import jax  # ImportError -> the caller falls back to the port and reports why
     import jax.numpy as jnp
+    import blackjax
 
     sig = jnp.asarray(sigma_ladder(D))
     imm = sig * sig
