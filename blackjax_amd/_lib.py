@@ -108,8 +108,9 @@ NUTS_F = {"H0": 0, "LLOGP": 1, "RLOGP": 2, "PLOGP": 3, "PENERGY": 4, "PW": 5, "P
           "SLOGP": 7, "SENERGY": 8, "SW": 9, "SSLPA": 10, "ACC": 11}
 NUTS_NF = 12
 NUTS_I = {"ACTIVE": 0, "SUB_ACTIVE": 1, "DIR": 2, "NSTATES": 3, "SUBN": 4, "SDIV": 5, "STURN": 6,
-          "DIV": 7, "TURN": 8, "DEPTH": 9, "KT": 10, "KTB": 11, "KP": 12, "KPB": 13, "IK": 14, "IKB": 15}
-NUTS_NI = 16
+          "DIV": 7, "TURN": 8, "DEPTH": 9, "KT": 10, "KTB": 11, "KP": 12, "KPB": 13, "IK": 14, "IKB": 15,
+          "LAZY": 16}
+NUTS_NI = 17
 
 SIGNATURES.update({
     "bjx_nuts_init": [c_void_p, POINTER(NutsDesc), _f32p, _f32p],
@@ -143,6 +144,7 @@ class NutsAsync(ctypes.Structure):
         ("adapt_log_x", c_void_p), ("adapt_log_x_avg", c_void_p), ("adapt_avg_err", c_void_p),
         ("adapt_mu", c_void_p), ("adapt_step_size", c_void_p), ("adapt_mean", c_void_p),
         ("adapt_m2", c_void_p), ("adapt_imm", c_void_p), ("out_step_size", c_void_p),
+        ("rec", c_void_p), ("front_p", c_void_p), ("end_list", c_void_p), ("end_count", c_void_p),
     ]
 
 
@@ -150,6 +152,7 @@ class NutsAsync(ctypes.Structure):
 NUTS_AT = {"FLAGS": 0, "DA_REG": 1, "DA_INV_REG": 2, "DA_ETA": 3, "DA_COEF": 4, "WEL_N": 5,
            "FIN_NM1": 6, "FIN_BETA_DATA": 7, "FIN_BETA_PREV": 8, "FIN_REG": 9}
 NUTS_ADAPT_COLS = 12
+NUTS_REC_WORDS = 32  # BJX_NUTS_REC_WORDS: packed per-chain record of the low-traffic tick kernels
 
 
 SIGNATURES.update({

@@ -1059,6 +1059,563 @@ k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
   });
 }
 
+// ------------------------------------------------------------------------------------ free-running chains, v2
+// The same schedule with the data movement and the dependent round trips cut to what the algorithm
+// needs (diagonal metric, 16-byte rows, D <= 256 * NI; needs bjx_nuts_async_t.rec / front_p).
+// A tick kernel's duration is (chains / resident waves) x (lifetime of a wave), and a wave's
+// lifetime is its chain of DEPENDENT memory round trips; the kernels above need 4-6 per leaf
+// (row list -> phase -> slot tables -> rows -> checkpoint rows -> merge rows ...).  Here:
+//  * every per-chain scalar a leaf needs sits in ONE 128-byte record rec[c] (the slot tables spread
+//    them over 25 cache lines), loaded by one wave instruction and broadcast with readlane;
+//  * while a subtree integrates, the moving end's position lives in the callable's row qf[b], its
+//    momentum in front_p[c] and its gradient in registers only -- all direction independent, so
+//    the record, the phase and ALL rows of a leaf are requested in the first round trip; the second
+//    one (checkpoint rows of an odd leaf, the two merge rows of a subtree's last leaf) is issued as
+//    soon as the record has arrived and overlaps the leaf's arithmetic;
+//  * the end arrays (Lq/Lp/Lg, Rq/Rp/Rg) are written only when a doubling LEAVES that end: a leaf no
+//    longer writes the end position and gradient (nor reads the position twice -- fq and qf[b] held
+//    the same values), and continuing a trajectory in the same direction moves no extra row;
+//  * a leaf that completes a subtree merges it at once and opens the next doubling (no second
+//    kernel visit with five row loads);
+//  * a transition starts lazily: "this end / the proposal / the momentum sum is still the initial
+//    state" is a bit of the record and those rows are read from q0 / p0 / g0 while it is set,
+//    instead of nine row copies per transition (nuts.py:278-291 builds the tree from z0).
+// Arithmetic, keys and decisions are those of the functions above, expression for expression; the
+// per-transition records are identical (tests/test_nuts_free_gpu.py, test_full_shape_gpu.py).
+// The trajectory-end states are NOT kept after a transition ends (run_free does not expose them).
+enum { LZ_L = 1, LZ_R = 2, LZ_P = 4, LZ_M = 8 };
+// words of rec[c] (BJX_NUTS_REC_WORDS = 32 per chain)
+enum {
+  RW_H0 = 0, RW_SW, RW_SSLPA, RW_SLOGP, RW_SENERGY, RW_PW, RW_PSLPA, RW_PLOGP, RW_PENERGY, RW_ACC,
+  RW_DEPTH, RW_SUBN, RW_DIR, RW_LAZY, RW_NSTATES, RW_KT, RW_KTB, RW_KP, RW_KPB, RW_IK, RW_IKB,
+  RW_DIV, RW_TURN, RW_EPS
+};
+static_assert(RW_EPS < BJX_NUTS_REC_WORDS, "record layout");
+
+__device__ __forceinline__ int rec_i(int w, int k) { return __builtin_amdgcn_readlane(w, k); }
+__device__ __forceinline__ float rec_f(int w, int k) { return __int_as_float(__builtin_amdgcn_readlane(w, k)); }
+// lane k of the wave-wide record register takes the (wave-uniform) value v
+__device__ __forceinline__ void rec_set_i(int& w, int k, int v) { if ((int)(threadIdx.x & 63) == k) w = v; }
+__device__ __forceinline__ void rec_set_f(int& w, int k, float v) { rec_set_i(w, k, __float_as_int(v)); }
+
+// Direction and keys of doubling `depth` (trajectory.py:645-650) into the record register.
+__device__ __forceinline__ int begin_doubling_rec(int& w, Key ik, int32_t depth) {
+  const Key subkey = key_child(ik, (uint64_t)depth);
+  const int dir = key_uniform(key_child(subkey, 0)) < 0.5f ? 1 : -1;
+  const Key kt = key_child(subkey, 1), kp = key_child(subkey, 2);
+  rec_set_i(w, RW_KT, (int)kt.k0);
+  rec_set_i(w, RW_KTB, (int)kt.k1);
+  rec_set_i(w, RW_KP, (int)kp.k0);
+  rec_set_i(w, RW_KPB, (int)kp.k1);
+  rec_set_i(w, RW_DIR, dir);
+  rec_set_i(w, RW_SUBN, 0);
+  return dir;
+}
+
+template <int NI>
+struct LeafRows {  // requested before the chain's phase and record are known (direction independent)
+  Row<4> G[NI], M[NI], P[NI], S[NI], X[NI];
+};
+
+// One leaf of chain c (phase 1), record register `w` and rows already requested.  Returns 0 = a
+// leaf is in flight again (phase stays 1), 1 = the transition is complete (phase 3 written;
+// async_end2_chain finishes it).
+template <int NI>
+__device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+                                                 float lp, int64_t c, int64_t b, int& w, LeafRows<NI>& R) {
+  constexpr int VEC = 4;
+  const int lane = threadIdx.x & 63;
+  const int32_t depth = rec_i(w, RW_DEPTH);
+  const int32_t s = rec_i(w, RW_SUBN);  // states already in the subtree = index of this leaf
+  const int dir = rec_i(w, RW_DIR);
+  int lazy = rec_i(w, RW_LAZY);
+  const float eps = rec_f(w, RW_EPS);
+  const float deps = (float)dir * eps;
+  const float h = deps * 0.5f;
+  const int64_t base = c * nt.D;
+  float* fpp = ax.front_p + base;
+  float* qn = qf + b * nt.D;
+  float* sm = nt.Smsum + base;
+  const float H0 = rec_f(w, RW_H0), sw = rec_f(w, RW_SW), sslpa = rec_f(w, RW_SSLPA);
+  const bool last = (s + 1) >= (1 << depth);
+  const uint32_t us = (uint32_t)s;  // checkpoint indices (termination.py:75-84)
+  const int idx_max = __popc(us >> 1);
+  const int nsub = __popc((~us & (us + 1u)) - 1u);
+  const int idx_min = idx_max - nsub + 1;
+  const bool even = (us & 1u) == 0u;
+
+  int64_t j0[NI];
+  bool ok[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    j0[k] = ((int64_t)lane + 64 * k) * VEC;
+    ok[k] = j0[k] < nt.D;
+  }
+  // second round trip, issued now: first checkpoint level of an odd leaf, merge rows of a last leaf
+  const int other_bit = dir > 0 ? LZ_L : LZ_R;
+  const float* op = ((lazy & other_bit) ? nt.p0 : (dir > 0 ? nt.Lp : nt.Rp)) + base;
+  const float* ms_src = ((lazy & LZ_M) ? nt.p0 : nt.msum) + base;
+  Row<VEC> C0[NI], C1[NI], MS[NI], OP[NI];
+  if (nsub > 0) {
+    const float* r_ck = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+    const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        C0[k] = ldr<VEC>(r_ck + j0[k]);
+        C1[k] = ldr<VEC>(rs_ck + j0[k]);
+      }
+  }
+  if (last) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        MS[k] = ldr<VEC>(ms_src + j0[k]);
+        OP[k] = ldr<VEC>(op + j0[k]);
+      }
+  }
+
+  // pass 1: closing half kick, kinetic energy
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
+        acc += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)R.P[k].v[e];
+      }
+    }
+  acc = wave_sum(acc);
+  const float ke = 0.5f * (float)acc;
+  const float e_new = -lp + ke;  // hmc_energy (trajectory.py:745-748)
+  float wgt = H0 - e_new;        // proposal.py:91-95
+  if (wgt != wgt) wgt = -__builtin_inff();
+  const float slpa_new = fminf(wgt, 0.0f);
+  const bool sdiv = (-wgt) > nt.divergence_threshold;  // trajectory.py:325
+  bool take;
+  float Wn, Sn;
+  if (s == 0) {
+    take = true;
+    Wn = wgt;
+    Sn = slpa_new;
+  } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
+    const Key kt{(uint32_t)rec_i(w, RW_KT), (uint32_t)rec_i(w, RW_KTB)};
+    const float u = key_uniform(key_child(kt, (uint64_t)(uint32_t)s));  // fold_in(kt, s)
+    const Scalars3 sc = scalars3(-(double)(wgt - sw), sw, wgt, sslpa, slpa_new);
+    take = u < sc.r0;
+    Wn = sc.lae1;
+    Sn = sc.lae2;
+  }
+
+  // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      if (s != 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) R.S[k].v[e] = R.S[k].v[e] + R.P[k].v[e];
+      } else {
+        R.S[k] = R.P[k];
+      }
+      // checkpoints are read by later leaves of the same subtree only: none follow the last leaf
+      // or a divergence (even leaves run no U-turn check, so `sdiv` is all that can stop them)
+      if (even && !last && !sdiv) {
+        str<VEC>(nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.P[k]);
+        str<VEC>(nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.S[k]);
+      }
+      if (take) {
+        str<VEC>(nt.Sq + base + j0[k], R.X[k]);
+        str<VEC>(nt.Sg + base + j0[k], R.G[k]);
+      }
+    }
+
+  // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104); the
+  // rows of level i - 1 are requested before the reduction of level i
+  bool turning = false;
+  for (int i = idx_max; i >= idx_min && !turning; --i) {
+    Row<VEC> N0[NI], N1[NI];
+    if (i > idx_min) {
+      const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i - 1) * nt.D;
+      const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i - 1) * nt.D;
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          N0[k] = ldr<VEC>(r_ck + j0[k]);
+          N1[k] = ldr<VEC>(rs_ck + j0[k]);
+        }
+    }
+    double a_left = 0.0, a_right = 0.0;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float rl = C0[k].v[e];
+          const float ssum = (R.S[k].v[e] - C1[k].v[e]) + rl;
+          const float rho = ssum - (R.P[k].v[e] + rl) * 0.5f;  // metrics.py:300
+          a_left += (double)(R.M[k].v[e] * rl) * (double)rho;
+          a_right += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)rho;
+        }
+      }
+    a_left = wave_sum(a_left);
+    a_right = wave_sum(a_right);
+    turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+    if (i > idx_min) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        C0[k] = N0[k];
+        C1[k] = N1[k];
+      }
+    }
+  }
+  const bool stop = sdiv || turning;
+  if (!(stop || last)) {  // the subtree keeps integrating: opening half of leaf s + 1
+    rec_set_f(w, RW_SW, Wn);
+    rec_set_f(w, RW_SSLPA, Sn);
+    if (take) {
+      rec_set_f(w, RW_SLOGP, lp);
+      rec_set_f(w, RW_SENERGY, e_new);
+    }
+    rec_set_i(w, RW_SUBN, s + 1);
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
+          R.X[k].v[e] = fmaf(deps, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+        }
+        str<VEC>(fpp + j0[k], R.P[k]);
+        str<VEC>(qn + j0[k], R.X[k]);
+        str<VEC>(sm + j0[k], R.S[k]);  // the subtree's momentum sum is only stored while it keeps growing
+      }
+    return 0;
+  }
+
+  // ---- the subtree is complete: merge it (trajectory.py:680-727, proposal.py:146-176)
+  if (!last) {  // stopped early: the merge rows were not requested above
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        MS[k] = ldr<VEC>(ms_src + j0[k]);
+        OP[k] = ldr<VEC>(op + j0[k]);
+      }
+  }
+  const float pw = rec_f(w, RW_PW), pslpa = rec_f(w, RW_PSLPA);
+  bool take_m = false;
+  float new_pw = pw;
+  const Scalars3 scm = scalars3((double)(Wn - pw), pslpa, Sn, pw, Wn);
+  const float new_pslpa = scm.lae1;
+  if (!stop) {  // progressive_biased_sampling
+    const Key kp{(uint32_t)rec_i(w, RW_KP), (uint32_t)rec_i(w, RW_KPB)};
+    take_m = key_uniform(kp) < min1_nan(scm.e0);
+    new_pw = scm.lae2;
+  }
+  // merged momentum sum + U-turn of the whole trajectory
+  double a_left = 0.0, a_right = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float pl = dir > 0 ? OP[k].v[e] : R.P[k].v[e];
+        const float pr = dir > 0 ? R.P[k].v[e] : OP[k].v[e];
+        MS[k].v[e] = MS[k].v[e] + R.S[k].v[e];
+        const float rho = MS[k].v[e] - (pr + pl) * 0.5f;
+        a_left += (double)(R.M[k].v[e] * pl) * (double)rho;
+        a_right += (double)(R.M[k].v[e] * pr) * (double)rho;
+      }
+      str<VEC>(nt.msum + base + j0[k], MS[k]);
+      if (take_m) {
+        // the subtree's proposal: this leaf's state when the leaf itself was taken, else rows an
+        // earlier leaf of the subtree stored
+        str<VEC>(nt.Pq + base + j0[k], take ? R.X[k] : ldr<VEC>(nt.Sq + base + j0[k]));
+        str<VEC>(nt.Pg + base + j0[k], take ? R.G[k] : ldr<VEC>(nt.Sg + base + j0[k]));
+      }
+    }
+  lazy &= ~LZ_M;
+  if (take_m) lazy &= ~LZ_P;
+  a_left = wave_sum(a_left);
+  a_right = wave_sum(a_right);
+  const bool turn = turning || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+  const bool grow = !sdiv && !turn && depth + 1 < nt.max_depth;
+  const int n = rec_i(w, RW_NSTATES) + s + 1;
+  rec_set_f(w, RW_PW, new_pw);
+  rec_set_f(w, RW_PSLPA, new_pslpa);
+  if (take_m) {
+    rec_set_f(w, RW_PLOGP, take ? lp : rec_f(w, RW_SLOGP));
+    rec_set_f(w, RW_PENERGY, take ? e_new : rec_f(w, RW_SENERGY));
+  }
+  rec_set_f(w, RW_ACC, exp_cr(new_pslpa) / (float)n);  // nuts.py:303-305
+  rec_set_i(w, RW_NSTATES, n);
+  rec_set_i(w, RW_DIV, sdiv ? 1 : 0);
+  rec_set_i(w, RW_TURN, turn ? 1 : 0);
+  rec_set_i(w, RW_DEPTH, depth + 1);
+  if (!grow) {  // the transition is complete
+    rec_set_i(w, RW_LAZY, lazy);
+    if (lane == 0) ax.phase[c] = 3;
+    return 1;
+  }
+  // ---- next doubling (trajectory.py:645-670)
+  const Key ik{(uint32_t)rec_i(w, RW_IK), (uint32_t)rec_i(w, RW_IKB)};
+  const int dir2 = begin_doubling_rec(w, ik, depth + 1);
+  const float deps2 = (float)dir2 * eps;
+  const float h2 = deps2 * 0.5f;
+  if (dir2 == dir) {  // the end just reached keeps moving: its state is in registers
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          R.P[k].v[e] = fmaf(h2, R.G[k].v[e], R.P[k].v[e]);
+          R.X[k].v[e] = fmaf(deps2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+        }
+        str<VEC>(fpp + j0[k], R.P[k]);
+        str<VEC>(qn + j0[k], R.X[k]);
+      }
+  } else {  // park this end in its arrays, continue from the other one
+    float* eq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+    float* eg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+    float* ep = (dir > 0 ? nt.Rp : nt.Lp) + base;
+    const bool z0 = (lazy & other_bit) != 0;
+    const float* oq = (z0 ? nt.q0 : (dir2 > 0 ? nt.Rq : nt.Lq)) + base;
+    const float* og = (z0 ? nt.g0 : (dir2 > 0 ? nt.Rg : nt.Lg)) + base;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        str<VEC>(eq + j0[k], R.X[k]);
+        str<VEC>(eg + j0[k], R.G[k]);
+        str<VEC>(ep + j0[k], R.P[k]);
+        const Row<VEC> g2 = ldr<VEC>(og + j0[k]);
+        Row<VEC> q2 = ldr<VEC>(oq + j0[k]);
+        Row<VEC> p2 = OP[k];  // the other end's momentum was loaded for the merge
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          p2.v[e] = fmaf(h2, g2.v[e], p2.v[e]);
+          q2.v[e] = fmaf(deps2, R.M[k].v[e] * p2.v[e], q2.v[e]);
+        }
+        str<VEC>(fpp + j0[k], p2);
+        str<VEC>(qn + j0[k], q2);
+      }
+    lazy &= ~other_bit;
+  }
+  rec_set_i(w, RW_LAZY, lazy);
+  return 0;
+}
+
+// End of a transition (phase 3) and start of the next one (phase 0 / after phase 3): record, accept,
+// adapt, momentum draw, lazy tree start, doubling 0, opening half of its first leaf.
+template <int NI>
+__device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+                                                 int64_t c, int64_t b, int phase, int& w) {
+  constexpr int VEC = 4;
+  const int lane = threadIdx.x & 63;
+  int32_t t = ax.t[c];
+  const int64_t base = c * nt.D;
+  float* qrow = qf + b * nt.D;
+  int64_t j0[NI];
+  bool ok[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    j0[k] = ((int64_t)lane + 64 * k) * VEC;
+    ok[k] = j0[k] < nt.D;
+  }
+  Row<VEC> Q[NI], G[NI];
+  float lp;
+  if (phase == 3) {
+    // transition t is complete: the proposal becomes the chain's state unless it still IS the state
+    const bool same = (rec_i(w, RW_LAZY) & LZ_P) != 0;
+    const int64_t row = (int64_t)t * nt.N + c;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        Q[k] = ldr<VEC>((same ? ax.q : nt.Pq) + base + j0[k]);
+        G[k] = ldr<VEC>((same ? ax.g : nt.Pg) + base + j0[k]);
+        if (!same) {
+          str<VEC>(ax.q + base + j0[k], Q[k]);
+          str<VEC>(ax.g + base + j0[k], G[k]);
+        }
+        if (ax.out_position) str<VEC>(ax.out_position + row * nt.D + j0[k], Q[k]);
+      }
+    lp = rec_f(w, RW_PLOGP);
+    const float acc_rate = rec_f(w, RW_ACC);
+    if (lane == 0) {
+      ax.logp[c] = lp;
+      if (ax.out_logdensity) ax.out_logdensity[row] = lp;
+      if (ax.out_acceptance_rate) ax.out_acceptance_rate[row] = acc_rate;
+      if (ax.out_energy) ax.out_energy[row] = rec_f(w, RW_PENERGY);
+      if (ax.out_num_integration_steps) ax.out_num_integration_steps[row] = rec_i(w, RW_NSTATES);
+      if (ax.out_num_trajectory_expansions) ax.out_num_trajectory_expansions[row] = rec_i(w, RW_DEPTH);
+      if (ax.out_is_divergent) ax.out_is_divergent[row] = (uint8_t)(rec_i(w, RW_DIV) != 0);
+      if (ax.out_is_turning) ax.out_is_turning[row] = (uint8_t)(rec_i(w, RW_TURN) != 0);
+    }
+    if (ax.adapt_tab) {
+      if (lane == 0) FS(BJX_NUTS_F_ACC, c) = acc_rate;  // async_adapt_chain reads it from the slot table
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ax.q: written above, read by the Welford update
+      async_adapt_chain<VEC>(nt, ax, c, t);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // step size / metric: read again below
+    }
+    t += 1;
+    if (lane == 0) ax.t[c] = t;
+    if (t >= ax.n_steps) {
+      if (lane == 0) {
+        ax.phase[c] = 2;
+        atomicAdd(ax.n_done, 1);
+      }
+      return;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        Q[k] = ldr<VEC>(ax.q + base + j0[k]);
+        G[k] = ldr<VEC>(ax.g + base + j0[k]);
+      }
+    lp = ax.logp[c];
+  }
+  // start transition t: momentum draw (hmc.py:299-302, metrics.py:260-270), tree of nuts.py:278-294
+  const StepCtx cx = async_ctx(nt, ax, t);
+  const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
+  const Key km = key_child(kc, 0);  // split(kc, 2)[0]
+  const Key ik = key_child(kc, 1);  // split(kc, 2)[1]   (nuts.py:133)
+  const float* im = nt.imm + c * nt.imm_stride;
+  const float eps = chain_eps(nt, c);
+  Row<VEC> M[NI], P[NI];
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      M[k] = ldr<VEC>(im + j0[k]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0[k] + e)));
+        const float ms = 1.0f / sqrtf(M[k].v[e]);
+        P[k].v[e] = ms * z;
+        acc += (double)(M[k].v[e] * P[k].v[e]) * (double)P[k].v[e];
+      }
+      str<VEC>(ax.p + base + j0[k], P[k]);
+    }
+  acc = wave_sum(acc);
+  const float ke = 0.5f * (float)acc;
+  const float H0 = -lp + ke;
+  rec_set_f(w, RW_H0, H0);
+  rec_set_f(w, RW_PLOGP, lp);
+  rec_set_f(w, RW_PENERGY, H0);
+  rec_set_f(w, RW_PW, 0.0f);
+  rec_set_f(w, RW_PSLPA, -__builtin_inff());
+  rec_set_f(w, RW_SW, 0.0f);
+  rec_set_f(w, RW_SSLPA, -__builtin_inff());
+  rec_set_f(w, RW_ACC, __builtin_nanf(""));
+  rec_set_i(w, RW_NSTATES, 0);
+  rec_set_i(w, RW_DIV, 0);
+  rec_set_i(w, RW_TURN, 0);
+  rec_set_i(w, RW_DEPTH, 0);
+  rec_set_i(w, RW_IK, (int)ik.k0);
+  rec_set_i(w, RW_IKB, (int)ik.k1);
+  rec_set_f(w, RW_EPS, eps);
+  const int dir = begin_doubling_rec(w, ik, 0);
+  const float deps = (float)dir * eps;
+  const float h = deps * 0.5f;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        P[k].v[e] = fmaf(h, G[k].v[e], P[k].v[e]);
+        Q[k].v[e] = fmaf(deps, M[k].v[e] * P[k].v[e], Q[k].v[e]);
+      }
+      str<VEC>(ax.front_p + base + j0[k], P[k]);
+      str<VEC>(qrow + j0[k], Q[k]);
+    }
+  rec_set_i(w, RW_LAZY, (LZ_L | LZ_R | LZ_P | LZ_M) & ~(dir > 0 ? LZ_R : LZ_L));
+  if (lane == 0) ax.phase[c] = 1;
+}
+
+// One tick of one compact row.  MODE 0: leaf work only (phase 1), 1: transition ends / starts only
+// (phases 3, 0), 2: both in the same wave (one launch per tick).
+#ifndef BJX_LEAF2_WAVES
+#define BJX_LEAF2_WAVES 4
+#endif
+template <int NI, int MODE>
+__device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+                                                const float* __restrict__ logp_f,
+                                                const float* __restrict__ gf, int64_t b) {
+  constexpr int VEC = 4;
+  const int lane = threadIdx.x & 63;
+  const int chain = ax.rows ? ax.rows[b] : (int)b;
+  const int64_t c = (int64_t)__builtin_amdgcn_readfirstlane(chain);
+  // first round trip: the phase, the record and (leaf modes) every row of a leaf, all at once
+  int phase = ax.phase[c];
+  int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
+  int w = recp[lane & (BJX_NUTS_REC_WORDS - 1)];
+  LeafRows<NI> R;
+  float lp = 0.0f;
+  if constexpr (MODE != 1) {
+    const int64_t base = c * nt.D;
+    const float* im = nt.imm + c * nt.imm_stride;
+    lp = logp_f[b];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int64_t j = ((int64_t)lane + 64 * k) * VEC;
+      if (j < nt.D) {
+        R.G[k] = ldr<VEC>(gf + b * nt.D + j);
+        R.M[k] = ldr<VEC>(im + j);
+        R.P[k] = ldr<VEC>(ax.front_p + base + j);
+        R.X[k] = ldr<VEC>(qf + b * nt.D + j);
+        R.S[k] = ldr<VEC>(nt.Smsum + base + j);
+      }
+    }
+  }
+  phase = __builtin_amdgcn_readfirstlane(phase);
+  const int w_in = w;
+  if (MODE != 1 && phase == 1) {
+    const int done = async_leaf2_chain<NI>(nt, ax, qf, lp, c, b, w, R);
+    if (MODE == 2 && done) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
+    }
+    // two-kernel ticks: rows whose transition ended go on the work list of the second kernel
+    if (MODE == 0 && done && ax.end_list && lane == 0) ax.end_list[atomicAdd(ax.end_count, 1)] = (int32_t)b;
+  } else if (MODE != 0 && (phase == 3 || phase == 0)) {
+    async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
+  } else {
+    if (MODE == 0 && phase == 0 && ax.end_list && lane == 0)  // first tick of a run: every chain starts
+      ax.end_list[atomicAdd(ax.end_count, 1)] = (int32_t)b;
+    return;
+  }
+  if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
+}
+
+// WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168
+template <int NI, int MODE, int WAVES>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES)))
+k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                   const float* __restrict__ gf) {
+  for (int64_t b = wave_row0(); b < ax.n_rows; b += wave_row_stride())
+    async_tick2_row<NI, MODE>(nt, ax, qf, logp_f, gf, b);
+}
+
+// Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
+// ended, or -- first tick -- starts): one in eighteen chains at C3, so scanning all rows for them
+// costs more than serving them (32 768 waves that load a phase and exit: ~12 us; the transition
+// ends themselves: ~10 us).  The last wave to finish resets the list for the next tick.
+template <int NI>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
+k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                      const float* __restrict__ gf) {
+  const int n = __builtin_amdgcn_readfirstlane(ax.end_count[0]);  // read by every wave before any reset
+  for (int64_t i = wave_row0(); i < n; i += wave_row_stride())
+    async_tick2_row<NI, 1>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(ax.end_list[i]));
+  if ((threadIdx.x & 63) == 0) {
+    const int total = (int)(gridDim.x * kWavesPerBlock);
+    if (atomicAdd(ax.end_count + 1, 1) == total - 1) {  // every wave has read the count
+      ax.end_count[0] = 0;
+      ax.end_count[1] = 0;
+    }
+  }
+}
+
 // Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
 // One 1024-thread workgroup (same ballot + LDS scan as k_nuts_compact); src[b'] remembers the old
 // row so the pending positions can be gathered by k_nuts_async_gather.
@@ -1352,6 +1909,37 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
   // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
   const bool fused = run->n_rows <= fused_rows;
+  static const bool use_v2 = [] {
+    const char* e = getenv("BJX_NUTS_V2");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const bool all_vec4 = nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm);
+  const int ni2 = all_vec4 ? nuts_resident_ni(nuts, qf, gf) : 0;
+  if (use_v2 && ni2 > 0 && run->rec && run->front_p) {  // v2 data movement (see "free-running chains, v2")
+    const dim3 rgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
+    const dim3 lgrid(rgrid.x < 512u ? rgrid.x : 512u);           // work-list kernel: at most 2 048 waves
+    static const int leaf_waves = [] { const char* e = getenv("BJX_LEAF2_WAVES"); return e ? atoi(e) : 3; }();
+    static const int fused_waves = [] { const char* e = getenv("BJX_FUSED2_WAVES"); return e ? atoi(e) : 3; }();
+#define BJX_TICK2_L(NI_, MODE_, W_) \
+  hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_>), rgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf)
+#define BJX_TICK2(NI_)                                                                     \
+  do {                                                                                     \
+    if (fused) {                                                                           \
+      if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);           \
+    } else {                                                                               \
+      if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);            \
+      if (run->end_list && run->end_count)                                                 \
+        hipLaunchKernelGGL((k_nuts_async_end_list<NI_>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
+      else                                                                                 \
+        BJX_TICK2_L(NI_, 1, 4);                                                            \
+    }                                                                                      \
+  } while (0)
+    if (ni2 == 1) BJX_TICK2(1);
+    else BJX_TICK2(2);
+#undef BJX_TICK2_L
+#undef BJX_TICK2
+    return bjx_check_launch("bjx_nuts_async_tick");
+  }
   if (fused) {
     const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
     if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {

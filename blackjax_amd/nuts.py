@@ -343,6 +343,21 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     return kernel_graph if use_graph else kernel_eager
 
 
+def auto_row_block(n_rows: int, dim: int) -> int:
+    """Rows per group of the free-running schedule.  Default: ALL rows in one group.  Ticking the
+    ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; set
+    ``BJX_NUTS_ROW_BLOCK=n`` or pass ``row_block=n``) was measured SLOWER at the C3 shape (32 768 x
+    256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s): the
+    tick kernels are bound by instruction issue and dependent latency at 3 waves per SIMD, not by HBM
+    bandwidth, so cache residency buys nothing and the smaller launches cost."""
+    import os
+
+    v = os.environ.get("BJX_NUTS_ROW_BLOCK", "")
+    if v not in ("", "auto"):
+        return int(v)  # 0 = one group
+    return int(n_rows)
+
+
 class NUTSRunInfo(NamedTuple):
     """Per-(transition, chain) records of a free-running run, each ``(num_steps, N)``: the scalar
     fields of ``NUTSInfo`` plus the log-density of the accepted state."""
@@ -360,7 +375,8 @@ class NUTSRunInfo(NamedTuple):
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048, adaptation=None):
+             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
+             row_block=None):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -464,6 +480,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     qf = torch.zeros_like(q)
     t_done = torch.zeros(N, **i32)
     phase = torch.zeros(N, **i32)
+    # work buffers of the low-traffic tick kernels (include/bjx_nuts.h: rec / front_p)
+    rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32)
+    front_p = torch.empty_like(q)
+    end_list = torch.empty(N, **i32)
+    end_count = torch.zeros(2, **i32)
     n_done = torch.zeros(1, **i32)
     desc = _lib.NutsDesc(
         N=N, D=D, max_depth=max_depth, reserved=0, imm=metric.imm.data_ptr(),
@@ -482,80 +503,114 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         out_num_integration_steps=info.num_integration_steps.data_ptr(),
         out_num_trajectory_expansions=info.num_trajectory_expansions.data_ptr(),
         out_is_divergent=info.is_divergent.data_ptr(), out_is_turning=info.is_turning.data_ptr(),
-        **adapt_fields)
+        rec=rec.data_ptr(), front_p=front_p.data_ptr(), end_list=end_list.data_ptr(),
+        end_count=end_count.data_ptr(), **adapt_fields)
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
-    logp_f = torch.zeros(N, **f32)  # the first tick only starts transitions: nothing reads these
-    gf = torch.zeros_like(q)
     max_ticks = T * ((1 << max_depth) - 1) + 2
     sync_every = max(1, int(sync_every))
-    # Finished chains are dropped from the callable's batch: when an occasional host sync shows that
-    # fewer than 3/4 of the current rows are still running, the device compacts the row list and
-    # gathers the pending positions into a smaller batch (two buffers, swapped at each compaction).
-    n_rows = N
-    rows_buf = [torch.empty(N, **i32), torch.empty(N, **i32)]
-    qf_buf = [qf, None]
-    src_work = torch.empty(N, **i32)
-    n_out = torch.zeros(1, **i32)
-    cur = 0
-
-    def chunk(n_ticks, qf, logp_f, gf):
-        """``n_ticks`` ticks, each followed by the callable on the current batch."""
-        for _ in range(n_ticks):
-            _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref, qf.data_ptr(),
-                      logp_f.data_ptr(), gf.data_ptr())
-            logp_f, gf = eval_logdensity(vg, qf)
-        return logp_f, gf
-
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
-    graph = None  # (CUDAGraph, static logp_f, static gf) for the current batch
-    graph_ok = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
-    eager_chunks = 0  # plain chunks since the batch last changed (they warm kernels and allocator)
-    ticks_left = max_ticks
-    while ticks_left > 0:
-        tail = n_rows <= graph_max_rows
-        n_ticks = sync_every * (4 if tail else 1)
-        if graph is not None:
-            graph[0].replay()
-        else:
-            logp_f, gf = chunk(n_ticks, qf, logp_f, gf)
-            eager_chunks += 1
-            # "auto" records only when a batch size has lasted 4 plain chunks already: recording a
-            # chunk costs milliseconds, which only a long tail pays back
-            if graph_ok and ticks_left < max_ticks and (use_graph is True or (tail and eager_chunks >= 4)):
+    can_record = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
+
+    def make_run(rows, n_rows):
+        r = _lib.NutsAsync()
+        ctypes.memmove(ctypes.byref(r), ctypes.byref(run), ctypes.sizeof(run))  # copy of the template
+        r.rows, r.n_rows = _lib.ptr(rows), n_rows
+        return r
+
+    class _Group:
+        """A set of compact rows ticked together: (qf, logp_f, gf) batch + its row list."""
+
+        def __init__(self, rows, n_rows, qf_g):
+            self.rows, self.n_rows, self.qf = rows, n_rows, qf_g
+            self.run = make_run(rows, n_rows)
+            self.rref = ctypes.byref(self.run)
+            self.logp_f = torch.zeros(n_rows, **f32)  # the first tick only starts transitions
+            self.gf = torch.zeros_like(qf_g)
+            self.graph = None  # (CUDAGraph, static logp_f, static gf, n_ticks)
+            self.eager_chunks = 0
+
+        def chunk(self, n_ticks, logp_f, gf):
+            """``n_ticks`` ticks, each followed by the callable on the group's batch."""
+            for _ in range(n_ticks):
+                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
+                          logp_f.data_ptr(), gf.data_ptr())
+                logp_f, gf = eval_logdensity(vg, self.qf)
+            return logp_f, gf
+
+        def advance(self, n_ticks, record):
+            nonlocal can_record
+            if self.graph is not None and self.graph[3] == n_ticks:
+                self.graph[0].replay()
+                return
+            self.graph = None
+            self.logp_f, self.gf = self.chunk(n_ticks, self.logp_f, self.gf)
+            self.eager_chunks += 1
+            if record:
                 # recording does not execute anything, so the chains' state is untouched by it
-                lp_s, g_s = logp_f.clone(), gf.clone()
+                lp_s, g_s = self.logp_f.clone(), self.gf.clone()
                 try:
                     cg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(cg):
-                        lp_e, g_e = chunk(n_ticks, qf, lp_s, g_s)
+                        lp_e, g_e = self.chunk(n_ticks, lp_s, g_s)
                         lp_s.copy_(lp_e)
                         g_s.copy_(g_e)
-                    graph = (cg, lp_s, g_s)
+                    self.graph = (cg, lp_s, g_s, n_ticks)
+                    self.logp_f, self.gf = lp_s, g_s
                 except Exception:
                     if use_graph is True:
                         raise
-                    graph_ok = False  # "auto": this callable cannot be captured -- plain launches
+                    can_record = False  # "auto": this callable cannot be captured -- plain launches
                     torch.cuda.synchronize()
+
+    # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
+    # the next one gets its turn (chains are independent, so the results do not depend on the
+    # grouping).  One group by default -- see auto_row_block for the measurement.
+    rb = auto_row_block(N, D) if row_block is None else int(row_block)
+    blk = N if not rb or rb >= N else rb
+    groups = []
+    for s0 in range(0, N, blk):
+        n_g = min(blk, N - s0)
+        rows_g = None if blk >= N else torch.arange(s0, s0 + n_g, **i32)
+        groups.append(_Group(rows_g, n_g, qf[s0:s0 + n_g]))
+    src_work = torch.empty(N, **i32)
+    n_out = torch.zeros(1, **i32)
+    ticks_left = max_ticks
+    while ticks_left > 0:
+        n_rows = sum(g_.n_rows for g_ in groups)
+        tail = n_rows <= graph_max_rows
+        n_ticks = sync_every * (4 if tail else 1)
+        for g_ in groups:
+            # a multi-group (busy-phase) schedule replays fixed-size groups for many chunks: record at
+            # once; a single group is recorded once its batch size has lasted 4 plain chunks in the tail
+            rec_now = can_record and ticks_left < max_ticks and (
+                use_graph is True or len(groups) > 1 or (tail and g_.eager_chunks >= 4))
+            g_.advance(n_ticks, rec_now)
         ticks_left -= n_ticks
         n_active = N - int(n_done.item())  # one host sync per chunk
         if n_active == 0:
             break
         if n_active <= n_rows // 2 and n_rows > 64:
-            # drop the finished chains from the batch (device-side compaction + gather)
-            nxt = cur ^ 1
-            if qf_buf[nxt] is None:
-                qf_buf[nxt] = torch.empty_like(qf_buf[0])
-            _lib.call("bjx_nuts_async_compact", stream, dref, rref, qf.data_ptr(),
-                      rows_buf[nxt].data_ptr(), qf_buf[nxt].data_ptr(), src_work.data_ptr(),
-                      n_out.data_ptr())
-            cur, n_rows = nxt, n_active
-            qf = qf_buf[cur][:n_rows]
-            run.rows, run.n_rows = rows_buf[cur].data_ptr(), n_rows
-            logp_f, gf = eval_logdensity(vg, qf)  # the gathered positions, row for row
-            graph = None
-            eager_chunks = 0
+            # drop the finished chains from the batch (device-side compaction + gather); the groups
+            # are merged into one batch of the live rows
+            rows_all = torch.empty(n_rows, **i32)
+            qf_all = torch.empty((n_rows, D), **f32)
+            off = 0
+            for g_ in groups:
+                _lib.call("bjx_nuts_async_compact", stream, dref, g_.rref, g_.qf.data_ptr(),
+                          rows_all[off:].data_ptr(), qf_all[off:].data_ptr(), src_work.data_ptr(),
+                          n_out.data_ptr())
+                off += int(n_out.item()) if len(groups) > 1 else n_active
+            assert off == n_active, (off, n_active)
+            rb = auto_row_block(n_active, D) if row_block is None else int(row_block)
+            blk_now = n_active if not rb or rb >= n_active else rb
+            groups = []
+            for s0 in range(0, n_active, blk_now):
+                n_g = min(blk_now, n_active - s0)
+                g_ = _Group(rows_all[s0:s0 + n_g], n_g, qf_all[s0:s0 + n_g])
+                g_.logp_f, g_.gf = eval_logdensity(vg, g_.qf)  # the gathered positions, row for row
+                groups.append(g_)
     else:
         if int(n_done.item()) != N:
             raise RuntimeError("free-running NUTS did not finish within its tick bound")

@@ -61,7 +61,10 @@ enum {
   BJX_NUTS_I_KPB = 13,
   BJX_NUTS_I_IK = 14,        /* the transition's integrator key split(chain_key, 2)[1], written at doubling 0 */
   BJX_NUTS_I_IKB = 15,
-  BJX_NUTS_NI = 16
+  BJX_NUTS_I_LAZY = 16,      /* free-running chains: bit 1/2 = the left/right trajectory end, 4 = the
+                                proposal, 8 = the momentum sum is still the transition's initial state
+                                (its rows are then read from q0 / p0 / g0 instead of being copied) */
+  BJX_NUTS_NI = 17
 };
 
 typedef struct {
@@ -208,7 +211,21 @@ typedef struct {
   float *adapt_mean, *adapt_m2; /* (N, D) Welford state, in/out */
   float* adapt_imm;           /* (N, D) per-chain diagonal inverse mass matrix, in/out */
   float* out_step_size;       /* optional (n_steps, N): the step size after the update of transition t */
+  /* Optional work buffers of the low-traffic tick kernels (diagonal metric, D % 4 == 0, D <= 512,
+   * 16-byte aligned buffers): rec = (N, BJX_NUTS_REC_WORDS) packed per-chain scalars (every scalar
+   * a leaf needs in one 128-byte line; the kernels own the layout, the caller only zero-fills it
+   * before the first tick), front_p = (N, D) momentum of the trajectory end that is integrating.
+   * Both NULL: the general kernels over the fs / is slot tables are used. */
+  int32_t* rec;
+  float* front_p;
+  /* Optional work list of the two-kernel ticks (both or neither): end_list = (N,) compact rows whose
+   * transition ended in this tick's first kernel, end_count = int32[2] {count, waves done}, zeroed
+   * by the caller before the first tick and reset by the kernels after every tick. */
+  int32_t* end_list;
+  int32_t* end_count;
 } bjx_nuts_async_t;
+
+#define BJX_NUTS_REC_WORDS 32
 
 /* columns of adapt_tab */
 enum {

@@ -32,7 +32,10 @@ def test_free_running_warmup_equals_lockstep(dev, N, D, T, max_depth, shrink):
         set(), {"acceptance_rate", "num_integration_steps"}, {"step_size"}), **kw)
     key = prng.key(11)
     (st_l, par_l), hist = warm.run(key, q0, T, chain_offset=5)
-    (st_f, par_f), info = warm.run(key, q0, T, chain_offset=5, free_running=True)
+    with pytest.raises(ValueError):  # a custom adaptation_info_fn is not silently ignored
+        warm.run(key, q0, T, chain_offset=5, free_running=True)
+    warm_f = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=None, **kw)
+    (st_f, par_f), info = warm_f.run(key, q0, T, chain_offset=5, free_running=True)
     assert torch.equal(st_f.position, st_l.position)
     assert torch.equal(st_f.logdensity, st_l.logdensity)
     assert torch.equal(st_f.logdensity_grad, st_l.logdensity_grad)
