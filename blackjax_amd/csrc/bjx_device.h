@@ -119,10 +119,33 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
 
 // ---------------------------------------------------------------------------------------
 // wave64 reductions (all lanes receive the result)
+//
+// DPP row shifts instead of the ds_bpermute butterfly a __shfl_xor loop compiles to: the permute goes
+// through the LDS crossbar (~100 cycles of latency per step, twice per double) and a reduction sits
+// on the critical path of every kernel that decides something per chain (kinetic energy, U-turn dot
+// products: three per NUTS leaf).  Classic GCN sequence: inclusive prefix sums inside each row of 16
+// lanes (row_shr 1, 2, 4, 8, zeros shifted in), lane 15 of rows 0 / 2 added into rows 1 / 3
+// (row_bcast:15), lane 31 into rows 2 and 3 (row_bcast:31); lane 63 then holds the total, which
+// readlane broadcasts.  The summation order differs from the butterfly's; in fp64 that moves the
+// sum by ~1e-16 relative, far below the fp32 rounding every caller applies.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(thi, tlo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, BJX_WAVE);
-  return v;
+  v = dpp_add_f64<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add_f64<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add_f64<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add_f64<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }

@@ -1576,44 +1576,48 @@ __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_
       async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
     }
     // two-kernel ticks: rows whose transition ended go on the work list of the second kernel
-    if (MODE == 0 && done && ax.end_list && lane == 0) ax.end_list[atomicAdd(ax.end_count, 1)] = (int32_t)b;
+    if (MODE == 0 && done && ax.end_list && lane == 0)
+      ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
   } else if (MODE != 0 && (phase == 3 || phase == 0)) {
     async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
   } else {
     if (MODE == 0 && phase == 0 && ax.end_list && lane == 0)  // first tick of a run: every chain starts
-      ax.end_list[atomicAdd(ax.end_count, 1)] = (int32_t)b;
+      ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
     return;
   }
   if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
 }
 
-// WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168
+// WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168.
+// ONE WAVE PER WORKGROUP: the waves of a workgroup are placed together and a new workgroup needs
+// all its wave slots at once, so with four chains per workgroup a CU slot group lives as long as
+// the slowest of four leaves (a merge + direction change takes several times a plain leaf); these
+// kernels use neither LDS nor barriers, so nothing is lost by launching 64-thread workgroups.
 template <int NI, int MODE, int WAVES>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
-  for (int64_t b = wave_row0(); b < ax.n_rows; b += wave_row_stride())
+  if (MODE == 0 && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
+    ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
+  for (int64_t b = blockIdx.x; b < ax.n_rows; b += gridDim.x)
     async_tick2_row<NI, MODE>(nt, ax, qf, logp_f, gf, b);
 }
 
 // Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
 // ended, or -- first tick -- starts): one in eighteen chains at C3, so scanning all rows for them
-// costs more than serving them (32 768 waves that load a phase and exit: ~12 us; the transition
-// ends themselves: ~10 us).  The last wave to finish resets the list for the next tick.
+// costs more than serving them.  Two lists, used alternately (run->tick & 1): the first kernel of
+// tick k appends to list k & 1 and clears the counter of the other one, whose readers (tick k - 1)
+// are done -- no completion counting (2 048 same-address atomics with a returned value cost more
+// than the transition ends themselves: 35 us per tick measured).
 template <int NI>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                       const float* __restrict__ gf) {
-  const int n = __builtin_amdgcn_readfirstlane(ax.end_count[0]);  // read by every wave before any reset
+  const int par = ax.tick & 1;
+  const int n = __builtin_amdgcn_readfirstlane(ax.end_count[par]);
+  const int32_t* list = ax.end_list + (int64_t)par * nt.N;
   for (int64_t i = wave_row0(); i < n; i += wave_row_stride())
-    async_tick2_row<NI, 1>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(ax.end_list[i]));
-  if ((threadIdx.x & 63) == 0) {
-    const int total = (int)(gridDim.x * kWavesPerBlock);
-    if (atomicAdd(ax.end_count + 1, 1) == total - 1) {  // every wave has read the count
-      ax.end_count[0] = 0;
-      ax.end_count[1] = 0;
-    }
-  }
+    async_tick2_row<NI, 1>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(list[i]));
 }
 
 // Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
@@ -1903,7 +1907,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   hipStream_t s = (hipStream_t)stream;
   static const int64_t fused_rows = [] {
     const char* e = getenv("BJX_NUTS_FUSED_ROWS");
-    return e ? atoll(e) : (int64_t)16384;
+    return e ? atoll(e) : (int64_t)8192;
   }();
   // One launch per tick (leaf, fence, boundary in the same wave) unless nearly all chains of a large
   // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
@@ -1918,10 +1922,11 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   if (use_v2 && ni2 > 0 && run->rec && run->front_p) {  // v2 data movement (see "free-running chains, v2")
     const dim3 rgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
     const dim3 lgrid(rgrid.x < 512u ? rgrid.x : 512u);           // work-list kernel: at most 2 048 waves
+    const dim3 wgrid((unsigned)(run->n_rows < (int64_t)1 << 20 ? run->n_rows : (int64_t)1 << 20));  // one wave per workgroup
     static const int leaf_waves = [] { const char* e = getenv("BJX_LEAF2_WAVES"); return e ? atoi(e) : 3; }();
     static const int fused_waves = [] { const char* e = getenv("BJX_FUSED2_WAVES"); return e ? atoi(e) : 3; }();
 #define BJX_TICK2_L(NI_, MODE_, W_) \
-  hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_>), rgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf)
+  hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf)
 #define BJX_TICK2(NI_)                                                                     \
   do {                                                                                     \
     if (fused) {                                                                           \

@@ -483,7 +483,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # work buffers of the low-traffic tick kernels (include/bjx_nuts.h: rec / front_p)
     rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32)
     front_p = torch.empty_like(q)
-    end_list = torch.empty(N, **i32)
+    end_list = torch.empty((2, N), **i32)
     end_count = torch.zeros(2, **i32)
     n_done = torch.zeros(1, **i32)
     desc = _lib.NutsDesc(
@@ -508,7 +508,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2
-    sync_every = max(1, int(sync_every))
+    sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even: the work lists alternate per tick
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
     can_record = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
@@ -533,7 +533,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 
         def chunk(self, n_ticks, logp_f, gf):
             """``n_ticks`` ticks, each followed by the callable on the group's batch."""
-            for _ in range(n_ticks):
+            for i in range(n_ticks):
+                self.run.tick = i & 1  # work-list parity (include/bjx_nuts.h); chunks have an even length
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
                           logp_f.data_ptr(), gf.data_ptr())
                 logp_f, gf = eval_logdensity(vg, self.qf)

@@ -218,11 +218,15 @@ typedef struct {
    * Both NULL: the general kernels over the fs / is slot tables are used. */
   int32_t* rec;
   float* front_p;
-  /* Optional work list of the two-kernel ticks (both or neither): end_list = (N,) compact rows whose
-   * transition ended in this tick's first kernel, end_count = int32[2] {count, waves done}, zeroed
-   * by the caller before the first tick and reset by the kernels after every tick. */
+  /* Optional work lists of the two-kernel ticks (both or neither): end_list = (2, N) compact rows
+   * whose transition ended in this tick's first kernel, end_count = int32[2], zeroed by the caller
+   * before the first tick; list `tick & 1` is used by tick number `tick`, which the caller advances
+   * by one per call (only its parity matters: a recorded sequence of an even number of ticks can be
+   * replayed). */
   int32_t* end_list;
   int32_t* end_count;
+  int32_t tick;
+  int32_t reserved2;
 } bjx_nuts_async_t;
 
 #define BJX_NUTS_REC_WORDS 32

@@ -16,11 +16,13 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pmc_nuts3/g*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'async_tick2<' not in k and 'k_neal_funnel' not in k:
+        import re
+        m = re.search(r'(k_nuts_async_tick2<[^>]*>|k_nuts_async_end_list<[^>]*>|k_neal_funnel\w*(<[^>]*>)?)', k)
+        if not m:
             continue
-        if int(r['Grid_Size']) < 32768 * 64:
+        name = m.group(1)
+        if 'end_list' not in name and int(r['Grid_Size']) < 32768 * 64:
             continue
-        name = k.split('(')[0].replace('void (anonymous namespace)::', '')[:40]
         acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(acc.items()):
     print(k)
