@@ -145,7 +145,7 @@ class NutsAsync(ctypes.Structure):
         ("adapt_mu", c_void_p), ("adapt_step_size", c_void_p), ("adapt_mean", c_void_p),
         ("adapt_m2", c_void_p), ("adapt_imm", c_void_p), ("out_step_size", c_void_p),
         ("rec", c_void_p), ("front_p", c_void_p), ("end_list", c_void_p), ("end_count", c_void_p),
-        ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("n_rows_dev", c_void_p),
     ]
 
 

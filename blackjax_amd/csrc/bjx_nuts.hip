@@ -811,13 +811,22 @@ constexpr int kAsyncGroup = 8;
 #define BJX_FUSED_WAVES 3
 #endif
 
+// rows to process: the host's count, or -- so that one recorded launch sequence serves every batch
+// size of the tail -- the smaller device-side count the last compaction wrote
+__device__ __forceinline__ int64_t async_n_rows(const bjx_nuts_async_t& ax) {
+  if (!ax.n_rows_dev) return ax.n_rows;
+  const int64_t n = (int64_t)__builtin_amdgcn_readfirstlane(*ax.n_rows_dev);
+  return n < ax.n_rows ? n : ax.n_rows;
+}
+
 // f(chain, compact row, phase) for every chain of the compact rows whose phase is want_a or want_b
 template <bool GROUPED = true, class F>
 __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax, int want_a, int want_b,
                                                      F f) {
   const int lane = threadIdx.x & 63;
   if constexpr (!GROUPED) {
-    for (int64_t b = wave_row0(); b < ax.n_rows; b += wave_row_stride()) {
+    const int64_t n_rows = async_n_rows(ax);
+    for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
       const int chain = ax.rows ? ax.rows[b] : (int)b;
       const int ph = ax.phase[chain];
       if (ph == want_a || ph == want_b)
@@ -825,11 +834,12 @@ __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax,
     }
     return;
   }
-  const int64_t n_groups = (ax.n_rows + kAsyncGroup - 1) / kAsyncGroup;
+  const int64_t n_rows_g = async_n_rows(ax);
+  const int64_t n_groups = (n_rows_g + kAsyncGroup - 1) / kAsyncGroup;
   for (int64_t grp = wave_row0(); grp < n_groups; grp += wave_row_stride()) {
     const int64_t b0 = grp * kAsyncGroup;
     int chain = -1, ph = -1;
-    if (lane < kAsyncGroup && b0 + lane < ax.n_rows) {
+    if (lane < kAsyncGroup && b0 + lane < n_rows_g) {
       chain = ax.rows ? ax.rows[b0 + lane] : (int)(b0 + lane);
       ph = ax.phase[chain];
     }
@@ -1599,7 +1609,8 @@ k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
                    const float* __restrict__ gf) {
   if (MODE == 0 && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
-  for (int64_t b = blockIdx.x; b < ax.n_rows; b += gridDim.x)
+  const int64_t n_rows = async_n_rows(ax);
+  for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
     async_tick2_row<NI, MODE>(nt, ax, qf, logp_f, gf, b);
 }
 
@@ -1631,10 +1642,11 @@ k_nuts_async_compact(bjx_nuts_async_t ax, int32_t* __restrict__ rows_out, int32_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int64_t start = 0; start < ax.n_rows; start += 1024) {
+  const int64_t n_rows = async_n_rows(ax);
+  for (int64_t start = 0; start < n_rows; start += 1024) {
     const int64_t i = start + tid;
     int32_t c = -1;
-    if (i < ax.n_rows) c = ax.rows ? ax.rows[i] : (int32_t)i;
+    if (i < n_rows) c = ax.rows ? ax.rows[i] : (int32_t)i;
     const bool keep = c >= 0 && ax.phase[c] != 2;
     const unsigned long long ballot = __ballot(keep);
     const int lane_prefix = __popcll(ballot & ((1ull << lane) - 1ull));

@@ -565,6 +565,92 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     can_record = False  # "auto": this callable cannot be captured -- plain launches
                     torch.cuda.synchronize()
 
+    src_work = torch.empty(N, **i32)
+    n_out = torch.zeros(1, **i32)
+
+    class _Tail:
+        """The tail of a run (at most ``cap`` live rows) on FIXED-CAPACITY buffers: the kernels read
+        the live-row count from device memory (``n_rows_dev``, include/bjx_nuts.h), so ONE recorded
+        chunk of ticks per buffer set serves every batch size the tail goes through -- compaction
+        only rewrites the row list, the pending positions and the count -- instead of a plain-launch
+        warm-up and a new recording at every halving of the batch.  Two buffer sets because a
+        compaction cannot work in place."""
+
+        def __init__(self, cap, n_ticks, reps):
+            # a recorded sequence of n_ticks ticks, replayed `reps` times per host sync: recording
+            # costs ~40 us per tick, so a short sequence pays for itself within a few hundred ticks
+            self.cap, self.n_ticks, self.reps = cap, n_ticks, reps
+            self.rows = [torch.zeros(cap, **i32) for _ in range(2)]
+            self.qf = [torch.zeros((cap, D), **f32) for _ in range(2)]
+            self.n_dev = [torch.zeros(1, **i32) for _ in range(2)]
+            self.lp = [torch.zeros(cap, **f32) for _ in range(2)]
+            self.g = [torch.zeros((cap, D), **f32) for _ in range(2)]
+            self.run = []
+            for k in range(2):
+                r = make_run(self.rows[k], cap)
+                r.n_rows_dev = self.n_dev[k].data_ptr()
+                self.run.append(r)
+            self.graph = [None, None]
+            self.chunks = [0, 0]
+            self.cur, self.n_cur = 0, 0
+
+        def _after_compaction(self, k, n_active):
+            lp, g_ = eval_logdensity(vg, self.qf[k])  # the gathered positions, row for row
+            self.lp[k].copy_(lp)
+            self.g[k].copy_(g_)
+            self.cur, self.n_cur = k, n_active
+
+        def enter(self, groups_in, n_active):
+            off = 0
+            for g_ in groups_in:
+                _lib.call("bjx_nuts_async_compact", stream, dref, g_.rref, g_.qf.data_ptr(),
+                          self.rows[0][off:].data_ptr(), self.qf[0][off:].data_ptr(), src_work.data_ptr(),
+                          n_out.data_ptr())
+                off += int(n_out.item()) if len(groups_in) > 1 else n_active
+            assert off == n_active, (off, n_active)
+            self.n_dev[0].fill_(n_active)
+            self._after_compaction(0, n_active)
+
+        def compact(self, n_active):
+            x, y = self.cur, self.cur ^ 1
+            _lib.call("bjx_nuts_async_compact", stream, dref, ctypes.byref(self.run[x]), self.qf[x].data_ptr(),
+                      self.rows[y].data_ptr(), self.qf[y].data_ptr(), src_work.data_ptr(),
+                      self.n_dev[y].data_ptr())
+            self._after_compaction(y, n_active)
+
+        def _body(self, k):
+            lp, g_ = self.lp[k], self.g[k]
+            rref_k = ctypes.byref(self.run[k])
+            for i in range(self.n_ticks):
+                self.run[k].tick = i & 1
+                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, self.qf[k].data_ptr(),
+                          lp.data_ptr(), g_.data_ptr())
+                lp, g_ = eval_logdensity(vg, self.qf[k])
+            self.lp[k].copy_(lp)
+            self.g[k].copy_(g_)
+
+        def advance(self):
+            nonlocal can_record
+            k = self.cur
+            if self.graph[k] is not None:
+                for _ in range(self.reps):
+                    self.graph[k].replay()
+                return
+            for _ in range(self.reps):
+                self._body(k)
+            self.chunks[k] += 1
+            if can_record:  # record after one plain chunk on this buffer set (kernels, allocator warm)
+                try:
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg):
+                        self._body(k)
+                    self.graph[k] = cg
+                except Exception:
+                    if use_graph is True:
+                        raise
+                    can_record = False
+                    torch.cuda.synchronize()
+
     # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
     # the next one gets its turn (chains are independent, so the results do not depend on the
     # grouping).  One group by default -- see auto_row_block for the measurement.
@@ -575,16 +661,25 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         n_g = min(blk, N - s0)
         rows_g = None if blk >= N else torch.arange(s0, s0 + n_g, **i32)
         groups.append(_Group(rows_g, n_g, qf[s0:s0 + n_g]))
-    src_work = torch.empty(N, **i32)
-    n_out = torch.zeros(1, **i32)
+    tail_ctx = None
     ticks_left = max_ticks
     while ticks_left > 0:
+        if tail_ctx is not None:
+            tail_ctx.advance()
+            ticks_left -= tail_ctx.n_ticks * tail_ctx.reps
+            n_active = N - int(n_done.item())  # one host sync per chunk
+            if n_active == 0:
+                break
+            if n_active <= tail_ctx.n_cur // 2 and tail_ctx.n_cur > 64:
+                tail_ctx.compact(n_active)
+            continue
         n_rows = sum(g_.n_rows for g_ in groups)
         tail = n_rows <= graph_max_rows
         n_ticks = sync_every * (4 if tail else 1)
         for g_ in groups:
-            # a multi-group (busy-phase) schedule replays fixed-size groups for many chunks: record at
-            # once; a single group is recorded once its batch size has lasted 4 plain chunks in the tail
+            # a multi-group schedule replays fixed-size groups for many chunks: record at once; a
+            # single small group (a run that STARTS with few chains) is recorded once its batch size
+            # has lasted 4 plain chunks
             rec_now = can_record and ticks_left < max_ticks and (
                 use_graph is True or len(groups) > 1 or (tail and g_.eager_chunks >= 4))
             g_.advance(n_ticks, rec_now)
@@ -595,6 +690,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         if n_active <= n_rows // 2 and n_rows > 64:
             # drop the finished chains from the batch (device-side compaction + gather); the groups
             # are merged into one batch of the live rows
+            if can_record and n_active <= graph_max_rows:
+                tail_ctx = _Tail(n_active, sync_every, 4)
+                tail_ctx.enter(groups, n_active)
+                groups = []
+                continue
             rows_all = torch.empty(n_rows, **i32)
             qf_all = torch.empty((n_rows, D), **f32)
             off = 0

@@ -227,6 +227,11 @@ typedef struct {
   int32_t* end_count;
   int32_t tick;
   int32_t reserved2;
+  /* Optional device-side row count: when non-NULL the kernels process min(n_rows, *n_rows_dev) rows
+   * (launch geometry still follows n_rows).  Lets ONE recorded sequence of ticks serve every batch
+   * size of a run's tail: bjx_nuts_async_compact writes the new count to its n_out argument, which
+   * the next ticks then read here. */
+  const int32_t* n_rows_dev;
 } bjx_nuts_async_t;
 
 #define BJX_NUTS_REC_WORDS 32

@@ -60,8 +60,18 @@ if args.free_running:
     ticks = tick_timer.seen["bjx_nuts_async_tick"] or int(per_chain.max())
     tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick") or [float("nan")]
     avg_tick_us = sum(tick_ms) / len(tick_ms) * 1e3
+    # per window of 100 transitions: what a schedule that synchronised the chains every 100 transitions
+    # could use at best = leapfrogs of the window / (N x the busiest chain's leapfrogs in it)
+    util_windows = []
+    for w0 in range(0, args.steps, 100):
+        win = rinfo.num_integration_steps[w0:w0 + 100].sum(0).float()
+        util_windows.append({"transitions": [w0, min(w0 + 100, args.steps)],
+                             "utilisation": float(win.sum() / (N * win.max())),
+                             "busiest_chain_leapfrogs": int(win.max()), "mean_chain_leapfrogs": float(win.mean())})
     print(json.dumps({
         "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot / dt, "unit": "chain-leapfrog-steps/s",
+        "frac_of_52B_roofline": tot / dt / (8e12 / (52.0 * D)),
+        "utilisation_per_100_transitions": util_windows,
         "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
                    "driver": "free-running chains (alg.run)",
                    "hip_graph": "on" if args.use_graph else args.run_graph},
