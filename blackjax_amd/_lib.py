@@ -55,6 +55,16 @@ SIGNATURES = {
                              _f32p, _f32p, c_float,
                              _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                              _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
+    "bjx_leapfrog_dense_coef": [c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_float, c_float, _f32p,
+                                _f32p, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, c_void_p, ctypes.c_int32],
+    "bjx_hmc_finish_dense_coef": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_float,
+                                  c_float, _f32p, _f32p, c_int64, c_float,
+                                  _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                  _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p],
+    "bjx_mhmc_step_dense": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                            c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p,
+                            _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p,
+                            _f32p],
     "bjx_pc_matvec_t": [c_void_p, c_int64, c_int64, _f32p, c_int64, _f32p, _f32p],
     "bjx_hmc_momentum_dense_pc": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
                                   _f32p, _f32p, c_int64, _f32p, _f32p, _f32p, _f32p],

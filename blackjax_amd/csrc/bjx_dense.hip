@@ -41,7 +41,20 @@ struct GemmArgs {
   float* Q_out;
   bool b_symmetric = false;  // B is the inverse mass matrix: B[k][n] and B[n][k] are interchangeable,
                              // so complete aligned tiles may take the k-contiguous "TN" kernel
+  // General palindromic integrators (integrators.py:104-150): the kicks are p += (eps*kick_a) g
+  // [; p += (eps*kick_b) g] and the drift q += (eps*drift) v, `eps*coef` an fp32 product as in the
+  // reference.  Velocity Verlet: (0.5, 0.5, 1.0) -- eps*0.5f and eps*1.0f are the values used before
+  // the coefficients existed, bit for bit.
+  float kick_a = 0.5f, kick_b = 0.5f, drift = 1.0f;
+  // Per-chain trajectory length (dynamic HMC): row r advances only while step_idx < n_steps[r];
+  // otherwise its momentum and position are copied through untouched.  NULL = every row advances.
+  const int32_t* n_steps = nullptr;
+  int32_t step_idx = 0;
 };
+
+__device__ __forceinline__ bool gemm_row_active(const GemmArgs& a, int64_t row) {
+  return !a.n_steps || a.step_idx < a.n_steps[row];
+}
 
 // FULL: M % BM == 0 and D % BN == 0 (hence D % BK == 0): every tile is complete, no bounds checks.
 template <int EPI, bool ALIGNED, bool FULL>
@@ -83,8 +96,14 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   const int b_k = tid / (BN / EPT), b_n = (tid % (BN / EPT)) * EPT;  // B tile: BK x 128, EPT n per thread
   const int64_t g_row = row0 + a_row;
   const bool row_ok = FULL || g_row < a.M;
-  float h = 0.0f;
-  if (a.n_kicks > 0 && row_ok) h = (a.eps_pc ? a.eps_pc[g_row] : a.eps) * 0.5f;
+  float ha = 0.0f, hb = 0.0f;
+  bool kick_row = false;
+  if (a.n_kicks > 0 && row_ok) {
+    const float e = a.eps_pc ? a.eps_pc[g_row] : a.eps;
+    ha = e * a.kick_a;
+    hb = e * a.kick_b;
+    kick_row = gemm_row_active(a, g_row);
+  }
 
   // Staging is split (issue early / consume late): load_tiles only ISSUES the global loads of the
   // next K-tile; the kick fma, the A_out store and the LDS writes happen in store_tiles AFTER the
@@ -140,10 +159,12 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
   };
   auto store_tiles = [&](int buf) {
     if (a.n_kicks > 0 && row_ok) {  // kick prologue on the staged A values
+      if (kick_row) {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        ra[e] = fmaf(h, rg[e], ra[e]);
-        if (a.n_kicks == 2) ra[e] = fmaf(h, rg[e], ra[e]);
+        for (int e = 0; e < EPT; ++e) {
+          ra[e] = fmaf(ha, rg[e], ra[e]);
+          if (a.n_kicks == 2) ra[e] = fmaf(hb, rg[e], ra[e]);
+        }
       }
       if (a.A_out && col_blk == 0) {
         const int64_t kk = cur_kk;
@@ -247,10 +268,13 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
           if constexpr (EPI == EPI_STORE) {
             st4(a.C + row * D + col, c);
           } else {
-            const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
+            const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
             const F4 q = ld4(a.Q_in + row * D + col);
-            st4(a.Q_out + row * D + col,
-                F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+            if (gemm_row_active(a, row))
+              st4(a.Q_out + row * D + col,
+                  F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+            else
+              st4(a.Q_out + row * D + col, q);
           }
         }
       }
@@ -275,8 +299,9 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
             if constexpr (EPI == EPI_STORE) {
               a.C[row * D + col] = c;
             } else {
-              const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
-              a.Q_out[row * D + col] = fmaf(e, c, a.Q_in[row * D + col]);
+              const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
+              const float q = a.Q_in[row * D + col];
+              a.Q_out[row * D + col] = gemm_row_active(a, row) ? fmaf(e, c, q) : q;
             }
           }
         }
@@ -334,8 +359,14 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
   // quarter of the K-tiles each at D = 512 instead of all of them in column block 0, whose
   // store drains then made its row's slowest workgroup.
   float* a_out = (KICKS > 0 && a.A_out) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
-  float h = 0.0f;
-  if (KICKS > 0) h = (a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps) * 0.5f;
+  float ha = 0.0f, hb = 0.0f;
+  bool kick_row = true;
+  if (KICKS > 0) {
+    const float e = a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps;
+    ha = e * a.kick_a;
+    hb = e * a.kick_b;
+    kick_row = gemm_row_active(a, row0 + s_row);
+  }
   // Software pipeline over K-tiles with two register sets (loop unrolled by two so the set index
   // is static).  In iteration t, in program order:
   //   LDS operand reads of tile t, first half of its MFMAs           (matrix pipe now busy)
@@ -355,13 +386,15 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
     if constexpr (KICKS > 0) { r.g[0] = ld4(g_src + k0); r.g[1] = ld4(g_src + k0 + 4); }
     r.b[0] = ld4(b_src + k0); r.b[1] = ld4(b_src + k0 + 4);
   };
-  auto kick = [&](F4& x, const F4& g) {
+  auto kick = [&](F4& x, const F4& g, float h) {
     x.x = fmaf(h, g.x, x.x); x.y = fmaf(h, g.y, x.y); x.z = fmaf(h, g.z, x.z); x.w = fmaf(h, g.w, x.w);
   };
   auto store_tiles = [&](Regs& r, int buf, int64_t k0) {
     if constexpr (KICKS > 0) {
-      kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]);
-      if constexpr (KICKS == 2) { kick(r.a[0], r.g[0]); kick(r.a[1], r.g[1]); }
+      if (kick_row) {
+        kick(r.a[0], r.g[0], ha); kick(r.a[1], r.g[1], ha);
+        if constexpr (KICKS == 2) { kick(r.a[0], r.g[0], hb); kick(r.a[1], r.g[1], hb); }
+      }
       if (a_out && k0 / BN == col_blk) { st4(a_out + k0, r.a[0]); st4(a_out + k0 + 4, r.a[1]); }
     }
     float* as = As0 + buf * BM * LDK + s_row * LDK + s_k;
@@ -442,10 +475,13 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
       if constexpr (EPI == EPI_STORE) {
         st4(a.C + row * D + col, c);
       } else {
-        const float e = a.eps_pc ? a.eps_pc[row] : a.eps;
+        const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
         const F4 q = ld4(a.Q_in + row * D + col);
-        st4(a.Q_out + row * D + col,
-            F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+        if (gemm_row_active(a, row))
+          st4(a.Q_out + row * D + col,
+              F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+        else
+          st4(a.Q_out + row * D + col, q);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -531,6 +567,66 @@ k_hmc_finish_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, flo
   }
 }
 
+// Multinomial HMC with a dense metric (hmc.py:181-248, trajectory.py:170-232): the part of
+// k_mhmc_step_diag after the closing kick.  p1 (fully kicked momentum of the new state) and
+// v1 = imm @ p1 come from the GEMM; energy, weight, divergence, progressive uniform sampling with
+// key fold_in(integrator_key, step) (proposal.py:118-143) and the reservoir copy happen here.
+__global__ void __launch_bounds__(kBlock)
+k_mhmc_step_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64_t step, float thr,
+                  const float* __restrict__ logp0, const float* __restrict__ ke0,
+                  const float* __restrict__ q, const float* __restrict__ p1,
+                  const float* __restrict__ v1, const float* __restrict__ g,
+                  const float* __restrict__ logp_new, float* __restrict__ W, float* __restrict__ S,
+                  uint8_t* __restrict__ any_div, uint8_t* __restrict__ ever, float* __restrict__ Rq,
+                  float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
+                  float* __restrict__ Renergy) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const int64_t base = r * D;
+    double acc = 0.0;
+    for (int64_t j = lane; j < D; j += 64) acc += (double)v1[base + j] * (double)p1[base + j];
+    acc = wave_sum(acc);
+    const float ke = 0.5f * (float)acc;
+    const float lp = logp_new[r];
+    const float H0 = -logp0[r] + ke0[r];
+    const float e_new = -lp + ke;
+    float w = H0 - e_new;
+    if (w != w) w = -__builtin_inff();
+    const float s_new = fminf(w, 0.0f);
+    const bool is_div = (-w) > thr;
+    const float Wc = W[r];
+    const Key ki = key_child(chain_key(key, (uint64_t)(r + off), fold), 1);
+    const float u = key_uniform(key_child(ki, (uint64_t)step));
+    const float pa = (float)(1.0 / (1.0 + exp(-(double)(w - Wc))));  // expit
+    const bool take = u < pa;
+    auto lae = [](float a, float b) {  // np.logaddexp in fp64, rounded once
+      const double x = (double)a, y = (double)b;
+      if (x == y) return (float)(x + 0.6931471805599453);
+      const double t = x - y;
+      if (t > 0) return (float)(x + log1p(exp(-t)));
+      if (t <= 0) return (float)(y + log1p(exp(t)));
+      return (float)t;
+    };
+    const float Wn = lae(Wc, w), Sn = lae(S[r], s_new);
+    if (lane == 0) {
+      W[r] = Wn;
+      S[r] = Sn;
+      if (is_div) any_div[r] = 1;
+      if (take) {
+        ever[r] = 1;
+        Rlogp[r] = lp;
+        Renergy[r] = e_new;
+      }
+    }
+    if (take)
+      for (int64_t j = lane; j < D; j += 64) {
+        Rq[base + j] = q[base + j];
+        Rp[base + j] = p1[base + j];
+        Rg[base + j] = g[base + j];
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PER-CHAIN dense metric (one (D, D) matrix per chain: what a vmapped dense window_adaptation
 // produces).  Each chain has its own matrix, so this is a batched matrix-vector product, bound by
@@ -551,6 +647,9 @@ struct PcArgs {
   float* Y;             // EPI_STORE
   const float* Q_in;    // EPI_DRIFT
   float* Q_out;
+  float kick_a = 0.5f, kick_b = 0.5f, drift = 1.0f;  // as in GemmArgs
+  const int32_t* n_steps = nullptr;
+  int32_t step_idx = 0;
 };
 
 template <int EPI>
@@ -564,19 +663,24 @@ __global__ void __launch_bounds__(kBlock) k_pc_gemv(PcArgs a) {
     const int64_t c = base + wave;
     const bool ok = c < a.N;
     float e = 0.0f;
+    bool active = true;
     if (ok) {
       e = a.eps_pc ? a.eps_pc[c] : a.eps;
-      const float h = e * 0.5f;
+      const float ha = e * a.kick_a, hb = e * a.kick_b;
+      active = !a.n_steps || a.step_idx < a.n_steps[c];
       for (int64_t j = lane; j < a.D; j += 64) {
         float x = a.X[c * a.D + j];
         if (a.n_kicks > 0) {
-          const float g = a.G[c * a.D + j];
-          x = fmaf(h, g, x);
-          if (a.n_kicks == 2) x = fmaf(h, g, x);
+          if (active) {
+            const float g = a.G[c * a.D + j];
+            x = fmaf(ha, g, x);
+            if (a.n_kicks == 2) x = fmaf(hb, g, x);
+          }
           if (a.X_out) a.X_out[c * a.D + j] = x;
         }
         xs[j] = x;
       }
+      e = e * a.drift;
     }
     __syncthreads();
     if (ok) {
@@ -586,7 +690,7 @@ __global__ void __launch_bounds__(kBlock) k_pc_gemv(PcArgs a) {
         for (int64_t j = 0; j < a.D; ++j) acc += (double)m[j * a.D + i] * (double)xs[j];
         const float y = (float)acc;
         if constexpr (EPI == EPI_STORE) a.Y[c * a.D + i] = y;
-        else a.Q_out[c * a.D + i] = fmaf(e, y, a.Q_in[c * a.D + i]);
+        else a.Q_out[c * a.D + i] = active ? fmaf(e, y, a.Q_in[c * a.D + i]) : a.Q_in[c * a.D + i];
       }
     }
     __syncthreads();
@@ -855,6 +959,96 @@ int bjx_welford_final_dense(void* stream, int64_t N, int64_t D, int64_t sample_s
                      (hipStream_t)stream, total, D, (float)(sample_size - 1), beta_data, beta_prev,
                      reg, m2, imm_prev, (int64_t)imm_prev_per_chain, imm_out);
   return bjx_check_launch("bjx_welford_final_dense");
+}
+
+// ------------------------------------------------------------------ general coefficients / masks
+// matrix_stride < 0: ONE shared matrix on the MFMA GEMM path; 0 or D*D: the fp64-accumulated
+// matrix-vector path (shared or per-chain matrices), as in the *_pc entry points.
+int bjx_leapfrog_dense_coef(void* stream, int64_t N, int64_t D, int n_kicks, float kick_a, float kick_b,
+                            float drift, float eps, const float* eps_per_chain, const float* imm,
+                            int64_t matrix_stride, const float* q_in, const float* p_in, const float* g,
+                            float* q_out, float* p_out, const int32_t* n_steps, int32_t step_idx) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q_in && p_in && g && q_out && p_out &&
+                    (matrix_stride < 0 || matrix_stride == 0 || matrix_stride == D * D),
+                "bjx_leapfrog_dense_coef: bad arguments");
+  BJX_CHECK_ARG(n_kicks == 1 || n_kicks == 2, "bjx_leapfrog_dense_coef: n_kicks must be 1 or 2");
+  if (matrix_stride < 0) {
+    BJX_CHECK_ARG(p_out != p_in, "bjx_leapfrog_dense_coef: p_out must not alias p_in on the GEMM path");
+    GemmArgs ga{N, D, p_in, g, n_kicks, eps, eps_per_chain, p_out, imm, nullptr, q_in, q_out};
+    ga.b_symmetric = true;
+    ga.kick_a = kick_a; ga.kick_b = kick_b; ga.drift = drift;
+    ga.n_steps = n_steps; ga.step_idx = step_idx;
+    return launch_gemm((hipStream_t)stream, EPI_DRIFT, ga);
+  }
+  PcArgs pa{N, D, imm, matrix_stride, p_in, g, n_kicks, eps, eps_per_chain, p_out, nullptr, q_in, q_out};
+  pa.kick_a = kick_a; pa.kick_b = kick_b; pa.drift = drift;
+  pa.n_steps = n_steps; pa.step_idx = step_idx;
+  return launch_pc((hipStream_t)stream, EPI_DRIFT, pa);
+}
+
+int bjx_hmc_finish_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, float kick_coef, float eps,
+                              const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                              float divergence_threshold, const float* q0, const float* logp0,
+                              const float* g0, const float* ke0, const float* q1, const float* logp1,
+                              const float* g1, const float* p, float* p1_work, float* v_work,
+                              float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                              float* acceptance_rate_out, uint8_t* is_accepted_out,
+                              uint8_t* is_divergent_out, float* energy_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && logp0 && g0 && ke0 && q1 && logp1 && g1 && p &&
+                    p1_work && v_work && q_out && logp_out && g_out && acceptance_rate_out &&
+                    is_accepted_out && is_divergent_out && energy_out && p1_work != p &&
+                    (matrix_stride < 0 || matrix_stride == 0 || matrix_stride == D * D),
+                "bjx_hmc_finish_dense_coef: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  // closing kick fused into the product's prologue: p1 = p + (eps*kick_coef) g1 ; v1 = imm p1
+  if (matrix_stride < 0) {
+    GemmArgs ga{N, D, p, g1, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+    ga.b_symmetric = true;
+    ga.kick_a = kick_coef;
+    if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
+  } else {
+    PcArgs pa{N, D, imm, matrix_stride, p, g1, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+    pa.kick_a = kick_coef;
+    if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;
+  }
+  hipLaunchKernelGGL(k_hmc_finish_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
+                     Key{key0, key1}, chain_offset, step_fold, N, D, divergence_threshold, q0, logp0,
+                     g0, ke0, q1, logp1, g1, p1_work, v_work, p_end_out, q_out, logp_out, g_out,
+                     acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
+  return bjx_check_launch("bjx_hmc_finish_dense_coef");
+}
+
+int bjx_mhmc_step_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                        int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
+                        const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                        float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                        const float* p, const float* g, const float* logp_new, float* p1_work,
+                        float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                        uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                        float* prop_logp, float* prop_energy) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
+  BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
+                    p1_work && v_work && weight && sum_log_p_accept && any_divergent && ever_accepted &&
+                    prop_q && prop_p && prop_g && prop_logp && prop_energy && p1_work != p &&
+                    (matrix_stride < 0 || matrix_stride == 0 || matrix_stride == D * D),
+                "bjx_mhmc_step_dense: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (matrix_stride < 0) {  // closing half kick p1 = p + (eps/2) g ; v1 = imm p1
+    GemmArgs ga{N, D, p, g, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+    ga.b_symmetric = true;
+    if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
+  } else {
+    PcArgs pa{N, D, imm, matrix_stride, p, g, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+    if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;
+  }
+  hipLaunchKernelGGL(k_mhmc_step_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
+                     Key{key0, key1}, chain_offset, step_fold, N, D, step, divergence_threshold, logp0,
+                     ke0, q, p1_work, v_work, g, logp_new, weight, sum_log_p_accept, any_divergent,
+                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy);
+  return bjx_check_launch("bjx_mhmc_step_dense");
 }
 
 }  // extern "C"

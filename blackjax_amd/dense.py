@@ -56,3 +56,47 @@ def finish(stream, metric, k0, k1, off, fold, n, d, eps, eps_pc, thr, q0, logp0,
         _lib.call("bjx_hmc_finish_dense_pc", *head, d * d, *tail)
     else:
         _lib.call("bjx_hmc_finish_dense", *head, *tail)
+
+
+def matrix_stride(metric, d: int) -> int:
+    """``matrix_stride`` argument of the ``*_dense_coef`` entry points: < 0 = one shared matrix on
+    the MFMA GEMM path, ``d * d`` = one matrix per chain on the fp64 matrix-vector path."""
+    return d * d if metric.kind == "dense_pc" else -1
+
+
+def leapfrog_coef(stream, metric, n, d, n_kicks, kick_a, kick_b, drift, eps, eps_pc, q_in, p_in, g,
+                  q_out, p_out, n_steps=None, step_idx: int = 0):
+    """One position update of a general palindromic integrator (kicks ``eps*kick_a`` [, ``eps*kick_b``],
+    drift ``eps*drift``), optionally masked by per-chain trajectory lengths.  Returns the tensor that
+    holds the new momentum (the shared-matrix GEMM cannot update p in place)."""
+    ms = matrix_stride(metric, d)
+    if ms < 0 and p_out.data_ptr() == p_in.data_ptr():
+        p_out = torch.empty_like(p_in)
+    _lib.call("bjx_leapfrog_dense_coef", stream, n, d, n_kicks, kick_a, kick_b, drift, eps, _lib.ptr(eps_pc),
+              metric.imm.data_ptr(), ms, q_in.data_ptr(), p_in.data_ptr(), g.data_ptr(), q_out.data_ptr(),
+              p_out.data_ptr(), _lib.ptr(n_steps), int(step_idx))
+    return p_out
+
+
+def finish_coef(stream, metric, k0, k1, off, fold, n, d, kick_coef, eps, eps_pc, thr, q0, logp0, g0, ke0, q,
+                logp, g, p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div, energy):
+    p1 = torch.empty_like(p)
+    v = torch.empty_like(p)
+    _lib.call("bjx_hmc_finish_dense_coef", stream, k0, k1, off, fold, n, d, kick_coef, eps, _lib.ptr(eps_pc),
+              metric.imm.data_ptr(), matrix_stride(metric, d), thr, q0.data_ptr(), logp0.data_ptr(),
+              g0.data_ptr(), ke0.data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(),
+              p1.data_ptr(), v.data_ptr(), p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(),
+              g_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+
+
+def mhmc_step(stream, metric, k0, k1, off, fold, n, d, step, eps, eps_pc, thr, logp0, ke0, q, p, g, logp,
+              weight, slpa, any_div, ever, pq, pp, pg, plogp, penergy):
+    """Closing half kick + reservoir step of multinomial HMC; returns the fully kicked momentum."""
+    p1 = torch.empty_like(p)
+    v = torch.empty_like(p)
+    _lib.call("bjx_mhmc_step_dense", stream, k0, k1, off, fold, n, d, step, eps, _lib.ptr(eps_pc),
+              metric.imm.data_ptr(), matrix_stride(metric, d), thr, logp0.data_ptr(), ke0.data_ptr(),
+              q.data_ptr(), p.data_ptr(), g.data_ptr(), logp.data_ptr(), p1.data_ptr(), v.data_ptr(),
+              weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(),
+              pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr())
+    return p1

@@ -131,12 +131,14 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         k0, k1, fold = key_spec(rng_key)
         vg = value_and_grad(logdensity_fn)
         metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
-        if metric.kind != "diag":
-            raise NotImplementedError("dynamic_hmc is implemented for diagonal metrics only")
         eps, eps_pc = step_size_args(step_size, N, dev)
         stream = _lib.current_stream()
         off = int(chain_offset)
-        imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+        is_diag = metric.kind == "diag"
+        if is_diag:
+            imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+        else:
+            from . import dense
 
         n_steps = integration_steps_fn(state.random_generator_arg, *integration_steps_params)
         n_steps = n_steps.to(device=dev, dtype=torch.int32).contiguous()
@@ -146,40 +148,49 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
-                  p0.data_ptr(), ke0.data_ptr())
-        q, p = torch.empty_like(q0), torch.empty_like(q0)
-        if lo == hi:
-            # every chain integrates the same number of steps (e.g. a shared Halton counter after
-            # ChEES warmup): the plain, unmasked leapfrog kernel of blackjax_amd.hmc
-            _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                      q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
-            logp, g = eval_logdensity(vg, q)
-            for l in range(1, hi):
-                _lib.call("bjx_leapfrog_diag", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                          q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr())
-                logp, g = eval_logdensity(vg, q)
+        if is_diag:
+            _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
+                      p0.data_ptr(), ke0.data_ptr())
         else:
-            ns = n_steps.data_ptr()
-            _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                      q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), ns, 0)
+            dense.momentum(stream, metric, k0, k1, off, fold, N, D, p0, ke0)
+        q, p = torch.empty_like(q0), torch.empty_like(q0)
+        # every chain integrates the same number of steps (e.g. a shared Halton counter after ChEES
+        # warmup): the plain, unmasked kernels; otherwise chains with n_steps <= l are skipped (their q
+        # is unchanged, so the callable keeps returning the same (logp, g) for them)
+        ns = None if lo == hi else n_steps
+
+        def stage(n_k, l, q_in, p_in, g_in, p_out):
+            if not is_diag:  # dense metric: kick + GEMM / mat-vec + drift, masked by the chain's length
+                return dense.leapfrog_coef(stream, metric, N, D, n_k, 0.5, 0.5, 1.0, eps, eps_pc, q_in,
+                                           p_in, g_in, q, p_out, ns, l)
+            if ns is None:
+                _lib.call("bjx_leapfrog_diag", stream, N, D, n_k, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                          q_in.data_ptr(), p_in.data_ptr(), g_in.data_ptr(), q.data_ptr(), p_out.data_ptr())
+            else:
+                _lib.call("bjx_leapfrog_diag_masked", stream, N, D, n_k, eps, _lib.ptr(eps_pc), imm_p,
+                          imm_s, q_in.data_ptr(), p_in.data_ptr(), g_in.data_ptr(), q.data_ptr(),
+                          p_out.data_ptr(), ns.data_ptr(), l)
+            return p_out
+
+        p = stage(1, 0, q0, p0, g0, p)
+        logp, g = eval_logdensity(vg, q)
+        for l in range(1, hi):
+            p = stage(2, l, q, p, g, p)
             logp, g = eval_logdensity(vg, q)
-            for l in range(1, hi):
-                # chains with n_steps <= l are skipped; their q is unchanged so the callable keeps
-                # returning the same (logp, g) for them
-                _lib.call("bjx_leapfrog_diag_masked", stream, N, D, 2, eps, _lib.ptr(eps_pc), imm_p, imm_s,
-                          q.data_ptr(), p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr(), ns, l)
-                logp, g = eval_logdensity(vg, q)
 
         p_end, q_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         logp_new, acc_rate, energy = (torch.empty_like(logp0) for _ in range(3))
         is_acc = torch.empty(N, dtype=torch.bool, device=dev)
         is_div = torch.empty(N, dtype=torch.bool, device=dev)
-        _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, fold, N, D, eps, _lib.ptr(eps_pc), imm_p,
-                  imm_s, thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
-                  q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(), p_end.data_ptr(),
-                  q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(),
-                  is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        if is_diag:
+            _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, fold, N, D, eps, _lib.ptr(eps_pc), imm_p,
+                      imm_s, thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
+                      q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(), p_end.data_ptr(),
+                      q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(),
+                      is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        else:
+            dense.finish(stream, metric, k0, k1, off, fold, N, D, eps, eps_pc, thr, q0, logp0, g0, ke0, q,
+                         logp, g, p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div, energy)
         info = HMCInfo(p0, acc_rate, is_acc, is_div, energy, IntegratorState(q, p_end, logp, g),
                        n_steps)
         new_arg = next_random_arg_fn(state.random_generator_arg)

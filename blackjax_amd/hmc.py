@@ -104,18 +104,23 @@ def _build_mhmc_kernel(thr: float):
         k0, k1, fold = key_spec(rng_key)
         vg = value_and_grad(logdensity_fn)
         metric = metrics.default_metric(inverse_mass_matrix, N, D, q0.device)
-        if metric.kind != "diag":
-            raise NotImplementedError("multinomial HMC is implemented for diagonal metrics only")
         eps, eps_pc = step_size_args(step_size, N, q0.device)
         stream = _lib.current_stream()
         off = int(chain_offset)
         dev = q0.device
-        imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+        is_diag = metric.kind == "diag"
+        if is_diag:
+            imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
-        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
-                  p0.data_ptr(), ke0.data_ptr())
+        if is_diag:
+            _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s,
+                      p0.data_ptr(), ke0.data_ptr())
+        else:
+            from . import dense
+
+            dense.momentum(stream, metric, k0, k1, off, fold, N, D, p0, ke0)
         weight = torch.zeros_like(logp0)
         slpa = torch.full_like(logp0, float("-inf"))
         any_div = torch.zeros(N, dtype=torch.bool, device=dev)
@@ -123,7 +128,7 @@ def _build_mhmc_kernel(thr: float):
         pq, pp, pg = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         plogp, penergy = torch.empty_like(logp0), torch.empty_like(logp0)
         acc_rate = torch.empty_like(logp0)
-        if L > 0:
+        if L > 0 and is_diag:
             q, p = torch.empty_like(q0), torch.empty_like(q0)
             _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
                       q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
@@ -135,6 +140,19 @@ def _build_mhmc_kernel(thr: float):
                           logp.data_ptr(), weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(),
                           ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
                           plogp.data_ptr(), penergy.data_ptr())
+        elif L > 0:
+            # dense metric (shared matrix: MFMA GEMMs; per-chain matrices: fp64 matrix-vector kernels):
+            # opening kick + drift, callable, then closing kick + reservoir step; the next leapfrog
+            # starts from the fully kicked momentum with its own (separately rounded) opening kick
+            q, p_half = torch.empty_like(q0), torch.empty_like(q0)
+            p_half = dense.leapfrog(stream, metric, N, D, 1, eps, eps_pc, q0, p0, g0, q, p_half)
+            for i in range(L):
+                logp, g = eval_logdensity(vg, q)
+                p1 = dense.mhmc_step(stream, metric, k0, k1, off, fold, N, D, i, eps, eps_pc, thr, logp0,
+                                     ke0, q, p_half, g, logp, weight, slpa, any_div, ever, pq, pp, pg,
+                                     plogp, penergy)
+                if i + 1 < L:
+                    p_half = dense.leapfrog(stream, metric, N, D, 1, eps, eps_pc, q, p1, g, q, p_half)
         _lib.call("bjx_mhmc_finish", stream, N, D, L, q0.data_ptr(), p0.data_ptr(), g0.data_ptr(),
                   logp0.data_ptr(), ke0.data_ptr(), ever.data_ptr(), slpa.data_ptr(), pq.data_ptr(),
                   pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr(),
@@ -283,9 +301,6 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         off = int(chain_offset)
         dev = q0.device
         graphed = use_graph is True and L >= 1 and metric.kind == "diag" and not general
-        if general and metric.kind != "diag":
-            raise NotImplementedError(
-                f"{integrator!r} is implemented for diagonal metrics only (velocity_verlet for dense)")
 
         p0 = torch.empty_like(q0)
         ke0 = torch.empty_like(logp0)
@@ -372,23 +387,28 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 # generalized_two_stage_integrator (integrators.py:104-150): one launch per position
                 # update; the closing kick b_K of a step merges with the opening kick b_1 of the next
                 q, p = q_end[sl], p_work[sl]
-                args = (_lib.ptr(eb), m.imm.data_ptr(), m.imm_stride)
+
+                def stage(n_k, ka, kb, a_c, q_in, p_in, g_in, p_out):
+                    if m.kind == "diag":
+                        _lib.call("bjx_leapfrog_diag_coef", stream, n, D, n_k, ka, kb, a_c, eps, _lib.ptr(eb),
+                                  m.imm.data_ptr(), m.imm_stride, q_in.data_ptr(), p_in.data_ptr(),
+                                  g_in.data_ptr(), q.data_ptr(), p_out.data_ptr(), None, 0)
+                        return p_out
+                    from . import dense
+
+                    return dense.leapfrog_coef(stream, m, n, D, n_k, ka, kb, a_c, eps, eb, q_in, p_in,
+                                               g_in, q, p_out)
+
                 first = True
                 for _ in range(L):
                     for si, a_c in enumerate(drift_c):
                         if first:
-                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 1, kick_c[0], 0.0, a_c,
-                                      eps, *args, q0[sl].data_ptr(), p0[sl].data_ptr(),
-                                      g0[sl].data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)
+                            p = stage(1, kick_c[0], 0.0, a_c, q0[sl], p0[sl], g0[sl], p)
                             first = False
                         elif si == 0:
-                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 2, kick_c[-1], kick_c[0],
-                                      a_c, eps, *args, q.data_ptr(), p.data_ptr(), g.data_ptr(),
-                                      q.data_ptr(), p.data_ptr(), None, 0)
+                            p = stage(2, kick_c[-1], kick_c[0], a_c, q, p, g, p)
                         else:
-                            _lib.call("bjx_leapfrog_diag_coef", stream, n, D, 1, kick_c[si], 0.0, a_c,
-                                      eps, *args, q.data_ptr(), p.data_ptr(), g.data_ptr(),
-                                      q.data_ptr(), p.data_ptr(), None, 0)
+                            p = stage(1, kick_c[si], 0.0, a_c, q, p, g, p)
                         logp, g = eval_logdensity(vg, q)
                 eps_fin, eps_pc_fin = eps, eb
             else:
@@ -416,6 +436,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                           p.data_ptr(), p_end[sl].data_ptr(), q_new[sl].data_ptr(),
                           logp_new[sl].data_ptr(), g_new[sl].data_ptr(), acc_rate[sl].data_ptr(),
                           is_acc[sl].data_ptr(), is_div[sl].data_ptr(), energy[sl].data_ptr())
+            elif general:
+                from . import dense
+
+                dense.finish_coef(stream, m, k0, k1, boff, fold, n, D, kick_c[-1], eps_fin, eps_pc_fin, thr,
+                                  q0[sl], logp0[sl], g0[sl], ke0[sl], q, logp, g, p, p_end[sl], q_new[sl],
+                                  logp_new[sl], g_new[sl], acc_rate[sl], is_acc[sl], is_div[sl], energy[sl])
             else:
                 from . import dense
 

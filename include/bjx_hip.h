@@ -193,6 +193,42 @@ int bjx_leapfrog_dense(void* stream, int64_t N, int64_t D, int n_kicks, float ep
                        const float* eps_per_chain, const float* imm, const float* q_in,
                        const float* p_in, const float* g, float* q_out, float* p_out);
 
+/* Dense-metric counterparts of bjx_leapfrog_diag_coef / bjx_leapfrog_diag_masked,
+ * bjx_hmc_finish_diag_coef and bjx_mhmc_step_diag (the reference's
+ * multinomial_hmc_proposal, dynamic_hmc and palindromic integrators work with any metric,
+ * blackjax/mcmc/hmc.py:181-248, dynamic_hmc.py:65-126, integrators.py:335-369).
+ * matrix_stride < 0: ONE (D, D) matrix shared by all chains, applied on the fp32 MFMA GEMM
+ * (p_out must not alias p_in); matrix_stride = 0 or D*D: the fp64-accumulated matrix-vector kernels
+ * (shared matrix / one matrix per chain).  Kicks p += (eps*kick) g, drift q += (eps*drift) (imm p);
+ * n_steps / step_idx as in bjx_leapfrog_diag_masked (NULL = every chain advances). */
+int bjx_leapfrog_dense_coef(void* stream, int64_t N, int64_t D, int n_kicks, float kick_a, float kick_b,
+                            float drift, float eps, const float* eps_per_chain, const float* imm,
+                            int64_t matrix_stride, const float* q_in, const float* p_in, const float* g,
+                            float* q_out, float* p_out, const int32_t* n_steps, int32_t step_idx);
+
+int bjx_hmc_finish_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, float kick_coef, float eps,
+                              const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                              float divergence_threshold, const float* q0, const float* logp0,
+                              const float* g0, const float* ke0, const float* q1, const float* logp1,
+                              const float* g1, const float* p, float* p1_work, float* v_work,
+                              float* p_end_out, float* q_out, float* logp_out, float* g_out,
+                              float* acceptance_rate_out, uint8_t* is_accepted_out,
+                              uint8_t* is_divergent_out, float* energy_out);
+
+/* One step of multinomial HMC after the callable, dense metric: closing half kick p1 = p + (eps/2) g
+ * [-> p1_work], v1 = imm p1 [-> v_work], then energy, weight, divergence flag, progressive uniform
+ * sampling with key fold_in(integrator_key, step) and the reservoir copy of (q, p1, g).  The caller
+ * continues the trajectory from p1_work with bjx_leapfrog_dense(_coef) and n_kicks = 1. */
+int bjx_mhmc_step_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                        int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
+                        const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                        float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                        const float* p, const float* g, const float* logp_new, float* p1_work,
+                        float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                        uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                        float* prop_logp, float* prop_energy);
+
 /* Closing half kick + energies + Metropolis accept + select with a dense metric (same contract as
  * bjx_hmc_finish_diag).  p1_work, v_work: (N, D) scratch (p1_work must not alias p). */
 int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

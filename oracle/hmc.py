@@ -92,10 +92,11 @@ def default_metric(inverse_mass_matrix, n_chains=None, per_chain_diag=False,
         return Metric(imm, np.asarray(mass_matrix_sqrt).astype(f32), True, dense_accum)
     if imm.ndim == 3 and imm.shape[1] == imm.shape[2]:
         # one dense matrix PER CHAIN (what a vmapped dense window_adaptation produces)
-        L = np.linalg.cholesky(imm.astype(f64))
-        eye = np.broadcast_to(np.eye(imm.shape[1]), imm.shape)
-        mass_sqrt = np.linalg.solve(np.swapaxes(L, 1, 2), eye)  # L^{-T} per chain
-        return Metric(imm, mass_sqrt.astype(f32), True)
+        if mass_matrix_sqrt is None:
+            L = np.linalg.cholesky(imm.astype(f64))
+            eye = np.broadcast_to(np.eye(imm.shape[1]), imm.shape)
+            mass_matrix_sqrt = np.linalg.solve(np.swapaxes(L, 1, 2), eye)  # L^{-T} per chain
+        return Metric(imm, np.asarray(mass_matrix_sqrt).astype(f32), True)
     raise ValueError(
         "The mass matrix has the wrong number of dimensions:"
         f" expected 1 or 2, got {imm.ndim}."
@@ -210,7 +211,7 @@ def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matr
 
 def mhmc_kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
                 num_integration_steps: int, divergence_threshold: float = 1000.0,
-                chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False):
+                chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None):
     """blackjax.mhmc: hmc.build_kernel(build_proposal=multinomial_hmc_proposal)
     (hmc.py:181-248, 279-312) with static_progressive_integration (trajectory.py:170-232) and
     progressive_uniform_sampling (proposal.py:118-143), batched over chains."""
@@ -218,7 +219,8 @@ def mhmc_kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass
 
     N, D = state.position.shape
     L = int(num_integration_steps)
-    metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
+    if metric is None:
+        metric = default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
     keys = chain_keys(rng_key, N, chain_offset) if chain_keys_override is None else chain_keys_override
     kk = prng.split(keys, 2)  # hmc.py:299
     key_momentum, key_integrator = kk[:, 0], kk[:, 1]
@@ -277,7 +279,7 @@ class DynamicHMCState(NamedTuple):  # blackjax/mcmc/dynamic_hmc.py:39-52
 
 def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size,
                        inverse_mass_matrix, divergence_threshold: float = 1000.0,
-                       chain_offset: int = 0, steps_bounds=(1, 10)):
+                       chain_offset: int = 0, steps_bounds=(1, 10), metric=None):
     """blackjax/mcmc/dynamic_hmc.py:65-126 with the default callables
     ``integration_steps_fn = lambda key: randint(key, (), 1, 10)`` and
     ``next_random_arg_fn = lambda key: split(key)[1]``: every chain draws its own trajectory
@@ -287,12 +289,19 @@ def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size
     keys = chain_keys(rng_key, N, chain_offset)
     eps = np.broadcast_to(np.asarray(step_size, f32), (N,))
     imm = np.asarray(inverse_mass_matrix, f32)
+    if metric is None and imm.ndim >= 2 and imm.shape[-1] == imm.shape[-2] and (imm.ndim == 3 or imm.shape[0] != N):
+        metric = default_metric(imm, n_chains=N)  # a dense matrix (shared, or one per chain)
     outs = []
     for i in range(N):
         st_i = HMCState(state.position[i:i + 1], state.logdensity[i:i + 1], state.logdensity_grad[i:i + 1])
-        imm_i = imm if imm.ndim == 1 else imm[i]
+        imm_i = imm if (imm.ndim == 1 or metric is not None) else imm[i]
+        met_i = None
+        if metric is not None:  # ``metric``: a prepared (dense) Metric; per-chain matrices are sliced
+            met_i = metric
+            if metric.is_dense and metric.inverse_mass_matrix.ndim == 3:
+                met_i = Metric(metric.inverse_mass_matrix[i], metric.mass_matrix_sqrt[i], True, metric.dense_accum)
         outs.append(kernel(None, st_i, logdensity_fn, eps[i], imm_i, int(n_steps[i]),
-                           divergence_threshold, chain_keys_override=keys[i:i + 1]))
+                           divergence_threshold, chain_keys_override=keys[i:i + 1], metric=met_i))
     cat = lambda f: np.concatenate([f(o) for o in outs], 0)
     new = DynamicHMCState(cat(lambda o: o[0].position), cat(lambda o: o[0].logdensity),
                           cat(lambda o: o[0].logdensity_grad),

@@ -42,10 +42,11 @@ def one_step(state: ohmc.IntegratorState, step_size, logdensity_fn, metric, coef
 
 def hmc_kernel(rng_key, state: ohmc.HMCState, logdensity_fn, step_size, inverse_mass_matrix,
                num_integration_steps: int, coefficients, divergence_threshold: float = 1000.0,
-               chain_offset: int = 0):
+               chain_offset: int = 0, metric=None):
     """blackjax.hmc(..., integrator=<palindromic integrator>): hmc.py:279-312 / 153-176."""
     N, D = state.position.shape
-    metric = ohmc.default_metric(inverse_mass_matrix, n_chains=N)
+    if metric is None:
+        metric = ohmc.default_metric(inverse_mass_matrix, n_chains=N)
     kk = prng.split(ohmc.chain_keys(rng_key, N, chain_offset), 2)
     p0 = ohmc.sample_momentum(metric, kk[:, 0], D)
     z0 = ohmc.IntegratorState(state.position, p0, state.logdensity, state.logdensity_grad)

@@ -118,8 +118,6 @@ def test_regression_posterior_through_window_adaptation(dev, name, params, n_war
     ``algorithm(logposterior, **parameters)``."""
     N = 48
     algorithm = {"hmc": bjx.hmc, "nuts": bjx.nuts, "mhmc": bjx.mhmc}[name]
-    if name == "mhmc" and not is_diag:
-        pytest.skip("multinomial HMC with a dense metric: see tests/test_frows_dense_gpu.py")
     tree0 = {"log_scale": torch.zeros(N, device=dev), "coefs": torch.full((N,), 4.0, device=dev)}
     flat0, unravel = bjx.util.ravel_chain_pytree(tree0)
     fn = bjx.util.flat_logdensity(_regression_logposterior(dev), unravel)
