@@ -319,14 +319,15 @@ def bench_c2(args, ctx):
     n_sub = min(1024, N)
     timed_kernel = "bjx_leapfrog_diag"
 
-    def measure(chain_block, use_graph, collect_draws, steps=None, fn=None, eps=None, timing=True):
+    def measure(chain_block, use_graph, collect_draws, steps=None, fn=None, eps=None, timing=True, streams=1):
         """W warm-up + K timed transitions in one scheduling mode.  The warm-up runs EXACTLY the
         timed loop's body (bookkeeping torch ops and launch-timer events included) plus one priming
         pass: on a fresh box the first use of any kernel pages its code object in from disk, which
         must not land in the timed region."""
         steps = args.steps if steps is None else steps
         alg = bjx.hmc(target if fn is None else fn, args.eps if eps is None else eps, imm, L,
-                      chain_offset=rank * N, chain_block=chain_block, use_graph=use_graph)
+                      chain_offset=rank * N, chain_block=chain_block, use_graph=use_graph,
+                      streams=streams)
         state = alg.init(q_init)
         launches = L * ((N + chain_block - 1) // chain_block)
         # Sampling rate of the HIP-event brackets.  A bracket costs host time and drains the
@@ -372,7 +373,8 @@ def bench_c2(args, ctx):
 
         dt, per, t_enq = timed_region(ctx, one, steps)
         _lib.set_timer(None)
-        res = {"chain_block": chain_block, "hip_graph": bool(use_graph), "dt": dt, "per_rank_dt": per,
+        res = {"chain_block": chain_block, "hip_graph": bool(use_graph), "streams": streams, "dt": dt,
+               "per_rank_dt": per,
                "steps": steps, "ms_per_step": dt / steps * 1e3,
                "value": world * N * L * steps / dt,
                "host_enqueue_ms_per_step": t_enq / max(steps, 1) * 1e3,
@@ -390,16 +392,18 @@ def bench_c2(args, ctx):
         return res
 
     # ---- scheduling autotune (untimed, part of the warm-up)
-    candidates = [(blk_auto, False)]
+    # candidates: (chains per block, inner loop as a HIP graph, blocks in flight on their own streams)
+    candidates = [(blk_auto, False, 1)]
     if args.chain_block >= 0:
-        candidates = [(min(args.chain_block or N, N), bool(args.use_graph))]
+        candidates = [(min(args.chain_block or N, N), bool(args.use_graph), max(1, args.streams))]
     elif blk_auto < N:
-        candidates += [(blk_auto, True), (N, False)]
+        candidates += [(blk_auto, True, 1), (max(blk_auto // 2, 1024), False, 2), (N, False, 1)]
     tuning = {}
     if len(candidates) > 1:
-        for cb, gr in candidates:
+        for cb, gr, ns_ in candidates:
             try:
-                alg_t = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=cb, use_graph=gr)
+                alg_t = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=cb, use_graph=gr,
+                                streams=ns_)
                 st_t = alg_t.init(q_init)
                 for kk in bjx.random.split(bjx.random.key(777), 2):  # priming (and graph recording)
                     st_t, _ = alg_t.step(kk, st_t)
@@ -408,12 +412,13 @@ def bench_c2(args, ctx):
                 for kk in bjx.random.split(bjx.random.key(778), 2):
                     st_t, _ = alg_t.step(kk, st_t)
                 torch.cuda.synchronize()
-                tuning[(cb, gr)] = (time.perf_counter() - t_t) / 2 * 1e3
+                tuning[(cb, gr, ns_)] = (time.perf_counter() - t_t) / 2 * 1e3
                 del alg_t, st_t
             except Exception as e:  # a mode that cannot run here is simply not a candidate
-                tuning[(cb, gr)] = float("inf")
+                tuning[(cb, gr, ns_)] = float("inf")
                 if rank == 0:
-                    print(f"bench.py: candidate chain_block={cb} hip_graph={gr} failed: {e!r}", file=sys.stderr)
+                    print(f"bench.py: candidate chain_block={cb} hip_graph={gr} streams={ns_} failed: {e!r}",
+                          file=sys.stderr)
         if world > 1:  # every rank must benchmark the same mode
             t = torch.tensor([tuning[c] for c in candidates], device=ctx.coll_dev, dtype=torch.float64)
             ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
@@ -422,13 +427,13 @@ def bench_c2(args, ctx):
     else:
         best = candidates[0]
 
-    head = measure(best[0], best[1], True)  # THE timed region
+    head = measure(best[0], best[1], True, streams=best[2])  # THE timed region
     final_draws = ctx.gather_rows(head["state"].position[:256])  # the only thing that crosses xGMI
 
     # ---- extra regions (rank 0 timing only matters; all ranks run them so barriers line up)
     extras = not args.headline_only
     stream_m = cache_m = None
-    if head["launch"] is not None:
+    if head["launch"] is not None and head["streams"] == 1:  # concurrent blocks share the chip: not a clean per-launch time
         if head["chain_block"] >= N:
             stream_m = head
         else:
@@ -524,7 +529,7 @@ def bench_c2(args, ctx):
                        "ess_nonresonant for a meaningful figure")
     ess_nr = None
     if extras and not args.no_ess_nonresonant and args.steps >= 4:
-        m = measure(head["chain_block"], head["hip_graph"], True, eps=0.21, timing=False)
+        m = measure(head["chain_block"], head["hip_graph"], True, eps=0.21, timing=False, streams=head["streams"])
         ess_nr = ess_of(m["draws"], m["dt"])
         if ess_nr is not None:
             ess_nr.update({"eps": 0.21, "leapfrogs": L, "ms_per_step": m["ms_per_step"],
@@ -544,7 +549,7 @@ def bench_c2(args, ctx):
             "workload": f"C2: HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
                         f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
             "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
-            "chain_block": head["chain_block"], "hip_graph": head["hip_graph"],
+            "chain_block": head["chain_block"], "hip_graph": head["hip_graph"], "streams": head["streams"],
             "parallelism": f"chains sharded x{world}, no data-path collective",
         },
         "per_rank_ms_per_step": [p / args.steps * 1e3 for p in head["per_rank_dt"]],
@@ -554,8 +559,8 @@ def bench_c2(args, ctx):
         "ess": ess, "ess_nonresonant": ess_nr,
         "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
         "final_draws_gathered": list(final_draws.shape),
-        "scheduling_autotune_ms_per_step": {f"chain_block={cb},hip_graph={gr}": v
-                                            for (cb, gr), v in tuning.items()} or None,
+        "scheduling_autotune_ms_per_step": {f"chain_block={cb},hip_graph={gr},streams={ns_}": v
+                                            for (cb, gr, ns_), v in tuning.items()} or None,
         "torch_callable_mode": torch_mode,
         "roofline": roofline,
     }
@@ -657,6 +662,8 @@ def main():
                     help="chains per launch: -1 = autotune, 0 = all chains at once, n = n chains")
     ap.add_argument("--use-graph", action="store_true",
                     help="with an explicit --chain-block: the block's inner loop as a HIP graph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="chain blocks advanced concurrently on their own HIP streams (c2)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only THE timed region (no roofline/torch-callable/ESS extra regions)")
     ap.add_argument("--no-torch-callable", action="store_true")

@@ -237,8 +237,18 @@ class _GraphedTrajectory:
         return logp, g
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(dev, n):
+    pool = _SIDE_STREAMS.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: float = 1000,
-                 build_proposal=None, *, chain_block=None, use_graph="auto"):
+                 build_proposal=None, *, chain_block=None, use_graph="auto", streams="auto"):
     """blackjax/mcmc/hmc.py:251-314.  ``build_proposal`` other than the default endpoint
     proposal (hmc_proposal, 115-178) is out of scope.
 
@@ -249,6 +259,13 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     identical for any blocking (per-chain keys depend only on the global chain index).
     ``chain_block="auto"`` sizes the block for the 256 MiB Infinity Cache (``auto_chain_block``);
     measured at 65 536 x 1 024, L = 50: +12 % whole-transition throughput over one block.
+
+    ``streams``: chain blocks advanced concurrently, each on its own HIP stream (blocks are
+    independent; results are identical for any value), so that one block's callable and launch
+    ramps overlap another block's kernels.  Measured: 65 536 x 1 024 diagonal, two blocks of 8 192
+    in flight 234.5 vs 228.0 M/s with one stream (+2.9 %; the host then issues launches for two
+    queues); 16 384 x 512 dense, two half batches: the GEMM launches shorten from 91 to 83 us each
+    but the transition does not (2.46 vs 2.42 ms).  ``"auto"`` = 1.
 
     ``use_graph``: capture the per-block inner loop (the user's callable included) in a HIP
     graph (diagonal metric; the callable must be capturable: static shapes, no host sync).
@@ -314,9 +331,16 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         is_div = torch.empty(N, dtype=torch.bool, device=dev)
 
         cb = chain_block
+        n_streams = streams
+        if n_streams == "auto":
+            n_streams = 1
         if cb == "auto":  # Infinity-Cache tiling pays for the streaming (diagonal) kernels only
-            cb = (auto_chain_block(N, D, 3 + (1 if metric.imm_stride else 0))
-                  if metric.kind == "diag" else N)
+            if metric.kind == "diag":
+                cb = auto_chain_block(N, D, 3 + (1 if metric.imm_stride else 0))
+            elif metric.kind == "dense" and int(n_streams) > 1:
+                cb = -(-N // int(n_streams) // 128) * 128  # equal blocks of whole 128-row GEMM tiles
+            else:
+                cb = N
         blk = N if not cb or cb >= N else int(cb)
         n_blocks = (N + blk - 1) // blk if N else 0
         fn_id = id(logdensity_fn)  # graphs are keyed on the USER's callable (and hold it)
@@ -346,7 +370,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         if L == 0:
             g_end, logp_end = g0, logp0
 
-        for b in range(n_blocks):
+        def run_block(b):
+            """One chain block's transition as a generator: yields after every log-density
+            evaluation so that several blocks can be advanced in turn on their own streams."""
+            nonlocal g_end, logp_end
+            stream = _lib.current_stream()
             s, e = b * blk, min(N, (b + 1) * blk)
             n = e - s
             sl = slice(s, e)
@@ -410,14 +438,20 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                         else:
                             p = stage(1, kick_c[si], 0.0, a_c, q, p, g, p)
                         logp, g = eval_logdensity(vg, q)
+                        yield
+                        stream = _lib.current_stream()
                 eps_fin, eps_pc_fin = eps, eb
             else:
                 q, p = q_end[sl], p_work[sl]
                 p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
                 logp, g = eval_logdensity(vg, q)
                 for _ in range(L - 1):
+                    yield
+                    stream = _lib.current_stream()
                     p = _launch_leapfrog(stream, m, n, D, 2, eps, eb, q, p, g, q, p)
                     logp, g = eval_logdensity(vg, q)
+                yield
+                stream = _lib.current_stream()
                 eps_fin, eps_pc_fin = eps, eb
 
             if m.kind == "diag" and general:
@@ -458,6 +492,32 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                     if graphed:
                         q_end[sl].copy_(q)
 
+
+        # Blocks are independent, so up to `n_streams` of them are advanced in turn, each on its own
+        # HIP stream: one block's callable (bandwidth-bound), the start-up of its launches and the
+        # output drain of a dense-metric GEMM then overlap another block's kernels.
+        ns = 1 if (graphed or n_blocks <= 1) else min(int(n_streams), n_blocks)
+        if ns <= 1:
+            for b in range(n_blocks):
+                for _ in run_block(b):
+                    pass
+        else:
+            main = torch.cuda.current_stream(dev)
+            pool = _side_streams(dev, ns)
+            for st_ in pool:
+                st_.wait_stream(main)
+            for w0 in range(0, n_blocks, ns):
+                active = [(run_block(b), pool[b - w0]) for b in range(w0, min(w0 + ns, n_blocks))]
+                while active:
+                    for item in list(active):
+                        with torch.cuda.stream(item[1]):
+                            try:
+                                next(item[0])
+                            except StopIteration:
+                                active.remove(item)
+            for st_ in pool:
+                main.wait_stream(st_)
+
         if n_blocks == 0 and L > 0:
             g_end, logp_end = g0, logp0
         info = HMCInfo(p0, acc_rate, is_acc, is_div, energy,
@@ -471,11 +531,11 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix,
                      num_integration_steps: int, *, divergence_threshold: float = 1000,
                      integrator=integrators.velocity_verlet, build_proposal=None,
                      chain_offset: int = 0, chain_block=None,
-                     use_graph="auto") -> SamplingAlgorithm:
+                     use_graph="auto", streams="auto") -> SamplingAlgorithm:
     """blackjax/mcmc/hmc.py:317-414.  ``chain_offset`` is this process' first global chain
     index when the chains of one run are sharded over several GPUs."""
     kernel = build_kernel(integrator, divergence_threshold, build_proposal,
-                          chain_block=chain_block, use_graph=use_graph)
+                          chain_block=chain_block, use_graph=use_graph, streams=streams)
 
     def init_fn(position, rng_key=None):
         del rng_key

@@ -21,12 +21,13 @@ ap.add_argument("--dim", type=int, default=512)
 ap.add_argument("--leapfrogs", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--streams", default="auto", help="chain blocks in flight (auto = 2 for a shared dense metric)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 N, D, L = args.chains, args.dim, args.leapfrogs
 tgt = bjx.targets.AR1Gaussian(0.9, D)
 cov = tgt.covariance(dev)
-alg = bjx.hmc(tgt, 0.5, cov, L)
+alg = bjx.hmc(tgt, 0.5, cov, L, streams=args.streams if args.streams == "auto" else int(args.streams))
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 state = alg.init(torch.randn(N, D, device=dev, generator=g))
@@ -49,7 +50,8 @@ flops = 2.0 * N * D * D
 print(json.dumps({
     "metric": "dense-mass HMC chain-leapfrog-steps/s", "value": N * L * args.steps / dt,
     "unit": "chain-leapfrog-steps/s",
-    "config": {"workload": f"dense HMC, AR(1) rho=0.9 D={D}, {N} chains, L={L}, eps=0.5"},
+    "config": {"workload": f"dense HMC, AR(1) rho=0.9 D={D}, {N} chains, L={L}, eps=0.5",
+               "streams": args.streams},
     "ms_per_transition": dt / args.steps * 1e3, "mean_acceptance": float(info.acceptance_rate.mean()),
     "roofline": {"bound": "mfma", "kernel": "k_dense_gemm<EPI_DRIFT>", "achieved": flops / avg / 1e12,
                  "peak": 157.3, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / 157.3,
