@@ -13,7 +13,7 @@ from . import dynamic_hmc as _dynamic_hmc
 from . import hmc as _hmc
 from . import nuts as _nuts
 from . import adaptation, chees, diagnostics, distributed, integrators, metrics, optim, random, targets, util
-from .adaptation import window_adaptation
+from .adaptation import staged_adaptation, window_adaptation
 from .chees import chees_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
 from ._util import capturable
@@ -52,4 +52,4 @@ dynamic_hmc.halton_sequence = _dynamic_hmc.halton_sequence
 dynamic_hmc.halton_steps_fn = _dynamic_hmc.halton_steps_fn
 dhmc = dynamic_hmc  # blackjax/__init__.py alias used by the ChEES examples
 
-__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "window_adaptation", "chees_adaptation", "chees", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]
+__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "chees", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]

@@ -25,7 +25,7 @@ from ._util import check_batch
 from .base import AdaptationAlgorithm
 from .random import ChainMajorKey, key_words
 
-__all__ = ["window_adaptation", "build_schedule", "free_running_table", "AdaptationResults", "AdaptationInfo",
+__all__ = ["window_adaptation", "staged_adaptation", "build_schedule", "free_running_table", "AdaptationResults", "AdaptationInfo",
            "return_all_adapt_info", "get_filter_adapt_info_fn", "DualAveragingAdaptationState",
            "WelfordAlgorithmState", "MassMatrixAdaptationState", "StagedAdaptationState"]
 
@@ -227,7 +227,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                       initial_inverse_mass_matrix=None, imm_shrinkage_to_previous: float = 0.0,
                       initial_step_size: float = 1.0, target_acceptance_rate: float = 0.80,
                       adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
-                      integrator=integrators.velocity_verlet, **extra_parameters) -> AdaptationAlgorithm:
+                      integrator=integrators.velocity_verlet, _schedule_fn: Optional[Callable] = None,
+                      **extra_parameters) -> AdaptationAlgorithm:
     """blackjax/adaptation/window_adaptation.py:296-444.  ``algorithm`` is ``blackjax_amd.hmc`` or
     ``blackjax_amd.nuts``; ``extra_parameters`` are forwarded to its kernel (e.g.
     ``num_integration_steps=...``).  ``adaptation_info_fn=None`` records nothing.
@@ -274,6 +275,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                              "pass adaptation_info_fn=None (or the default) with it")
         if integrator is not integrators.velocity_verlet:
             raise NotImplementedError("free_running=True is implemented for velocity_verlet only")
+        if _schedule_fn is not None:
+            raise NotImplementedError("free_running=True uses the Stan schedule (build_schedule)")
         n, d = state.position.shape
         dev = state.position.device
         extra = dict(extra_parameters)
@@ -327,7 +330,9 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             ss, MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, m2_0, 0)), eps0, imm)
         history = []
         info = None
-        for t, (stage, is_window_end) in enumerate(build_schedule(int(num_steps))):
+        schedule = build_schedule(int(num_steps)) if _schedule_fn is None else _as_schedule(
+            _schedule_fn(int(num_steps)), int(num_steps))
+        for t, (stage, is_window_end) in enumerate(schedule):
             # one_step: staged_adaptation.py:731-754
             imm_arg = ws.inverse_mass_matrix
             if is_mass_matrix_diagonal and imm_arg.ndim == 2:  # per-chain diagonals, not a dense matrix
@@ -361,3 +366,62 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         return AdaptationResults(state, parameters), _stack_history(history)
 
     return AdaptationAlgorithm(run)
+
+
+def _as_schedule(sched, num_steps: int) -> list:
+    """A ``schedule_fn`` result -- ``(num_steps, 2)`` array-like of ``(stage, is_window_end)`` as in
+    staged_adaptation.py:315-405 -- as the list of pairs the engine loops over."""
+    rows = [(int(a), bool(b)) for a, b in np.asarray(sched).reshape(-1, 2).tolist()]
+    if len(rows) != num_steps or any(st not in (0, 1) for st, _ in rows):
+        raise ValueError("schedule_fn(num_steps) must return num_steps rows of (stage in {0, 1}, is_window_end)")
+    return rows
+
+
+_RECIPES = {"welford_diag": True, "welford_dense": False}
+
+
+def staged_adaptation(algorithm, logdensity_fn: Callable, metric: str = "welford_diag", *,
+                      max_grad_budget=None, n_chains: int = 1, imm_shrinkage_to_previous: float = 0.0,
+                      initial_inverse_mass_matrix=None, initial_step_size: float = 1.0,
+                      target_acceptance_rate: float = 0.80,
+                      adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
+                      integrator=integrators.velocity_verlet, schedule_fn: Optional[Callable] = None,
+                      initial_metric_state=None, **extra_parameters) -> AdaptationAlgorithm:
+    """The engine entry point of blackjax/adaptation/staged_adaptation.py:519-983, of which
+    ``window_adaptation`` is the compatibility shim (window_adaptation.py:427-444).
+
+    ``metric``: the registry names of the Welford recipes, ``"welford_diag"`` (default) and
+    ``"welford_dense"`` (adaptation/metric_recipes.py:961-989); ``schedule_fn(num_steps)`` replaces
+    the Stan schedule exactly as in the reference (an explicit callable is always honoured).
+    As everywhere in this engine the chain axis is native: ``run(rng_key, position)`` takes ``(N, D)``
+    positions and adapts every chain on its own (the reference's ``n_chains = 1`` path under ``vmap``),
+    so ``n_chains`` must stay 1.
+
+    Out of scope: ``metric="auto"`` -- the experimental
+    meta-adaptation controller with low-rank escalation and its multi-chain pooled gate
+    (adaptation/meta/, ~3 200 lines) --, ``"fisher_diag"``, ``MetricCore`` / ``MetricRecipe`` objects,
+    ``initial_metric_state``.  For thousands of chains the pooled warm-up this engine offers is
+    ``chees_adaptation`` (what the reference recommends for that regime,
+    docs/examples/howto_sample_multiple_chains.md:246)."""
+    if n_chains < 1:
+        raise ValueError(f"staged_adaptation: n_chains must be >= 1, got {n_chains}.")
+    if n_chains > 1 and metric != "auto":
+        raise ValueError(
+            "staged_adaptation: n_chains > 1 is only supported with metric='auto' "
+            "(the multi-chain pooled gate is implemented in the meta-adaptation "
+            "controller). For other metric strings pass n_chains=1 (default) and "
+            "vmap the warmup call externally.")
+    if not isinstance(metric, str) or metric not in _RECIPES:
+        raise NotImplementedError(
+            f"staged_adaptation(metric={metric!r}): this engine builds the Welford recipes "
+            f"{sorted(_RECIPES)}; 'auto' (experimental meta-adaptation), 'fisher_diag' and MetricCore / "
+            "MetricRecipe objects are outside the hot path it replaces (SURVEY.md section 2)")
+    if initial_metric_state is not None or max_grad_budget is not None:
+        raise NotImplementedError("initial_metric_state / max_grad_budget belong to the meta-adaptation path")
+    return window_adaptation(algorithm, logdensity_fn, is_mass_matrix_diagonal=_RECIPES[metric],
+                             initial_inverse_mass_matrix=initial_inverse_mass_matrix,
+                             imm_shrinkage_to_previous=imm_shrinkage_to_previous,
+                             initial_step_size=initial_step_size,
+                             target_acceptance_rate=target_acceptance_rate,
+                             adaptation_info_fn=adaptation_info_fn, integrator=integrator,
+                             _schedule_fn=schedule_fn, **extra_parameters)

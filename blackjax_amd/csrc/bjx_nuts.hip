@@ -1154,12 +1154,12 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   const int idx_min = idx_max - nsub + 1;
   const bool even = (us & 1u) == 0u;
 
-  int64_t j0[NI];
+  uint32_t j0[NI];  // 32-bit element offsets: rows are addressed as (uniform base) + (32-bit lane offset)
   bool ok[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    j0[k] = ((int64_t)lane + 64 * k) * VEC;
-    ok[k] = j0[k] < nt.D;
+    j0[k] = ((uint32_t)lane + 64u * k) * VEC;
+    ok[k] = j0[k] < (uint32_t)nt.D;
   }
   // second round trip, issued now: first checkpoint level of an odd leaf, merge rows of a last leaf
   const int other_bit = dir > 0 ? LZ_L : LZ_R;
@@ -1424,12 +1424,12 @@ __device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx
   int32_t t = ax.t[c];
   const int64_t base = c * nt.D;
   float* qrow = qf + b * nt.D;
-  int64_t j0[NI];
+  uint32_t j0[NI];  // 32-bit element offsets: rows are addressed as (uniform base) + (32-bit lane offset)
   bool ok[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    j0[k] = ((int64_t)lane + 64 * k) * VEC;
-    ok[k] = j0[k] < nt.D;
+    j0[k] = ((uint32_t)lane + 64u * k) * VEC;
+    ok[k] = j0[k] < (uint32_t)nt.D;
   }
   Row<VEC> Q[NI], G[NI];
   float lp;
@@ -1567,8 +1567,8 @@ __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_
     lp = logp_f[b];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int64_t j = ((int64_t)lane + 64 * k) * VEC;
-      if (j < nt.D) {
+      const uint32_t j = ((uint32_t)lane + 64u * k) * VEC;
+      if (j < (uint32_t)nt.D) {
         R.G[k] = ldr<VEC>(gf + b * nt.D + j);
         R.M[k] = ldr<VEC>(im + j);
         R.P[k] = ldr<VEC>(ax.front_p + base + j);

@@ -187,7 +187,7 @@ def window_adaptation_run(rng_key, position, logdensity_fn, num_steps, num_integ
                           is_mass_matrix_diagonal=True, initial_step_size=1.0,
                           target_acceptance_rate=0.8, initial_inverse_mass_matrix=None,
                           imm_shrinkage_to_previous=0.0, chain_offset=0, kernel_fn=None,
-                          chain_keys_override=None):
+                          chain_keys_override=None, schedule=None):
     """window_adaptation(hmc, ...).run (window_adaptation.py:296-444 ->
     staged_adaptation.py:860-876,968-981), batched per chain, chain-major keys.
     ``chain_keys_override``: the chain keys ``c_i`` of an arbitrary subset of global chain indices
@@ -197,7 +197,8 @@ def window_adaptation_run(rng_key, position, logdensity_fn, num_steps, num_integ
     ws = adapt_init(N, D, initial_step_size, is_mass_matrix_diagonal, initial_inverse_mass_matrix)
     chain_keys = (prng.split(rng_key, N, offset=chain_offset) if chain_keys_override is None
                   else np.asarray(chain_keys_override, np.uint32))  # c_i
-    schedule = build_schedule(num_steps)
+    if schedule is None:  # staged_adaptation's schedule_fn hook: any list of (stage, is_window_end)
+        schedule = build_schedule(num_steps)
     history = []
     for t, (stage, is_end) in enumerate(schedule):
         keys_t = prng.fold_in(chain_keys, np.uint32(t))  # split(c_i, T)[t]

@@ -110,3 +110,36 @@ def test_window_adaptation_validation():
         bjx.window_adaptation(bjx.hmc, lambda q: q, initial_inverse_mass_matrix=np.eye(3))
     with pytest.raises(ValueError):
         bjx.window_adaptation(bjx.hmc, lambda q: q, imm_shrinkage_to_previous=-1.0)
+
+
+def test_staged_adaptation_engine_entry_and_schedule_fn(dev):
+    """blackjax.staged_adaptation(algorithm, logdensity_fn, metric="welford_diag") is the engine the
+    window_adaptation shim delegates to (window_adaptation.py:427-444): same results bit for bit; a
+    custom schedule_fn (staged_adaptation.py: "an explicit callable is always honored") is followed
+    step by step -- checked against the oracle run on the same schedule."""
+    N, D, L, T = 12, 20, 5, 36
+    sig = (10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32)
+    inv_var = (np.float32(1) / (sig * sig)).astype(np.float32)
+    fn = bjx.targets.DiagGaussian(dev_t(inv_var, dev))
+    q0 = (prng.normal(prng.key(3), (N, D)) * sig).astype(np.float32)
+    (s_w, p_w), _ = bjx.window_adaptation(bjx.hmc, fn, num_integration_steps=L).run(prng.key(5), dev_t(q0, dev), T)
+    (s_s, p_s), _ = bjx.staged_adaptation(bjx.hmc, fn, metric="welford_diag",
+                                          num_integration_steps=L).run(prng.key(5), dev_t(q0, dev), T)
+    assert torch.equal(s_w.position, s_s.position) and torch.equal(p_w["step_size"], p_s["step_size"])
+    assert torch.equal(p_w["inverse_mass_matrix"], p_s["inverse_mass_matrix"])
+
+    def two_windows(num_steps):  # 4 fast steps, two slow windows of 12 and 16, 4 fast steps
+        rows = [(0, False)] * 4 + [(1, False)] * 11 + [(1, True)] + [(1, False)] * 15 + [(1, True)] + [(0, False)] * 4
+        assert len(rows) == num_steps
+        return np.asarray(rows, dtype=np.int32)
+
+    (s_c, p_c), info = bjx.staged_adaptation(bjx.hmc, fn, schedule_fn=two_windows,
+                                             num_integration_steps=L).run(prng.key(5), dev_t(q0, dev), T)
+    st_o, par_o, hist_o = oad.window_adaptation_run(prng.key(5), q0, otargets.diag_gaussian(inv_var), T, L,
+                                                    schedule=[(int(a), bool(b)) for a, b in two_windows(T)])
+    eps_g = t2n(info.adaptation_state.step_size)
+    for t in range(T):
+        np.testing.assert_allclose(eps_g[t], hist_o[t][1], rtol=1e-6)
+    np.testing.assert_allclose(t2n(p_c["inverse_mass_matrix"]), par_o["inverse_mass_matrix"], rtol=1e-6)
+    np.testing.assert_allclose(t2n(s_c.position), st_o.position, rtol=1e-6, atol=1e-6)
+    assert not torch.equal(p_c["inverse_mass_matrix"], p_w["inverse_mass_matrix"])  # the schedule mattered

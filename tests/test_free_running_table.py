@@ -39,3 +39,29 @@ def test_table_follows_schedule(T, shrink):
             assert not tab[t, AT["FIN_NM1"]:AT["FIN_REG"] + 1].any()
     if T >= 20:
         assert any(end for _, end in sched), "a schedule of >= 20 steps has at least one window end"
+
+
+def test_staged_adaptation_entry_point_validation_and_schedule_fn():
+    """blackjax/adaptation/staged_adaptation.py:519-983: the engine entry point -- recipe names, the
+    reference's n_chains error, out-of-scope metrics, and a custom schedule_fn's shape check (no GPU
+    needed: construction-time behaviour only)."""
+    import pytest
+
+    import blackjax_amd as bjx
+    from blackjax_amd import adaptation as bad
+
+    fn = lambda q: q.sum(-1)
+    for name in ("welford_diag", "welford_dense"):
+        assert callable(bjx.staged_adaptation(bjx.hmc, fn, metric=name, num_integration_steps=3).run)
+    with pytest.raises(ValueError, match="n_chains > 1 is only supported"):
+        bjx.staged_adaptation(bjx.hmc, fn, n_chains=4)
+    with pytest.raises(ValueError, match="n_chains must be >= 1"):
+        bjx.staged_adaptation(bjx.hmc, fn, n_chains=0)
+    for bad_metric in ("auto", "fisher_diag", object()):
+        with pytest.raises(NotImplementedError):
+            bjx.staged_adaptation(bjx.hmc, fn, metric=bad_metric)
+    assert bad._as_schedule([[0, False], [1, False], [1, True]], 3) == [(0, False), (1, False), (1, True)]
+    with pytest.raises(ValueError):
+        bad._as_schedule([[0, False]], 3)
+    with pytest.raises(ValueError):
+        bad._as_schedule([[2, False]], 1)
