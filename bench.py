@@ -380,7 +380,8 @@ def bench_c2(args, ctx):
                "host_enqueue_ms_per_step": t_enq / max(steps, 1) * 1e3,
                "gpu_ms_of_each_step": [round(a.elapsed_time(b), 3) for a, b in zip(marks, marks[1:])],
                "mean_acceptance": float(acc_sum.item()) / max(steps, 1), "draws": draws,
-               "state": box["state"], "launch": None}
+               "state": box["state"], "launch": None,
+               "timed": bool(timing)}  # rank independent (the events themselves are rank 0's only)
         if timer is not None:
             d_ms = timer.durations_ms(timed_kernel)
             avg_s = float(np.mean(d_ms)) * 1e-3
@@ -433,7 +434,8 @@ def bench_c2(args, ctx):
     # ---- extra regions (rank 0 timing only matters; all ranks run them so barriers line up)
     extras = not args.headline_only
     stream_m = cache_m = None
-    if head["launch"] is not None and head["streams"] == 1:  # concurrent blocks share the chip: not a clean per-launch time
+    # (every rank takes the same branches here: the extra regions contain barriers)
+    if head["timed"] and head["streams"] == 1:  # concurrent blocks share the chip: not a clean per-launch time
         if head["chain_block"] >= N:
             stream_m = head
         else:
@@ -445,7 +447,7 @@ def bench_c2(args, ctx):
             cache_m = measure(blk_auto, False, False)
 
     roofline = None
-    if rank == 0 and (stream_m or cache_m):
+    if rank == 0 and ((stream_m and stream_m["launch"]) or (cache_m and cache_m["launch"])):
         flat = D % 1024 == 0 and os.environ.get("BJX_LF_FLAT", "1") != "0"
         src = stream_m or cache_m
         la = src["launch"]

@@ -130,11 +130,14 @@ k_neal_funnel(int64_t N, int64_t D, const float* __restrict__ q, float* __restri
 // sits between every two ticks of a NUTS run, where a tick is a few microseconds of dependent work.
 // fp64 accumulation as above (the summation order differs, the fp64 sum rounds to the same fp32).
 template <int NI>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(64)
 k_neal_funnel_v4(int64_t N, int64_t D, const float* __restrict__ q, float* __restrict__ logp,
                  float* __restrict__ g) {
   const int lane = threadIdx.x & 63;
-  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+  // one wave per WORKGROUP, row r in workgroup r: the same row -> XCD mapping as the NUTS tick kernels
+  // (workgroup b runs on XCD b % 8), so the positions a tick wrote and the gradient this kernel
+  // writes are found in the L2 of the XCD that uses them next
+  for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
     const int64_t base = r * D;
     F4 x[NI];
     double S = 0.0;
@@ -237,9 +240,10 @@ int bjx_target_neal_funnel(void* stream, int64_t N, int64_t D, const float* q, f
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock));
   hipStream_t st = (hipStream_t)stream;
   if (bjx_vec4_ok(D, q, g_out) && D <= 1024) {
-    if (D <= 256) hipLaunchKernelGGL(k_neal_funnel_v4<1>, grid, dim3(kBlock), 0, st, N, D, q, logp_out, g_out);
-    else if (D <= 512) hipLaunchKernelGGL(k_neal_funnel_v4<2>, grid, dim3(kBlock), 0, st, N, D, q, logp_out, g_out);
-    else hipLaunchKernelGGL(k_neal_funnel_v4<4>, grid, dim3(kBlock), 0, st, N, D, q, logp_out, g_out);
+    const dim3 wgrid((unsigned)(N < ((int64_t)1 << 20) ? N : ((int64_t)1 << 20)));
+    if (D <= 256) hipLaunchKernelGGL(k_neal_funnel_v4<1>, wgrid, dim3(64), 0, st, N, D, q, logp_out, g_out);
+    else if (D <= 512) hipLaunchKernelGGL(k_neal_funnel_v4<2>, wgrid, dim3(64), 0, st, N, D, q, logp_out, g_out);
+    else hipLaunchKernelGGL(k_neal_funnel_v4<4>, wgrid, dim3(64), 0, st, N, D, q, logp_out, g_out);
   } else {
     hipLaunchKernelGGL(k_neal_funnel, grid, dim3(kBlock), 0, st, N, D, q, logp_out, g_out);
   }

@@ -1,0 +1,29 @@
+#!/bin/bash
+# One-box summary of a round: full GPU test suite, smoke(), every bench (C2 default, C2 at 2 gloo ranks
+# on one GPU, C4 shard through bench.py --config c4, C3 NUTS free-running T = 20 / 100 / 400 + lockstep,
+# C5 dense, ChEES at C2, NUTS warm-up) and the rocprofv3 kernel stats of the NUTS and dense runs.
+# Outputs land in gpurun_out/round_summary/; tools/collect_summary.py <round> turns them into
+# profiles/<round>/summary_final_<round>.json and copies the kernel-stats CSVs.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/round_summary
+rm -rf $O; mkdir -p $O
+cd $R
+(time timeout 1500 python -m pytest tests/ -q -m gpu) > $O/gpu_tests.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+BJX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --headline-only --no-cpu-baseline > $O/bench_c2_2ranks_one_gpu.json 2> $O/bench_2r.err
+python bench.py --config c4 --steps 100 --warmup 20 > $O/bench_c4.json 2> $O/bench_c4.err
+for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --steps $T --no-tick-timing > $O/nuts_c3_T$T.json 2>> $O/nuts.err; done
+timeout 600 python tools/bench_nuts.py --use-graph --steps 5 > $O/nuts_c3_lockstep.json 2>> $O/nuts.err
+python tools/bench_dense.py > $O/dense_c5.json 2> $O/dense.err
+python tools/bench_chees.py > $O/chees_c2.json 2> $O/chees.err
+python tools/bench_nuts_warmup.py > $O/nuts_warmup_c3.json 2> $O/nuts_warmup.err
+python tools/bench_small.py > $O/hmc_small.json 2> $O/small.err
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_nuts -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing > $O/kt_nuts.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dense -- python $R/tools/bench_dense.py > $O/kt_dense.log 2>&1
+cd $R
+python tools/nuts_trace_phases.py $(ls $O/kt_nuts/*/*kernel_trace.csv | head -1) 100 > $O/nuts_c3_timeline.txt 2>&1
+rm -f $O/kt_nuts/*/*kernel_trace.csv $O/kt_dense/*/*kernel_trace.csv
+tail -3 $O/gpu_tests.log
