@@ -1165,15 +1165,18 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   const int other_bit = dir > 0 ? LZ_L : LZ_R;
   const float* op = ((lazy & other_bit) ? nt.p0 : (dir > 0 ? nt.Lp : nt.Rp)) + base;
   const float* ms_src = ((lazy & LZ_M) ? nt.p0 : nt.msum) + base;
+  // The first checkpoint level of an odd leaf s was stored by leaf s - 1: its momentum row is loaded,
+  // its momentum-SUM row is the subtree sum before this leaf, i.e. the S row already in registers
+  // (Smsum after leaf s - 1), so it is neither loaded here nor -- when no later leaf reads it, s - 1
+  // not a multiple of 4 -- stored by leaf s - 1.
   Row<VEC> C0[NI], C1[NI], MS[NI], OP[NI];
   if (nsub > 0) {
     const float* r_ck = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
-    const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D;
 #pragma unroll
     for (int k = 0; k < NI; ++k)
       if (ok[k]) {
         C0[k] = ldr<VEC>(r_ck + j0[k]);
-        C1[k] = ldr<VEC>(rs_ck + j0[k]);
+        C1[k] = R.S[k];
       }
   }
   if (last) {
@@ -1232,7 +1235,8 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
       // or a divergence (even leaves run no U-turn check, so `sdiv` is all that can stop them)
       if (even && !last && !sdiv) {
         str<VEC>(nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.P[k]);
-        str<VEC>(nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.S[k]);
+        // read from memory only as a SECOND or deeper level, i.e. by leaves s + 3, s + 7, ...: s % 4 == 0
+        if ((us & 3u) == 0u) str<VEC>(nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.S[k]);
       }
       if (take) {
         str<VEC>(nt.Sq + base + j0[k], R.X[k]);
