@@ -155,3 +155,34 @@ def test_free_running_is_shard_invariant(dev):
             for lo, hi in ((0, 20), (20, 48))]
     assert torch.equal(torch.cat([o.state.position for o in outs]), s_full.position)
     assert torch.equal(torch.cat([o.parameters["step_size"] for o in outs]), p_full["step_size"])
+
+
+@pytest.mark.parametrize("N,D", [(40, 384), (33, 512), (20, 260)])
+def test_free_running_two_rows_per_lane(dev, N, D):
+    """256 < D <= 512: the low-traffic tick kernels with two 16-byte pieces per lane (NI = 2);
+    D = 260 has a ragged second piece.  run(T) == T x step and == the oracle on a few chains."""
+    T = 4
+    rng = np.random.default_rng(D)
+    sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(f32)
+    inv_var = (f32(1) / (sig * sig)).astype(f32)
+    q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(f32)
+    eps = rng.uniform(0.05, 0.2, N).astype(f32)
+    imm = rng.uniform(0.5, 2.0, (N, D)).astype(f32)
+    alg = bjx.nuts(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), dev_t(eps, dev),
+                   bjx.metrics.PerChainDiag(dev_t(imm, dev)), max_num_doublings=6)
+    st0 = alg.init(dev_t(q0, dev))
+    final, positions, info = alg.run(prng.key(8), st0, T)
+    st = st0
+    for t, k in enumerate(prng.split(prng.key(8), T)):
+        st, inf = alg.step(k, st)
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps), t
+        assert torch.equal(positions[t], st.position), t
+        assert torch.equal(info.acceptance_rate[t], inf.acceptance_rate)
+    fn_o = otargets.diag_gaussian(inv_var)
+    idx = np.array([0, 1, N // 2, N - 1])
+    st_o = ohmc.init(q0[idx], fn_o)
+    for t, k in enumerate(prng.split(prng.key(8), T)):
+        st_o, info_o = onuts.kernel(None, st_o, fn_o, eps[idx], imm[idx], 6, per_chain_diag=True,
+                                    chain_keys_override=prng.split_at(k, idx))
+        assert np.array_equal(t2n(info.num_integration_steps[t])[idx], info_o.num_integration_steps)
+        np.testing.assert_allclose(t2n(positions[t])[idx], st_o.position, rtol=ATOL, atol=ATOL)
