@@ -490,6 +490,160 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same "TN" tile (128 x 128 block tile, K-tile 16, row-major LDS tiles of stride 20) computed by
+// EIGHT waves (512 threads, 2 x 4 waves of 64 x 32) instead of four of 64 x 64: the global traffic,
+// the LDS footprint and the summation order are unchanged, but a CU now holds 16 waves -- four per
+// SIMD -- so the matrix pipe finds an MFMA to issue while other waves wait on LDS reads, on the
+// staging stores or at the K-tile barrier (with two waves per SIMD the pipe was busy 61 % of a
+// launch).  Per wave and K-tile: 6 ds_read_b128 feed 16 MFMAs on two independent accumulators.
+constexpr int kThreads8 = 512;
+
+template <int EPI, int KICKS>
+__global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
+  static_assert(2 * BM * LDK + 2 * BN * LDK >= 8 * 32 * 32, "epilogue staging needs 32 KiB");
+  static_assert(BK == 16, "the k pairing below assumes two 8-wide halves");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t n_col = a.D / BN, n_row = a.M / BM;
+  const int64_t lin = blockIdx.x;
+  int64_t row_blk, col_blk;
+  {  // XCD-aware tile order, as in k_dense_gemm
+    const int64_t full = (n_row / 8) * 8 * n_col;
+    if (lin < full) {
+      const int64_t xcd = lin % 8, slot = lin / 8;
+      col_blk = slot % n_col;
+      row_blk = (slot / n_col) * 8 + xcd;
+    } else {
+      const int64_t r = lin - full;
+      row_blk = (n_row / 8) * 8 + r / n_col;
+      col_blk = r % n_col;
+    }
+  }
+  const int64_t row0 = row_blk * BM, col0 = col_blk * BN, D = a.D;
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BM * LDK;
+
+  // staging: thread -> (tile row tid/4, 4 consecutive k starting at (tid&3)*4) of A and of Bt
+  const int s_row = tid >> 2, s_k = (tid & 3) * 4;
+  const float* a_src = a.A + (row0 + s_row) * D + s_k;
+  const float* g_src = KICKS > 0 ? a.G + (row0 + s_row) * D + s_k : nullptr;
+  const float* b_src = a.B + (col0 + s_row) * D + s_k;
+  float* a_out = (KICKS > 0 && a.A_out) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
+  float ha = 0.0f, hb = 0.0f;
+  bool kick_row = true;
+  if (KICKS > 0) {
+    const float e = a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps;
+    ha = e * a.kick_a;
+    hb = e * a.kick_b;
+    kick_row = gemm_row_active(a, row0 + s_row);
+  }
+  struct Regs {
+    F4 a, g, b;
+  };
+  Regs R0, R1;
+  auto load_tiles = [&](Regs& r, int64_t k0) {
+    r.a = ld4(a_src + k0);
+    if constexpr (KICKS > 0) r.g = ld4(g_src + k0);
+    r.b = ld4(b_src + k0);
+  };
+  auto kick = [&](F4& x, const F4& g, float h) {
+    x.x = fmaf(h, g.x, x.x); x.y = fmaf(h, g.y, x.y); x.z = fmaf(h, g.z, x.z); x.w = fmaf(h, g.w, x.w);
+  };
+  auto store_tiles = [&](Regs& r, int buf, int64_t k0) {
+    if constexpr (KICKS > 0) {
+      if (kick_row) {
+        kick(r.a, r.g, ha);
+        if constexpr (KICKS == 2) kick(r.a, r.g, hb);
+      }
+      if (a_out && k0 / BN == col_blk) st4(a_out + k0, r.a);
+    }
+    st4(As0 + buf * BM * LDK + s_row * LDK + s_k, r.a);
+    st4(Bs0 + buf * BN * LDK + s_row * LDK + s_k, r.b);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
+  load_tiles(R0, 0);
+  load_tiles(R1, BK);
+  store_tiles(R0, 0, 0);
+  __syncthreads();
+  const int lm = lane & 31, lk = lane >> 5;
+  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
+  const int b_off = (wn * 32 + lm) * LDK + lk * 8;
+  auto tile = [&](int64_t t, Regs& stage, Regs& refill) {
+    const int buf = (int)(t & 1);
+    const float* as = As0 + buf * BM * LDK + a_off;
+    const float* bs = Bs0 + buf * BN * LDK + b_off;
+    float fa0[8], fa1[8], fb[8];
+    *reinterpret_cast<F4*>(fa0) = ld4(as);             *reinterpret_cast<F4*>(fa0 + 4) = ld4(as + 4);
+    *reinterpret_cast<F4*>(fb) = ld4(bs);              *reinterpret_cast<F4*>(fb + 4) = ld4(bs + 4);
+    *reinterpret_cast<F4*>(fa1) = ld4(as + 32 * LDK);  *reinterpret_cast<F4*>(fa1 + 4) = ld4(as + 32 * LDK + 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb[u], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb[u], acc[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the staging work here, behind 8 queued MFMAs
+    if (t + 1 < n_tiles) store_tiles(stage, buf ^ 1, (t + 1) * BK);
+    if (t + 2 < n_tiles) load_tiles(refill, (t + 2) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 4; u < 8; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb[u], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb[u], acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int64_t t = 0; t < n_tiles; t += 2) {
+    tile(t, R1, R0);
+    tile(t + 1, R0, R1);
+  }
+
+  // epilogue: each wave transposes its two 32 x 32 accumulator tiles through its private 4 KiB slice
+  // of the (now idle) tile buffers so that global accesses are 16-byte row segments
+  float* stage = smem + wave * (32 * 32);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(bq * 8 + lk * 4 + r) * 32 + lm] = acc[i][bq * 4 + r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int c4 = (lane & 7) * 4;
+    const int64_t col = col0 + wn * 32 + c4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (lane >> 3) + 8 * it;
+      const int64_t row = row0 + wm * 64 + i * 32 + rl;
+      const F4 c = *reinterpret_cast<const F4*>(stage + rl * 32 + c4);
+      if constexpr (EPI == EPI_STORE) {
+        st4(a.C + row * D + col, c);
+      } else {
+        const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
+        const F4 q = ld4(a.Q_in + row * D + col);
+        if (gemm_row_active(a, row))
+          st4(a.Q_out + row * D + col,
+              F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
+        else
+          st4(a.Q_out + row * D + col, q);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / BJX_WAVE;
 __device__ __forceinline__ int64_t wave_row0() {
@@ -765,7 +919,12 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B, ga.C, ga.Q_in, ga.Q_out);
   const bool full = (ga.M % BM == 0) && (ga.D % BN == 0);
   if (ga.b_symmetric && aligned && full) {
-#define BJX_LAUNCH_TN(E, K) hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga)
+    static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
+#define BJX_LAUNCH_TN(E, K)                                                                   \
+  do {                                                                                        \
+    if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga);   \
+    else hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga);         \
+  } while (0)
     const int kicks = ga.G ? ga.n_kicks : 0;
     if (epi == EPI_STORE) {
       if (kicks == 0) BJX_LAUNCH_TN(EPI_STORE, 0); else if (kicks == 1) BJX_LAUNCH_TN(EPI_STORE, 1); else BJX_LAUNCH_TN(EPI_STORE, 2);

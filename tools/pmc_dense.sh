@@ -3,6 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_dense
 rm -rf $OUT; mkdir -p $OUT
+# BJX_DENSE_TN8=0 selects the 4-wave tile kernel
 cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_ANY"; do
@@ -16,8 +17,10 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pmc_dense/g*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'gemm' in k:
-            acc[k.split('(')[0][-45:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        import re
+        m = re.search(r'(k_dense_gemm\w*<[^>]*>)', k)
+        if m and '<1, 2>' in m.group(1):  # the leapfrog launch: EPI_DRIFT, two kicks
+            acc[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
