@@ -509,6 +509,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2
     sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even: the work lists alternate per tick
+    import os as _os
+
+    graph_max_rows = int(_os.environ.get("BJX_NUTS_TAIL_ROWS", graph_max_rows))
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
     can_record = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
