@@ -922,7 +922,7 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
     static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
 #define BJX_LAUNCH_TN(E, K)                                                                   \
   do {                                                                                        \
-    if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga);   \
+    if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga); \
     else hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga);         \
   } while (0)
     const int kicks = ga.G ? ga.n_kicks : 0;
