@@ -45,8 +45,10 @@ for key, name in [("bench_py_C2", "bench_c2.json"), ("bench_py_C2_two_gloo_ranks
         summary[key] = j
 json.dump(summary, open(os.path.join(out_dir, f"summary_final_{rnd}.json"), "w"), indent=1)
 for tag in ("nuts", "dense"):
-    for fpath in glob.glob(os.path.join(SRC, f"kt_{tag}", "*", "*kernel_stats.csv")):
-        shutil.copy(fpath, os.path.join(out_dir, f"{'nuts_c3' if tag == 'nuts' else 'dense_c5'}_kernel_stats_final.csv"))
+    found = glob.glob(os.path.join(SRC, f"kt_{tag}", "*", "*kernel_stats.csv"))
+    if found:  # gpurun MERGES into the local directory: take the newest run
+        shutil.copy(max(found, key=os.path.getmtime),
+                    os.path.join(out_dir, f"{'nuts_c3' if tag == 'nuts' else 'dense_c5'}_kernel_stats_final.csv"))
 tl = os.path.join(SRC, "nuts_c3_timeline.txt")
 if os.path.exists(tl):
     shutil.copy(tl, os.path.join(out_dir, "nuts_c3_timeline_final.txt"))
