@@ -197,6 +197,51 @@ def test_halton_sequence():
 
 
 # ----------------------------------------------------------------------------- product host logic
+def _adam_closed_form(grads, lr, b1, b2, eps, eps_root):
+    """optax.scale_by_adam + scale(-lr) written out NON-recursively in fp64 from the documented
+    formulas (optax/_src/transform.py: m_t = (1-b1) sum_i b1^(t-i) g_i, v_t likewise with g_i^2,
+    bias corrections 1 - b^t, u = m_hat / (sqrt(v_hat + eps_root) + eps)): an independent statement,
+    not a copy of the step-by-step restatements in blackjax_amd/optim.py and oracle/chees.py."""
+    out = []
+    g = np.asarray(grads, f64)
+    for t in range(1, len(g) + 1):
+        w = np.arange(t - 1, -1, -1, dtype=f64)  # exponents t - i
+        m = (1.0 - b1) * np.sum(b1 ** w * g[:t])
+        v = (1.0 - b2) * np.sum(b2 ** w * g[:t] ** 2)
+        m_hat, v_hat = m / (1.0 - b1 ** t), v / (1.0 - b2 ** t)
+        out.append(-lr * m_hat / (np.sqrt(v_hat + eps_root) + eps))
+    return np.asarray(out)
+
+
+def test_optimizers_against_an_independent_closed_form_and_known_answers():
+    """Both step-by-step fp32 restatements of optax's Adam / SGD (product and oracle) against (a)
+    hand-computed first steps and (b) the closed-form fp64 evaluation over a gradient history."""
+    from blackjax_amd import optim
+
+    # known answers: first Adam step is -lr * g / (|g| + eps) whatever b1, b2 (bias correction)
+    for mk in (optim.adam, och.Adam):
+        opt = mk(0.5, b1=0.9, b2=0.999)
+        u, st = opt.update(f32(3.0), opt.init(f32(0.0)), f32(0.0))
+        # (1e-5: optax's own fp32 `1 - b2**count` cancels to ~1e-5 relative at count = 1, b2 = 0.999)
+        assert abs(float(u) + 0.5) < 1e-5 and st[0] == 1
+        u, _ = opt.update(f32(-2.0), opt.init(f32(0.0)), f32(0.0))
+        assert abs(float(u) - 0.5) < 1e-5
+    for mk in (optim.sgd, och.SGD):
+        assert float(mk(1e-3).update(f32(4.0), (), f32(0.0))[0]) == float(f32(-1e-3) * f32(4.0))
+    rng = np.random.default_rng(7)
+    grads = rng.normal(size=60) * 10.0 ** rng.integers(-3, 3, 60)
+    for lr, b1, b2 in ((0.5, 0.0, 0.95), (0.01, 0.9, 0.999), (0.1, 0.5, 0.9)):
+        want = _adam_closed_form(grads, lr, b1, b2, 1e-8, 0.0)
+        for mk in (optim.adam, och.Adam):
+            opt = mk(lr, b1=b1, b2=b2)
+            st = opt.init(f32(0.0))
+            got = []
+            for g in grads:
+                u, st = opt.update(f32(g), st, f32(0.0))
+                got.append(float(u))
+            np.testing.assert_allclose(got, want, rtol=5e-5, atol=1e-9)
+
+
 def test_product_optimizers_match_the_oracle_bitwise():
     from blackjax_amd import optim
 
