@@ -177,6 +177,7 @@ _f64p = c_void_p
 SIGNATURES.update({
     "bjx_chees_weights": [c_void_p, c_int64, c_int64, _f32p, _f32p, _u8p, _f32p],
     "bjx_chees_colstats": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, c_void_p, _f64p],
+    "bjx_chees_weights_colstats": [c_void_p, c_int64, c_int64, _f32p, _f32p, _u8p, _f32p, _f32p, c_void_p, _f64p],
     "bjx_chees_means": [c_void_p, c_int64, _f64p, _f32p, _f32p, _f32p, _f32p],
     "bjx_chees_criterion": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                             _f32p],

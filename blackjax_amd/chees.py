@@ -127,10 +127,8 @@ def _ensemble_means(ws: _Workspace, q_prop, acc, is_div, q_init, imm, group):
     """weights -> column statistics -> (all-reduce) -> means (chees_adaptation.py:376-386)."""
     N, D = q_prop.shape
     stream = _lib.current_stream()
-    _lib.call("bjx_chees_weights", stream, N, D, q_prop.data_ptr(), acc.data_ptr(), is_div.data_ptr(),
-              ws.w.data_ptr())
-    _lib.call("bjx_chees_colstats", stream, N, D, q_prop.data_ptr(), ws.w.data_ptr(), q_init.data_ptr(),
-              ws.scratch.data_ptr(), ws.stats.data_ptr())
+    _lib.call("bjx_chees_weights_colstats", stream, N, D, q_prop.data_ptr(), acc.data_ptr(), is_div.data_ptr(),
+              q_init.data_ptr(), ws.w.data_ptr(), ws.scratch.data_ptr(), ws.stats.data_ptr())
     all_reduce_sum_(ws.stats, group)
     _lib.call("bjx_chees_means", stream, D, ws.stats.data_ptr(), _lib.ptr(imm), ws.pm.data_ptr(),
               ws.im.data_ptr(), ws.isq.data_ptr() if imm is not None else None)

@@ -9,6 +9,7 @@
 //   * over dimensions (rows survive): one wavefront per chain, 16 B per lane, fp64 wave reduction
 //     (same shape as the leapfrog kernels).
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -25,8 +26,9 @@ struct ColGeom {
   int tpr_log2;  // threads per row segment = 1 << tpr_log2 (<= 256)
   int64_t ncb;   // column blocks (grid.y)
   int64_t nslab; // row slabs (grid.x)
-  int64_t rows_per_slab;
 };
+
+constexpr int kColU = 8;  // rows a thread has in flight = rows per thread and chunk
 
 ColGeom col_geom(int64_t N, int64_t D, int vec) {
   ColGeom g;
@@ -36,15 +38,17 @@ ColGeom col_geom(int64_t N, int64_t D, int vec) {
   const int64_t tpr = 1 << g.tpr_log2, rp = 256 >> g.tpr_log2;
   g.ncb = (groups + tpr - 1) / tpr;
   if (g.ncb < 1) g.ncb = 1;
-  int64_t want = 1024 / g.ncb;  // >= 4 workgroups per CU when the batch is large enough
+  // 512 slabs = 2 workgroups per CU on a large batch: more slabs buy occupancy but every slab writes
+  // (and k_colfinal re-reads) K * D doubles; 256 / 512 / 1024 slabs measured 131 / 136 / 143 us for the
+  // fused ChEES pass at 65 536 x 1 024
+  int64_t want = 512 / g.ncb;
   if (want < 1) want = 1;
-  int64_t max_slabs = (N + rp - 1) / rp;
-  if (max_slabs < 1) max_slabs = 1;
-  g.nslab = want < max_slabs ? want : max_slabs;
-  g.rows_per_slab = (N + g.nslab - 1) / g.nslab;
-  if (g.rows_per_slab < 1) g.rows_per_slab = 1;
-  g.nslab = (N + g.rows_per_slab - 1) / g.rows_per_slab;
-  if (g.nslab < 1) g.nslab = 1;
+  // rows are dealt to the slabs in chunks of kColU * rp rows, round robin (slab b takes chunks b,
+  // b + nslab, ...), so the workgroups of a launch read neighbouring chunks at any moment
+  const int64_t chunk = (int64_t)kColU * rp;
+  int64_t nchunks = (N + chunk - 1) / chunk;
+  if (nchunks < 1) nchunks = 1;
+  g.nslab = want < nchunks ? want : nchunks;
   return g;
 }
 
@@ -132,15 +136,13 @@ struct OpCenteredSq {  // metric_buffers.py:430-433
 };
 
 template <int VEC, class Op>
-__global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr_log2,
-                                                   int64_t rows_per_slab, Op op, double* partial) {
+__global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr_log2, Op op,
+                                                   double* partial) {
   constexpr int K = Op::K;
   __shared__ double sm[256 * K * VEC];
   const int tpr = 1 << tpr_log2, rp = 256 >> tpr_log2;
   const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x >> tpr_log2;
   const int64_t c0 = ((int64_t)blockIdx.y * tpr + tx) * VEC;
-  const int64_t r_lo = (int64_t)blockIdx.x * rows_per_slab;
-  const int64_t r_hi = r_lo + rows_per_slab < N ? r_lo + rows_per_slab : N;
   double a[K][VEC];
 #pragma unroll
   for (int k = 0; k < K; ++k)
@@ -150,21 +152,27 @@ __global__ __launch_bounds__(256) void k_colreduce(int64_t N, int64_t D, int tpr
     float c[VEC] = {};
     if constexpr (std::is_same<Op, OpCenteredSq>::value) ld_vec<VEC>(op.center + c0, c);
     // U rows are loaded before any is accumulated (memory-level parallelism: U independent 16-byte
-    // loads per input in flight per lane); accumulation order stays r ascending.
-    constexpr int U = 8;
+    // loads per input in flight per lane); a thread accumulates its rows in ascending order.
+    constexpr int U = kColU;
     using R = typename Op::template Regs<VEC>;
-    int64_t r = r_lo + ty;
-    for (; r + (int64_t)(U - 1) * rp < r_hi; r += (int64_t)U * rp) {
-      R g[U];
+    const int64_t chunk = (int64_t)U * rp;
+    for (int64_t rb = (int64_t)blockIdx.x * chunk; rb < N; rb += (int64_t)gridDim.x * chunk) {
+      if (rb + chunk <= N) {
+        R g[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) op.template load<VEC>(r + (int64_t)u * rp, (r + (int64_t)u * rp) * D + c0, g[u]);
+        for (int u = 0; u < U; ++u) {
+          const int64_t r = rb + ty + (int64_t)u * rp;
+          op.template load<VEC>(r, r * D + c0, g[u]);
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) op.template acc<VEC>(g[u], a, c);
-    }
-    for (; r < r_hi; r += rp) {
-      R g;
-      op.template load<VEC>(r, r * D + c0, g);
-      op.template acc<VEC>(g, a, c);
+        for (int u = 0; u < U; ++u) op.template acc<VEC>(g[u], a, c);
+      } else {
+        for (int64_t r = rb + ty; r < N; r += rp) {
+          R g;
+          op.template load<VEC>(r, r * D + c0, g);
+          op.template acc<VEC>(g, a, c);
+        }
+      }
     }
   }
   if constexpr (Op::kBroadcastLast) {
@@ -236,15 +244,147 @@ int run_colreduce(hipStream_t stream, int64_t N, int64_t D, bool vec4, Op op, vo
   dim3 grid((unsigned)g.nslab, (unsigned)g.ncb);
   double* partial = (double*)workspace;
   if (vec4)
-    hipLaunchKernelGGL((k_colreduce<4, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2,
-                       g.rows_per_slab, op, partial);
+    hipLaunchKernelGGL((k_colreduce<4, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2, op, partial);
   else
-    hipLaunchKernelGGL((k_colreduce<1, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2,
-                       g.rows_per_slab, op, partial);
+    hipLaunchKernelGGL((k_colreduce<1, Op>), grid, dim3(256), 0, stream, N, D, g.tpr_log2, op, partial);
   const int64_t KD = (int64_t)K * D;
   hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 63) / 64)), dim3(1024), 0, stream, g.nslab, KD,
                      partial, out);
   return bjx_check_launch(what);
+}
+
+// ChEES weights fused into the column statistics (chees_adaptation.py:376 + 241-246, 384-386): the
+// tpr threads that hold one row of q' between them also decide whether that row has a non-finite
+// entry (wave ballot; LDS across the waves of a row when tpr > 64), so q' is read once instead of
+// twice.  Needs the whole row in one workgroup (ncb == 1, i.e. D <= 1024 at 16 B per lane); the
+// accumulation order is k_colreduce<OpChees>'s, so the two paths agree bit for bit.
+template <int VEC, int U>
+struct WcolGeom {
+  int tpr_log2, tpr, rp, tx, ty, lane, wv;
+  int64_t c0, cl, r_hi, D;
+  bool col_in;
+};
+
+// U rows of q', q and their per-chain scalars as held by one thread.  No branches around the loads:
+// rows past the slab shadow its last row and columns past D shadow column 0 (neither is accumulated),
+// so the 2 U row loads of a batch issue back to back.
+template <int VEC, int U>
+__device__ __forceinline__ void wcol_load(const WcolGeom<VEC, U>& g, int64_t rb, const float* __restrict__ qp,
+                                          const float* __restrict__ qi, const float* __restrict__ acc,
+                                          const uint8_t* __restrict__ is_div, float (&x)[U][VEC],
+                                          float (&y)[U][VEC], float (&an)[U], int (&dn)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int64_t r = rb + g.ty + (int64_t)u * g.rp;
+    r = r < g.r_hi ? r : g.r_hi - 1;
+    an[u] = acc[r];
+    dn[u] = is_div[r];
+    ld_vec<VEC>(qp + r * g.D + g.cl, x[u]);
+    ld_vec<VEC>(qi + r * g.D + g.cl, y[u]);
+  }
+}
+
+template <int VEC, int U>
+__device__ __forceinline__ void wcol_process(const WcolGeom<VEC, U>& g, int64_t rb, unsigned* sbad_par,
+                                             const float (&x)[U][VEC], const float (&y)[U][VEC],
+                                             const float (&an)[U], const int (&dn)[U],
+                                             float* __restrict__ w_out, double (&a)[4][VEC]) {
+  unsigned bad = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bool nf = false;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) nf |= !isfinite(x[u][v]);
+    nf &= g.col_in;
+    const unsigned long long m = __ballot(nf);
+    bool any;
+    if (g.tpr >= 64) any = m != 0ull;
+    else any = ((m >> ((g.lane >> g.tpr_log2) << g.tpr_log2)) & ((1ull << g.tpr) - 1ull)) != 0ull;
+    bad |= any ? (1u << u) : 0u;
+  }
+  if (g.tpr > 64) {  // a row spans tpr / 64 waves
+    if (g.lane == 0) sbad_par[g.wv] = bad;
+    __syncthreads();
+    const int wpr = g.tpr >> 6, w0 = (g.wv / wpr) * wpr;
+    for (int j = 0; j < wpr; ++j) bad |= sbad_par[w0 + j];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t r = rb + g.ty + (int64_t)u * g.rp;
+    const bool in = r < g.r_hi;
+    const float wf = (dn[u] || ((bad >> u) & 1u)) ? 0.0f : an[u];
+    if (in && g.tx == 0) w_out[r] = wf;
+    if (in) {  // uniform over the threads of a row; a skipped row adds nothing (not even +0.0)
+      const double wr = (double)wf;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float xs = isfinite(x[u][v]) ? x[u][v] : 0.0f;
+        a[0][v] += wr * (double)xs;
+        const bool ok = !(y[u][v] != y[u][v]);
+        a[1][v] += ok ? (double)y[u][v] : 0.0;
+        a[2][v] += ok ? 1.0 : 0.0;
+      }
+      a[3][0] += wr;
+    }
+  }
+}
+
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_chees_wcol(int64_t N, int64_t D, int tpr_log2,
+                                                    const float* __restrict__ qp, const float* __restrict__ qi,
+                                                    const float* __restrict__ acc,
+                                                    const uint8_t* __restrict__ is_div, float* __restrict__ w_out,
+                                                    double* __restrict__ partial) {
+  constexpr int K = 4;
+  __shared__ double sm[256 * K * VEC];
+  __shared__ unsigned sbad[2][4];
+  WcolGeom<VEC, U> g;
+  g.tpr_log2 = tpr_log2;
+  g.tpr = 1 << tpr_log2;
+  g.rp = 256 >> tpr_log2;
+  g.tx = threadIdx.x & (g.tpr - 1);
+  g.ty = threadIdx.x >> tpr_log2;
+  g.lane = threadIdx.x & 63;
+  g.wv = threadIdx.x >> 6;
+  g.c0 = (int64_t)g.tx * VEC;
+  g.col_in = g.c0 < D;
+  g.cl = g.col_in ? g.c0 : 0;
+  g.D = D;
+  g.r_hi = N;
+  const int64_t chunk = (int64_t)U * g.rp, step = (int64_t)gridDim.x * chunk;
+  double a[K][VEC];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a[k][v] = 0.0;
+  int64_t rb = (int64_t)blockIdx.x * chunk;  // chunks blockIdx.x, + gridDim.x, ... (col_geom)
+  // uniform trip count over the workgroup (wcol_process has a barrier when a row spans waves).  A
+  // second batch requested ahead of the reduction (twice the registers) measured the same.
+  int par = 0;
+  for (; rb < g.r_hi; rb += step, par ^= 1) {
+    float x[U][VEC], y[U][VEC], an[U];
+    int dn[U];
+    wcol_load<VEC, U>(g, rb, qp, qi, acc, is_div, x, y, an, dn);
+    wcol_process<VEC, U>(g, rb, sbad[par], x, y, an, dn, w_out, a);
+  }
+#pragma unroll
+  for (int v = 1; v < VEC; ++v) a[K - 1][v] = a[K - 1][0];
+  double* mine = sm + (size_t)threadIdx.x * K * VEC;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) mine[k * VEC + v] = a[k][v];
+  __syncthreads();
+  if (g.ty == 0 && g.col_in) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        double s = 0.0;
+        for (int j = 0; j < g.rp; ++j) s += sm[((size_t)(j * g.tpr + g.tx)) * K * VEC + k * VEC + v];
+        partial[((int64_t)blockIdx.x * K + k) * D + g.c0 + v] = s;
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------ row kernels
@@ -313,7 +453,7 @@ __global__ __launch_bounds__(256) void k_chees_weights_short(int64_t N, int64_t 
       for (int64_t c = (int64_t)gl * 4; c < D; c += G * 4) {
         float x[4];
         ld_vec<4>(qp + n * D + c, x);
-        bad |= !isfinite(x[0]) | !isfinite(x[1]) | !isfinite(x[2]) | !isfinite(x[3]);
+        bad |= !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(x[3]));
       }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) bad |= __shfl_xor(bad, o, 64);
@@ -543,6 +683,34 @@ int bjx_chees_colstats(hipStream_t stream, int64_t N, int64_t D, const float* q_
   OpChees op{q_prop, w, q_init};
   return run_colreduce(stream, N, D, bjx_vec4_ok(D, q_prop, q_init), op, workspace, stats,
                        "bjx_chees_colstats");
+}
+
+int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const float* q_prop,
+                               const float* acc, const uint8_t* is_divergent, const float* q_init,
+                               float* w, void* workspace, double* stats) {
+  BJX_CHECK_ARG(N >= 0 && D >= 0, "bjx_chees_weights_colstats: negative size");
+  BJX_CHECK_ARG(stats || D == 0, "bjx_chees_weights_colstats: null stats");
+  BJX_CHECK_ARG(N == 0 || (acc && is_divergent && w), "bjx_chees_weights_colstats: null pointer");
+  BJX_CHECK_ARG(N == 0 || D == 0 || (q_prop && q_init && workspace), "bjx_chees_weights_colstats: null pointer");
+  const bool vec4 = bjx_vec4_ok(D, q_prop, q_init);
+  const ColGeom g = (N > 0 && D > 0) ? col_geom(N, D, vec4 ? 4 : 1) : ColGeom{0, 2, 1};
+  static const bool unfused = getenv("BJX_CHEES_UNFUSED") && atoi(getenv("BJX_CHEES_UNFUSED")) != 0;
+  if (N == 0 || D == 0 || g.ncb != 1 || unfused) {  // a row does not fit one workgroup: two passes
+    int rc = bjx_chees_weights(stream, N, D, q_prop, acc, is_divergent, w);
+    if (rc) return rc;
+    return bjx_chees_colstats(stream, N, D, q_prop, w, q_init, workspace, stats);
+  }
+  double* partial = (double*)workspace;
+#define BJX_WCOL(V)                                                                                         \
+  hipLaunchKernelGGL((k_chees_wcol<V, kColU>), dim3((unsigned)g.nslab), dim3(256), 0, stream, N, D, g.tpr_log2, \
+                     q_prop, q_init, acc, is_divergent, w, partial)
+  if (vec4) BJX_WCOL(4);
+  else BJX_WCOL(1);
+#undef BJX_WCOL
+  const int64_t KD = 4 * D;
+  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 63) / 64)), dim3(1024), 0, stream, g.nslab, KD,
+                     partial, stats);
+  return bjx_check_launch("bjx_chees_weights_colstats");
 }
 
 int bjx_chees_means(hipStream_t stream, int64_t D, const double* stats, const float* imm,

@@ -38,6 +38,13 @@ int bjx_chees_weights(hipStream_t stream, int64_t N, int64_t D, const float* q_p
 int bjx_chees_colstats(hipStream_t stream, int64_t N, int64_t D, const float* q_prop, const float* w,
                        const float* q_init, void* workspace, double* stats);
 
+/* bjx_chees_weights followed by bjx_chees_colstats in one pass over q_prop (the threads holding a row
+ * between them decide its weight before accumulating it); same results bit for bit.  Falls back to
+ * the two launches when a row does not fit one workgroup (D > 1024).  w is still written.        */
+int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const float* q_prop,
+                               const float* acc, const uint8_t* is_divergent, const float* q_init,
+                               float* w, void* workspace, double* stats);
+
 /* proposals_mean[d] = f32(stats0)/(f32(stats3) + 1e-20) (246-247); initials_mean[d] = f32(stats1)/f32(stats2);
  * inv_sqrt_imm[d] = 1/sqrt(imm[d]) (450) when imm != NULL (inv_sqrt_imm may be NULL otherwise).    */
 int bjx_chees_means(hipStream_t stream, int64_t D, const double* stats, const float* imm,

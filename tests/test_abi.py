@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in list(_lib.SIGNATURES) + list(_lib.INT64_FUNCTIONS):
         assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
     assert lib.bjx_pool_workspace_bytes(0, 8) == 0
-    assert lib.bjx_pool_workspace_bytes(65536, 1024) == 1024 * 4 * 1024 * 8
+    assert lib.bjx_pool_workspace_bytes(65536, 1024) == 512 * 4 * 1024 * 8  # 512 slabs x K=4 x D doubles
     assert lib.bjx_abi_version() == 1
 
 

@@ -51,7 +51,8 @@ def _oracle_sums(props, moms, inits, acc, div, imm, whiten, scale):
     return w, crit, sums
 
 
-@pytest.mark.parametrize("N,D", [(37, 6), (64, 8), (130, 257), (1000, 64), (3, 1), (77, 20), (41, 100), (9, 128)])
+@pytest.mark.parametrize("N,D", [(37, 6), (64, 8), (130, 257), (1000, 64), (3, 1), (77, 20), (41, 100), (9, 128),
+                                 (300, 512), (530, 1024), (70, 300), (33, 1028)])
 @pytest.mark.parametrize("whiten", [False, True])
 @pytest.mark.parametrize("poison", [False, True])
 def test_pool_kernels_vs_oracle(dev, N, D, whiten, poison):
@@ -76,6 +77,30 @@ def test_pool_kernels_vs_oracle(dev, N, D, whiten, poison):
         np.testing.assert_allclose(sums[2], sums_o[2], rtol=1e-5, atol=1e-4)
     else:
         assert not np.isfinite(sums[2])
+
+
+@pytest.mark.parametrize("N,D", [(37, 6), (1000, 64), (77, 20), (2100, 256), (4200, 512), (9000, 1024), (33, 1028)])
+def test_fused_weights_colstats_equals_the_two_launches(dev, N, D):
+    """bjx_chees_weights_colstats (one read of q') against bjx_chees_weights + bjx_chees_colstats:
+    weights and all 4*D fp64 column sums bit for bit, over every row-to-thread geometry (a row inside
+    one wave, across 2 and 4 waves, and the D > 1024 fall-back)."""
+    props, moms, inits, acc, div = _inputs(N, D, seed=3 * N + D)
+    rows = np.random.default_rng(N).choice(N, size=max(N // 50, 1), replace=False)
+    props[rows, (rows * 7) % D] = np.inf
+    qp, qi, a_t, d_t = dev_t(props, dev), dev_t(inits, dev), dev_t(acc, dev), dev_t(div, dev)
+    ws = pch._workspace(N, D, dev)
+    st = _lib.current_stream()
+    w1, w2 = torch.full((N,), -1.0, device=dev), torch.full((N,), -1.0, device=dev)
+    s1 = torch.empty(4 * D, dtype=torch.float64, device=dev)
+    s2 = torch.empty_like(s1)
+    _lib.call("bjx_chees_weights", st, N, D, qp.data_ptr(), a_t.data_ptr(), d_t.data_ptr(), w1.data_ptr())
+    _lib.call("bjx_chees_colstats", st, N, D, qp.data_ptr(), w1.data_ptr(), qi.data_ptr(), ws.scratch.data_ptr(),
+              s1.data_ptr())
+    _lib.call("bjx_chees_weights_colstats", st, N, D, qp.data_ptr(), a_t.data_ptr(), d_t.data_ptr(), qi.data_ptr(),
+              w2.data_ptr(), ws.scratch.data_ptr(), s2.data_ptr())
+    assert torch.equal(w1, w2) and float(w1.min()) >= 0.0
+    assert (w1[torch.as_tensor(rows, device=dev)] == 0).all()
+    assert torch.equal(s1, s2)
 
 
 def test_pool_empty_batch(dev):

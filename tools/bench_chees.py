@@ -4,7 +4,8 @@
 
 Reports whole-run chain-leapfrog/s and, for the pooled-statistics kernels of include/bjx_pool.h, the
 average launch time against their algorithmic bytes (HBM roofline):
-  bjx_chees_weights    reads q_prop                      4 B / element
+  bjx_chees_weights_colstats  (weights fused in) reads q_prop, q_init   8 B / element
+  bjx_chees_weights    reads q_prop                      4 B / element  (D > 1024 only)
   bjx_chees_colstats   reads q_prop, q_init              8 B / element
   bjx_chees_criterion  reads q_prop, p_prop, q_init     12 B / element
   bjx_pool_colsum      reads x                           4 B / element (x2 per step when estimating the metric)
@@ -46,7 +47,7 @@ q0 = sig * torch.randn(N, D, device=dev, generator=g)
 opt = bjx.optim.adam(0.5, b1=0, b2=0.95)
 # priming run (first use of every kernel / torch op)
 warm.run(bjx.random.key(1), q0, args.step_size, opt, 3)
-names = ["bjx_chees_weights", "bjx_chees_colstats", "bjx_chees_criterion", "bjx_pool_colsum", "bjx_leapfrog_diag"]
+names = ["bjx_chees_weights_colstats", "bjx_chees_weights", "bjx_chees_colstats", "bjx_chees_criterion", "bjx_pool_colsum", "bjx_leapfrog_diag"]
 # short leapfrog launches are sampled sparsely and all events come from a pre-recorded pool: creating
 # events inside the timed region slowed bench.py's region by 13 %
 timer = _lib.LaunchTimer(names, every={"bjx_leapfrog_diag": 16}, capacity=4096)
@@ -58,7 +59,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 _lib.set_timer(None)
 L_total = int(info.info.num_integration_steps.sum())
-bytes_per_elem = {"bjx_chees_weights": 4, "bjx_chees_colstats": 8, "bjx_chees_criterion": 12,
+bytes_per_elem = {"bjx_chees_weights_colstats": 8, "bjx_chees_weights": 4, "bjx_chees_colstats": 8, "bjx_chees_criterion": 12,
                   "bjx_pool_colsum": 4, "bjx_leapfrog_diag": 20}
 from blackjax_amd.hmc import auto_chain_block  # noqa: E402
 
