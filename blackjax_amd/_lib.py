@@ -156,6 +156,7 @@ class NutsAsync(ctypes.Structure):
         ("adapt_m2", c_void_p), ("adapt_imm", c_void_p), ("out_step_size", c_void_p),
         ("rec", c_void_p), ("front_p", c_void_p), ("end_list", c_void_p), ("end_count", c_void_p),
         ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("n_rows_dev", c_void_p),
+        ("mass_sqrt_t", c_void_p), ("v0", c_void_p),
     ]
 
 

@@ -857,10 +857,11 @@ __device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax,
 // complete moves to phase 3 and is finished by part 2.
 // NI = 0: general sweeps; NI > 0: register-resident leaf (VEC == 4, D <= 256 * NI)
 // Returns true when the chain's subtree is complete (phase 3 written).
-template <int VEC, int NI>
+template <int VEC, int NI, bool DENSE = false>
 __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
                                                  float* qf, const float* __restrict__ logp_f,
                                                  const float* __restrict__ gf, int64_t c, int64_t b) {
+  static_assert(!DENSE || NI == 0, "the register-resident leaf is for the diagonal metric");
   const int lane = threadIdx.x & 63;
   const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
   const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
@@ -868,7 +869,7 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
   const bool last = (s + 1) >= (1 << depth);
   bool stop;
   if constexpr (NI > 0) stop = nuts_post_chain_resident<VEC, NI>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
-  else stop = nuts_post_chain<VEC, false>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
+  else stop = nuts_post_chain<VEC, DENSE>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
   if ((stop || last) && lane == 0) ax.phase[c] = 3;
   return stop || last;
 }
@@ -959,7 +960,7 @@ __device__ __forceinline__ void async_adapt_chain(const bjx_nuts_t& nt, const bj
 
 // Tick, part 2 (phase 3: subtree complete; phase 0: start a transition): merge, then either the
 // next doubling, or record the finished transition, accept its proposal and start the next one.
-template <int VEC>
+template <int VEC, bool DENSE = false>
 __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
                                                      float* qf, int64_t c, int64_t b, int phase) {
   const int lane = threadIdx.x & 63;
@@ -970,12 +971,12 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
     float* qrow = qf + b * nt.D;  // this chain's row of the callable's batch
     if (phase == 3) {
       const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
-      const bool grow = nuts_merge_chain<VEC, false>(nt, cx, c, depth);
+      const bool grow = nuts_merge_chain<VEC, DENSE>(nt, cx, c, depth);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (grow) {
         const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
         const float deps = (float)dir * chain_eps(nt, c);
-        nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
+        nuts_open_half<VEC, DENSE>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
                                    qrow);
         if (lane == 0) ax.phase[c] = 1;
         return;
@@ -1019,26 +1020,54 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
     // element mapping of the other sweeps, then the tree of nuts.py:278-294
     const Key kc = chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold);
     const Key km = key_child(kc, 0);  // split(kc, 2)[0]
-    const float* im = nt.imm + c * nt.imm_stride;
     double acc = 0.0;
-    BJX_ROW_SWEEP(j0) {
-      const Row<VEC> m = ldr<VEC>(im + j0);
-      Row<VEC> pv;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0 + e)));
-        const float ms = 1.0f / sqrtf(m.v[e]);
-        pv.v[e] = ms * z;
-        acc += (double)(m.v[e] * pv.v[e]) * (double)pv.v[e];
+    if constexpr (DENSE) {
+      // the arithmetic of bjx_hmc_momentum_dense_pc (metrics.py:260-270, util.py:23-91), which the
+      // lockstep step uses for NUTS: z = normal(km); p = L^{-T} z; v = M^{-1} p, fp64 accumulated in
+      // ascending j; K = v.p / 2 summed lane-strided then across the wave
+      const float* Mt = ax.mass_sqrt_t + c * nt.Mdense_stride;
+      const float* Mi = nt.Mdense + c * nt.Mdense_stride;
+      float* pz = ax.p + base;
+      float* v0 = ax.v0 + base;
+      for (int64_t ic = 0; ic < nt.D; ic += 64) {
+        const int64_t i = ic + lane;
+        const double a = matvec_t_lane(Mt, nt.D, i, [&](int64_t j) {
+          return normal_from_bits(key_bits32(km, (uint64_t)j));
+        });
+        if (i < nt.D) pz[i] = (float)a;
       }
-      str<VEC>(ax.p + base + j0, pv);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // p: written lane-wise, read by every lane
+      for (int64_t ic = 0; ic < nt.D; ic += 64) {
+        const int64_t i = ic + lane;
+        const double a = matvec_t_lane(Mi, nt.D, i, [&](int64_t j) { return pz[j]; });
+        if (i < nt.D) {
+          const float v = (float)a;
+          v0[i] = v;
+          acc += (double)v * (double)pz[i];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // v0 is read by nuts_init_chain below
+    } else {
+      const float* im = nt.imm + c * nt.imm_stride;
+      BJX_ROW_SWEEP(j0) {
+        const Row<VEC> m = ldr<VEC>(im + j0);
+        Row<VEC> pv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0 + e)));
+          const float ms = 1.0f / sqrtf(m.v[e]);
+          pv.v[e] = ms * z;
+          acc += (double)(m.v[e] * pv.v[e]) * (double)pv.v[e];
+        }
+        str<VEC>(ax.p + base + j0, pv);
+      }
     }
     acc = wave_sum(acc);
-    nuts_init_chain<VEC, false>(nt, c, ax.logp[c], 0.5f * (float)acc);
+    nuts_init_chain<VEC, DENSE>(nt, c, ax.logp[c], 0.5f * (float)acc);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const int dir = nuts_begin_doubling(nt, cx, c, 0);
     const float deps = (float)dir * chain_eps(nt, c);
-    nuts_open_half<VEC, false>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
                                qrow);
     if (lane == 0) ax.phase[c] = 1;
   }
@@ -1055,17 +1084,17 @@ k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
 // Both parts in one launch, for ticks with few live chains (the long tail of a run, where a tick is
 // bound by its dependent launches, not by the work): leaf, then -- same wave, after a fence -- the
 // boundary work the leaf may have produced.
-template <int VEC, int NI>
+template <int VEC, int NI, bool DENSE = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_FUSED_WAVES)))
 k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
   async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
     if (phase == 1) {
-      if (!async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b)) return;
+      if (!async_leaf_chain<VEC, NI, DENSE>(nt, ax, qf, logp_f, gf, c, b)) return;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       phase = 3;
     }
-    async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
+    async_boundary_chain<VEC, DENSE>(nt, ax, qf, c, b, phase);
   });
 }
 
@@ -1901,7 +1930,9 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   if (check_nuts(nuts, "bjx_nuts_async_tick")) return 1;
   if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
   BJX_CHECK_ARG(run && qf && logp_f && gf, "bjx_nuts_async_tick: null argument");
-  BJX_CHECK_ARG(!nuts->Mdense, "bjx_nuts_async_tick: free-running chains support the diagonal metric only");
+  BJX_CHECK_ARG(!nuts->Mdense || (run->mass_sqrt_t && run->v0 && run->v0 == nuts->v0 && !run->adapt_tab),
+                "bjx_nuts_async_tick: a dense metric needs run->mass_sqrt_t, run->v0 == nuts->v0 and no "
+                "per-chain adaptation (adapt_tab adapts a diagonal metric)");
   BJX_CHECK_ARG(nuts->max_depth >= 1, "bjx_nuts_async_tick: max_depth must be >= 1");
   BJX_CHECK_ARG(run->n_steps >= 0 && run->t_first >= 0 && run->q && run->g && run->logp && run->p &&
                     run->t && run->phase && run->n_done,
@@ -1918,6 +1949,13 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                 "bjx_nuts_async_tick: adaptation needs every adapt_* buffer, nuts->eps_per_chain == "
                 "adapt_step_size and nuts->imm == adapt_imm with imm_stride == D");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
+  if (nuts->Mdense) {
+    // dense metric: every leaf is a D x D matrix-vector product per chain (fp64 accumulated, the
+    // arithmetic of the lockstep kernels), so one launch per tick whatever the row count
+    hipLaunchKernelGGL((k_nuts_async_fused<1, 0, true>), dim3(bjx_row_grid(run->n_rows, kWavesPerBlock)),
+                       dim3(kBlock), 0, (hipStream_t)stream, *nuts, *run, qf, logp_f, gf);
+    return bjx_check_launch("bjx_nuts_async_tick");
+  }
   const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;

@@ -449,8 +449,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             adapt_m2=ad["m2"].data_ptr(), adapt_imm=ad["imm"].data_ptr(),
             out_step_size=out_step_size.data_ptr())
     metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
-    if metric.kind != "diag":
-        raise NotImplementedError("free-running chains are implemented for diagonal metrics only")
+    if metric.kind != "diag" and adaptation is not None:
+        raise NotImplementedError("free-running per-chain adaptation is implemented for the diagonal metric")
     eps, eps_pc = step_size_args(step_size, N, dev)
     if adaptation is not None and (eps_pc is None or eps_pc.data_ptr() != adaptation["step_size"].data_ptr()
                                    or metric.imm.data_ptr() != adaptation["imm"].data_ptr()
@@ -480,9 +480,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     qf = torch.zeros_like(q)
     t_done = torch.zeros(N, **i32)
     phase = torch.zeros(N, **i32)
-    # work buffers of the low-traffic tick kernels (include/bjx_nuts.h: rec / front_p)
-    rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32)
-    front_p = torch.empty_like(q)
+    # work buffers of the low-traffic tick kernels (include/bjx_nuts.h: rec / front_p; diagonal metric)
+    dense_f = _dense_fields(metric.kind, metric.imm, N, D, max_depth, dev)
+    v0 = None
+    if metric.kind != "diag":  # the tick kernel draws p = L^{-T} z and v0 = M^{-1} p per chain
+        v0 = torch.empty_like(q)
+        dense_f["fields"]["v0"] = v0.data_ptr()
+    rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32) if v0 is None else None
+    front_p = torch.empty_like(q) if v0 is None else None
     end_list = torch.empty((2, N), **i32)
     end_count = torch.zeros(2, **i32)
     n_done = torch.zeros(1, **i32)
@@ -492,8 +497,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         divergence_threshold=float(divergence_threshold), key0=k0, key1=k1,
         chain_offset=int(chain_offset), step_fold=-1, q0=q.data_ptr(), g0=g.data_ptr(),
         p0=p.data_ptr(), ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(),
-        is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()},
-        **_dense_fields("diag", None, N, D, max_depth, dev)["fields"])
+        is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"])
     run = _lib.NutsAsync(
         step_keys=_lib.ptr(step_keys), t_first=0, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
         logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
@@ -503,8 +507,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         out_num_integration_steps=info.num_integration_steps.data_ptr(),
         out_num_trajectory_expansions=info.num_trajectory_expansions.data_ptr(),
         out_is_divergent=info.is_divergent.data_ptr(), out_is_turning=info.is_turning.data_ptr(),
-        rec=rec.data_ptr(), front_p=front_p.data_ptr(), end_list=end_list.data_ptr(),
-        end_count=end_count.data_ptr(), **adapt_fields)
+        rec=_lib.ptr(rec), front_p=_lib.ptr(front_p), end_list=end_list.data_ptr(),
+        end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
+        v0=_lib.ptr(v0), **adapt_fields)
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2

@@ -165,7 +165,7 @@ int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t 
  * chain c at transition t uses the same key either way.
  *
  * The host loops   bjx_nuts_async_tick -> user callable on qf (all N rows) -> bjx_nuts_async_tick ...
- * until *n_done == N.  Diagonal metric, max_depth >= 1. */
+ * until *n_done == N.  max_depth >= 1.  Diagonal or dense metric (per-chain adaptation: diagonal). */
 typedef struct {
   const uint32_t* step_keys;  /* (n_steps, 2) device table of the run's per-transition keys
                                  (step-major layout: chain key = split(step_keys[t], N)[c]); NULL:
@@ -232,6 +232,12 @@ typedef struct {
    * size of a run's tail: bjx_nuts_async_compact writes the new count to its n_out argument, which
    * the next ticks then read here. */
   const int32_t* n_rows_dev;
+  /* Dense metric (nuts->Mdense != NULL): the transition-start momentum draw of chain c needs
+   * mass_sqrt_t = L^{-1} ((D, D) shared or (N, D, D), the layout of nuts->Mdense; metrics.py:701-729,
+   * util.py:23-61) and writes the velocity M^{-1} p0 to v0, which must be the buffer nuts->v0 points
+   * to.  Both NULL for a diagonal metric. */
+  const float* mass_sqrt_t;
+  float* v0;
 } bjx_nuts_async_t;
 
 #define BJX_NUTS_REC_WORDS 32

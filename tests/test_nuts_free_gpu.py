@@ -186,3 +186,42 @@ def test_free_running_two_rows_per_lane(dev, N, D):
                                     chain_keys_override=prng.split_at(k, idx))
         assert np.array_equal(t2n(info.num_integration_steps[t])[idx], info_o.num_integration_steps)
         np.testing.assert_allclose(t2n(positions[t])[idx], st_o.position, rtol=ATOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("per_chain,N,D", [(False, 14, 9), (True, 14, 9), (False, 40, 70), (True, 11, 130)])
+def test_free_running_dense_metric_equals_lockstep_and_oracle(dev, per_chain, N, D):
+    """Free-running chains with a dense inverse mass matrix (shared (D, D) or one per chain): the tick
+    kernel draws p = L^{-T} z and v = M^{-1} p per chain at the start of ITS transition and runs the
+    dense leaf / merge arithmetic of the lockstep kernels, so run(T) == T x step bit for bit; tree
+    sizes and positions follow the oracle (metrics.py:260-304, nuts.py:113-145)."""
+    T, rho, depth = 4, 0.7, 6
+    fn_o = otargets.ar1_gaussian(rho, D)
+    rng = np.random.default_rng(D)
+    if per_chain:
+        a = rng.standard_normal((N, D, D))
+        imm = (a @ np.swapaxes(a, 1, 2) / D + 0.5 * np.eye(D)).astype(f32)
+    else:
+        imm = otargets.ar1_covariance(rho, D)
+    q0 = prng.normal(prng.key(6), (N, D)).astype(f32)
+    alg = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.3, dev_t(imm, dev), max_num_doublings=depth)
+    st0 = alg.init(dev_t(q0, dev))
+    run_key = prng.key(8)
+    final, positions, info = alg.run(run_key, st0, T)
+    st_g, st_o = st0, ohmc.init(q0, fn_o)
+    for t, k in enumerate(prng.split(run_key, T)):
+        st_g, inf = alg.step(k, st_g)
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps), t
+        assert torch.equal(positions[t], st_g.position), t
+        assert torch.equal(info.acceptance_rate[t], inf.acceptance_rate)
+        assert torch.equal(info.energy[t], inf.energy)
+        assert torch.equal(info.is_turning[t], inf.is_turning)
+        if D <= 16:  # the oracle's dense NUTS is a Python loop per leaf
+            st_o, info_o = onuts.kernel(k, st_o, fn_o, f32(0.3), imm, depth)
+            assert np.array_equal(t2n(info.num_integration_steps[t]), info_o.num_integration_steps)
+            np.testing.assert_allclose(t2n(positions[t]), st_o.position, rtol=1e-5, atol=1e-5)
+    assert torch.equal(final.position, st_g.position) and torch.equal(final.logdensity_grad, st_g.logdensity_grad)
+    assert len(set(t2n(info.num_trajectory_expansions).ravel().tolist())) > 1
+    # recorded tick chunks change nothing
+    alg_g = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.3, dev_t(imm, dev), max_num_doublings=depth, use_graph=True)
+    final_g, pos_g, info_g = alg_g.run(run_key, st0, T)
+    assert torch.equal(pos_g, positions) and torch.equal(info_g.num_integration_steps, info.num_integration_steps)
