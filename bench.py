@@ -373,11 +373,20 @@ def bench_c2(args, ctx):
 
         dt, per, t_enq = timed_region(ctx, one, steps)
         _lib.set_timer(None)
+        # host cost of issuing ONE transition into an empty queue (outside the timed region): the
+        # in-region enqueue time below also contains the time launch calls block once the host has
+        # run ahead as far as the queue allows, so it tracks the GPU time, not the host's work
+        torch.cuda.synchronize()
+        t_i = time.perf_counter()
+        alg.step(prime_key, box["state"])
+        t_issue = time.perf_counter() - t_i
+        torch.cuda.synchronize()
         res = {"chain_block": chain_block, "hip_graph": bool(use_graph), "streams": streams, "dt": dt,
                "per_rank_dt": per,
                "steps": steps, "ms_per_step": dt / steps * 1e3,
                "value": world * N * L * steps / dt,
                "host_enqueue_ms_per_step": t_enq / max(steps, 1) * 1e3,
+               "host_issue_ms_unthrottled": t_issue * 1e3,
                "gpu_ms_of_each_step": [round(a.elapsed_time(b), 3) for a, b in zip(marks, marks[1:])],
                "mean_acceptance": float(acc_sum.item()) / max(steps, 1), "draws": draws,
                "state": box["state"], "launch": None,
@@ -557,6 +566,10 @@ def bench_c2(args, ctx):
         "per_rank_ms_per_step": [p / args.steps * 1e3 for p in head["per_rank_dt"]],
         "gpu_ms_of_each_step": head["gpu_ms_of_each_step"],
         "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+        "host_issue_ms_unthrottled": head["host_issue_ms_unthrottled"],
+        "host_note": "host_enqueue_ms_per_step is measured inside the timed region and includes launch calls "
+                     "blocking on a full queue (the host runs ahead of the GPU until back-pressure); "
+                     "host_issue_ms_unthrottled is the host's own cost of issuing one transition into an empty queue",
         "mean_acceptance": head["mean_acceptance"],
         "ess": ess, "ess_nonresonant": ess_nr,
         "end_to_end_frac_of_28B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D)),
