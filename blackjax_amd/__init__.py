@@ -10,11 +10,13 @@ from __future__ import annotations
 import functools as _functools
 
 from . import dynamic_hmc as _dynamic_hmc
+from . import ghmc as _ghmc
 from . import hmc as _hmc
 from . import nuts as _nuts
-from . import adaptation, chees, diagnostics, distributed, integrators, metrics, optim, random, targets, util
+from . import adaptation, chees, diagnostics, distributed, integrators, meads, metrics, optim, random, targets, util
 from .adaptation import staged_adaptation, window_adaptation
 from .chees import chees_adaptation
+from .meads import meads_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
 from ._util import capturable
 
@@ -51,5 +53,7 @@ dynamic_hmc.chain_keys = _dynamic_hmc.chain_keys
 dynamic_hmc.halton_sequence = _dynamic_hmc.halton_sequence
 dynamic_hmc.halton_steps_fn = _dynamic_hmc.halton_steps_fn
 dhmc = dynamic_hmc  # blackjax/__init__.py alias used by the ChEES examples
+# Generalized HMC (blackjax/mcmc/ghmc.py), the sampler the MEADS warm-up tunes
+ghmc = GenerateSamplingAPI(_ghmc.as_top_level_api, _ghmc.init, _ghmc.build_kernel)
 
-__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "chees", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]
+__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]

@@ -191,6 +191,14 @@ SIGNATURES.update({
     "bjx_halton_steps": [c_void_p, c_int64, c_void_p, ctypes.c_int32, c_float, c_float, c_float,
                          c_void_p],
 })
+# include/bjx_ghmc.h (Generalized HMC: persistent momentum, slice accept)
+SIGNATURES.update({
+    "bjx_ghmc_init": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, _f32p, _f32p],
+    "bjx_ghmc_refresh": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p, c_int64,
+                         c_float, _f32p, c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_ghmc_finish": [c_void_p, c_int64, c_int64, c_float, _f32p, _f32p, c_int64, c_float]
+                       + [_f32p] * 12 + [c_int64, c_int64] + [_f32p] * 6 + [_u8p, _u8p, _f32p, _f32p],
+})
 INT64_FUNCTIONS = {"bjx_pool_workspace_bytes": [c_int64, c_int64]}
 
 _lib = None

@@ -1,0 +1,158 @@
+"""Batched Generalized HMC on MI355X behind the ``blackjax.ghmc`` API surface.
+
+Mirrors blackjax/mcmc/ghmc.py: ``GHMCState`` (32-50), ``init`` (53-64), ``build_kernel`` (89-200),
+``as_top_level_api`` (226-317).  GHMC keeps the momentum between transitions (partial refresh with
+persistence ``alpha``), takes ONE velocity-Verlet step per transition and accepts it with a
+non-reversible slice variable translated by ``delta`` -- "a good candidate for running many chains in
+parallel" (ghmc.py:246-249), and the sampler the MEADS warm-up tunes (``blackjax_amd.meads``).
+
+The chain axis is native; chain ``i`` of ``step(rng_key, state)`` reproduces the reference's
+single-chain ``step(jax.random.split(rng_key, N)[i], state_i)``.  ``step_size``, ``alpha`` and ``delta``
+may be per-chain ``(N,)`` tensors, ``momentum_inverse_scale`` a scalar, ``(D,)`` or per-chain ``(N, D)``
+tensor (MEADS hands every fold its own values).  Only the per-dimension inverse-SCALE form of the
+momentum metric is built (ghmc.py:67-86, legacy branch: inverse mass matrix = scale ** 2); dense and
+low-rank momentum metrics (blackjax#950) are outside SURVEY.md section 8 and raise.
+
+The arithmetic runs in libbjxhip (include/bjx_ghmc.h, include/bjx_hip.h); this module sequences
+refresh -> kick + drift -> user callable -> finish.
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple
+
+import torch
+
+from . import _lib, metrics
+from ._util import check_batch, eval_logdensity, step_size_args, value_and_grad
+from .base import SamplingAlgorithm
+from .hmc import HMCInfo, IntegratorState
+from .random import key_spec, key_words
+
+__all__ = ["GHMCState", "init", "build_kernel", "as_top_level_api"]
+
+
+class GHMCState(NamedTuple):
+    """blackjax/mcmc/ghmc.py:32-50, batched: (N, D), (N, D), (N,), (N, D), (N,)."""
+
+    position: torch.Tensor
+    momentum: torch.Tensor
+    logdensity: torch.Tensor
+    logdensity_grad: torch.Tensor
+    slice: torch.Tensor
+
+
+def init(position: torch.Tensor, logdensity_fn: Callable, rng_key, *, chain_offset: int = 0) -> GHMCState:
+    """blackjax/mcmc/ghmc.py:53-64: chain ``i`` draws its momentum and slice from
+    ``split(rng_key, N)[i]`` (the layout of meads_adaptation.py:726-727)."""
+    position = check_batch(position, "position")
+    if position.ndim != 2:
+        raise ValueError(f"position must be (n_chains, dim), got {tuple(position.shape)}")
+    logp, grad = eval_logdensity(value_and_grad(logdensity_fn), position)
+    N, D = position.shape
+    k0, k1 = key_words(rng_key)
+    momentum = torch.empty_like(position)
+    sl = torch.empty(N, dtype=torch.float32, device=position.device)
+    _lib.call("bjx_ghmc_init", _lib.current_stream(), k0, k1, int(chain_offset), N, D, momentum.data_ptr(),
+              sl.data_ptr())
+    return GHMCState(position, momentum, logp, grad, sl)
+
+
+def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, device):
+    """ghmc.py:67-86, legacy branch: the per-dimension inverse scale, squared.  -> (imm tensor,
+    row stride 0 | D)."""
+    x = momentum_inverse_scale
+    if isinstance(x, (metrics.Metric,)) or callable(x):
+        raise NotImplementedError("ghmc: only the per-dimension inverse-scale form of the momentum metric is built")
+    t = torch.as_tensor(x, dtype=torch.float32, device=device)
+    if t.ndim == 0:
+        t = t.expand(dim)
+    if t.ndim == 2 and t.shape == (dim, dim) and not isinstance(x, metrics.PerChainDiagTensor):
+        if n_chains != dim:
+            raise NotImplementedError("ghmc: a dense (d, d) momentum metric is outside the built scope "
+                                      "(per-dimension inverse scales: scalar, (D,) or per-chain (N, D))")
+    if t.shape not in ((dim,), (n_chains, dim)):
+        raise ValueError(f"momentum_inverse_scale must be a scalar, ({dim},) or ({n_chains}, {dim}); got {tuple(t.shape)}")
+    t = t.contiguous()
+    return (t * t).contiguous(), (dim if t.ndim == 2 else 0)
+
+
+def _per_chain_or_scalar(x, n_chains: int, device, name: str):
+    """-> (scalar, per-chain tensor or None)."""
+    if isinstance(x, torch.Tensor) and x.ndim > 0:
+        t = x.to(device=device, dtype=torch.float32).contiguous()
+        if t.shape != (n_chains,):
+            raise ValueError(f"per-chain {name} must have shape ({n_chains},), got {tuple(t.shape)}")
+        return 0.0, t
+    return float(x), None
+
+
+def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
+    """blackjax/mcmc/ghmc.py:89-200.  ``noise_fn`` other than the default (no noise on the slice
+    translation) is out of scope."""
+    if noise_fn is not None:
+        raise NotImplementedError("ghmc: a slice noise_fn is outside the built scope (default: none)")
+    thr = float(divergence_threshold)
+
+    def kernel(rng_key, state: GHMCState, logdensity_fn: Callable, step_size, momentum_inverse_scale,
+               alpha, delta, *, chain_offset: int = 0, skip_chains=None):
+        """``skip_chains = (begin, end)``: those chains keep their state (MEADS freezes one fold per
+        step, meads_adaptation.py:664-677); their info entries are still those of the proposal."""
+        q0 = check_batch(state.position, "state.position")
+        p_prev = check_batch(state.momentum, "state.momentum")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        sl_prev = check_batch(state.slice, "state.slice")
+        N, D = q0.shape
+        dev = q0.device
+        k0, k1, fold = key_spec(rng_key)
+        vg = value_and_grad(logdensity_fn)
+        imm, imm_stride = inverse_mass_from_scale(momentum_inverse_scale, N, D, dev)
+        eps, eps_pc = step_size_args(step_size, N, dev)
+        a_s, a_pc = _per_chain_or_scalar(alpha, N, dev, "alpha")
+        d_s, d_pc = _per_chain_or_scalar(delta, N, dev, "delta")
+        stream = _lib.current_stream()
+        p = torch.empty_like(q0)
+        sl = torch.empty_like(sl_prev)
+        ke0 = torch.empty_like(logp0)
+        _lib.call("bjx_ghmc_refresh", stream, k0, k1, int(chain_offset), fold, N, D, imm.data_ptr(), imm_stride,
+                  a_s, _lib.ptr(a_pc), d_s, _lib.ptr(d_pc), p_prev.data_ptr(), sl_prev.data_ptr(), p.data_ptr(),
+                  sl.data_ptr(), ke0.data_ptr())
+        q1, p_half = torch.empty_like(q0), torch.empty_like(q0)
+        _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm.data_ptr(), imm_stride,
+                  q0.data_ptr(), p.data_ptr(), g0.data_ptr(), q1.data_ptr(), p_half.data_ptr())
+        logp1, g1 = eval_logdensity(vg, q1)
+        q_new, p_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
+        logp_new, sl_new = torch.empty_like(logp0), torch.empty_like(sl_prev)
+        acc_rate, energy = torch.empty_like(logp0), torch.empty_like(logp0)
+        is_acc = torch.empty(N, dtype=torch.uint8, device=dev)
+        is_div = torch.empty(N, dtype=torch.uint8, device=dev)
+        p_end = torch.empty_like(q0)
+        s_lo, s_hi = (0, 0) if skip_chains is None else (int(skip_chains[0]), int(skip_chains[1]))
+        _lib.call("bjx_ghmc_finish", _lib.current_stream(), N, D, eps, _lib.ptr(eps_pc), imm.data_ptr(), imm_stride,
+                  thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(), p.data_ptr(), sl.data_ptr(),
+                  p_prev.data_ptr(), sl_prev.data_ptr(), q1.data_ptr(), p_half.data_ptr(), logp1.data_ptr(),
+                  g1.data_ptr(), s_lo, s_hi, q_new.data_ptr(), p_new.data_ptr(), logp_new.data_ptr(),
+                  g_new.data_ptr(), sl_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(),
+                  energy.data_ptr(), p_end.data_ptr())
+        info = HMCInfo(p, acc_rate, is_acc.bool(), is_div.bool(), energy,
+                       IntegratorState(q1, p_end, logp1, g1), 1)
+        return GHMCState(q_new, p_new, logp_new, g_new, sl_new), info
+
+    return kernel
+
+
+def as_top_level_api(logdensity_fn: Callable, step_size, momentum_inverse_scale, alpha, delta, *,
+                     divergence_threshold: int = 1000, noise_fn=None, chain_offset: int = 0) -> SamplingAlgorithm:
+    """blackjax/mcmc/ghmc.py:226-317: ``init(position, rng_key)``, ``step(rng_key, state)``."""
+    kernel = build_kernel(noise_fn, divergence_threshold)
+
+    def init_fn(position, rng_key=None):
+        if rng_key is None:
+            raise ValueError("ghmc.init needs an rng_key (momentum and slice are drawn at initialisation)")
+        return init(position, logdensity_fn, rng_key, chain_offset=chain_offset)
+
+    def step_fn(rng_key, state):
+        return kernel(rng_key, state, logdensity_fn, step_size, momentum_inverse_scale, alpha, delta,
+                      chain_offset=chain_offset)
+
+    return SamplingAlgorithm(init_fn, step_fn)

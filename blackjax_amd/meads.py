@@ -1,0 +1,188 @@
+"""MEADS: cross-chain adaptation of Generalized HMC (blackjax/adaptation/meads_adaptation.py).
+
+``meads_adaptation(logdensity_fn, num_chains, num_folds=4, ...).run(rng_key, positions, num_steps)``
+follows Algorithm 3 of Hoffman & Sountsov (2022) as the reference implements it (316-787): the chains
+are split into ``num_folds`` contiguous folds; at step ``t`` the fold ``t mod K`` is frozen, every
+fold gets its step size from the LEFT neighbour fold's preconditioned gradients and its damping from
+its own whitened positions, and every ``K`` steps the chains are reshuffled over the folds with
+``jax.random.permutation`` (restated on the host: it depends on the key only).  The transition is
+``blackjax_amd.ghmc`` with per-chain step size / scale / alpha / delta.
+
+Scope: the diagonal momentum metric (``low_rank_rank=None``, the reference's default and "the
+original behavior"); the MEADS-LRD low-rank extension raises.  Single process: the folds and the
+reshuffle span the whole ensemble, so under chain sharding this warm-up would exchange entire states
+every ``K`` steps -- run it on one GPU.
+
+Where the work is: the GHMC transition is HIP (include/bjx_ghmc.h).  The fold statistics are three
+reductions over chains per fold and step -- a standard deviation and two Gram-matrix traces for
+``maximum_eigenvalue`` (790-817; ``||X X^T||_F = ||X^T X||_F``, so the smaller Gram matrix is formed)
+-- done here as library GEMMs / reductions in fp64 (``torch``: rocBLAS), rounded once, which is this
+repo's numerics contract for cross-chain sums (XLA's fp32 reduction order is unspecified).
+"""
+from __future__ import annotations
+
+from typing import Callable, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import ghmc as _ghmc
+from . import random as bjx_random
+from .adaptation import AdaptationResults, return_all_adapt_info
+from .base import AdaptationAlgorithm
+from .util import stack_history
+
+__all__ = ["MEADSAdaptationState", "base", "maximum_eigenvalue", "meads_adaptation"]
+
+
+class MEADSAdaptationState(NamedTuple):
+    """meads_adaptation.py:31-52: ``step_size`` / ``alpha`` / ``delta`` (K,), ``position_sigma`` (K, D)."""
+
+    current_iteration: int
+    step_size: torch.Tensor
+    position_sigma: torch.Tensor
+    alpha: torch.Tensor
+    delta: torch.Tensor
+
+
+def maximum_eigenvalue(matrix: torch.Tensor) -> torch.Tensor:
+    """meads_adaptation.py:790-817 for an ``(n, d)`` batch or a stack ``(K, n, d)`` of batches:
+    ``(sum S^2 - sum diag(S)^2) / (n (n - 1)) / (sum diag(S) / n)`` with ``S = X X^T``."""
+    x = matrix.double()
+    n, d = x.shape[-2:]
+    xt = x.transpose(-1, -2)
+    gram = x @ xt if n <= d else xt @ x
+    row_sq = (x * x).sum(-1)
+    lam = row_sq.sum(-1) / n
+    lam_sq = ((gram * gram).sum((-1, -2)) - (row_sq * row_sq).sum(-1)) / (n * (n - 1))
+    return (lam_sq / lam).float()
+
+
+def _fold_std(x: torch.Tensor) -> torch.Tensor:
+    """Population standard deviation over the chain axis (``jnp.std``, ddof = 0)."""
+    return x.double().std(dim=-2, unbiased=False).float()
+
+
+def _step_size(precond_grads: torch.Tensor, multiplier: float) -> torch.Tensor:
+    """Algorithm 3 line 8 (583-588)."""
+    eps = torch.as_tensor(multiplier, dtype=torch.float32, device=precond_grads.device) / torch.sqrt(
+        maximum_eigenvalue(precond_grads))
+    return torch.minimum(eps, torch.ones_like(eps))
+
+
+def _damping(lam_max: torch.Tensor, eps: torch.Tensor, t: int, damping_slowdown: float):
+    """Algorithm 3 lines 9-10 (604-614) given lambda_max of the whitened, centred positions."""
+    g1 = 1.0 / torch.sqrt(lam_max)
+    g2 = torch.as_tensor(damping_slowdown, dtype=torch.float32, device=eps.device) / (
+        torch.as_tensor(float(t + 1), dtype=torch.float32, device=eps.device) * eps)
+    gamma = torch.maximum(g1, g2)
+    arg = (-2.0 * eps) * gamma
+    alpha = 1.0 - torch.exp(arg.double()).float()  # fp64 exp, rounded once
+    return alpha, alpha / 2.0
+
+
+def base(num_folds: int = 4, step_size_multiplier: float = 0.5, damping_slowdown: float = 1.0):
+    """meads_adaptation.py:55-212: ``(init, update)`` of the per-fold parameter table."""
+    if num_folds < 1:
+        raise ValueError(f"num_folds must be >= 1, got {num_folds}.")
+
+    def compute_parameters(positions, logdensity_grad, current_iteration):
+        mean = positions.double().mean(dim=0).float()
+        sd = _fold_std(positions)
+        normalized = (positions - mean) / sd
+        eps = _step_size(logdensity_grad * sd, step_size_multiplier)
+        alpha, delta = _damping(maximum_eigenvalue(normalized), eps, current_iteration, damping_slowdown)
+        return eps, sd, alpha, delta
+
+    def init(positions, logdensity_grad) -> MEADSAdaptationState:
+        eps, sd, alpha, delta = compute_parameters(positions, logdensity_grad, 0)
+        return MEADSAdaptationState(0, eps.expand(num_folds).clone(), sd[None].expand(num_folds, -1).clone(),
+                                    alpha.expand(num_folds).clone(), delta.expand(num_folds).clone())
+
+    def update(adaptation_state: MEADSAdaptationState, positions, logdensity_grad, source_fold: int):
+        target = (source_fold + 1) % num_folds
+        t = adaptation_state.current_iteration
+        eps, sd, alpha, delta = compute_parameters(positions, logdensity_grad, t)
+        step_size, sigma = adaptation_state.step_size.clone(), adaptation_state.position_sigma.clone()
+        alphas, deltas = adaptation_state.alpha.clone(), adaptation_state.delta.clone()
+        step_size[target], sigma[target], alphas[target], deltas[target] = eps, sd, alpha, delta
+        return MEADSAdaptationState(t + 1, step_size, sigma, alphas, deltas)
+
+    return init, update
+
+
+def _permutation(rng_key, n: int) -> np.ndarray:
+    """``jax.random.permutation(key, n)`` (jax/_src/random.py::_shuffle): ceil(3 ln n / ln(2^32 - 1))
+    rounds of a stable sort by fresh 32-bit keys, ``key, subkey = split(key)`` per round."""
+    x = np.arange(n, dtype=np.int64)
+    rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(float(2**32 - 1))))
+    key = rng_key
+    for _ in range(rounds):
+        key, sub = bjx_random.split(key, 2)
+        words = bjx_random.split(sub, n)  # random_bits(sub, 32, (n,))[i] = xor of the words of child i
+        bits = words[:, 0] ^ words[:, 1]
+        x = x[np.argsort(bits, kind="stable")]
+    return x
+
+
+def meads_adaptation(logdensity_fn: Callable, num_chains: int, num_folds: int = 4,
+                     step_size_multiplier: float = 0.5, damping_slowdown: float = 1.0,
+                     adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
+                     low_rank_rank: Optional[int] = None,
+                     low_rank_window_fraction: float = 0.5) -> AdaptationAlgorithm:
+    """meads_adaptation.py:316-787 (diagonal momentum metric)."""
+    del low_rank_window_fraction
+    if num_folds < 1:
+        raise ValueError(f"num_folds must be >= 1, got {num_folds}.")
+    if num_chains % num_folds != 0:
+        raise ValueError(f"num_chains ({num_chains}) must be divisible by num_folds ({num_folds}).")
+    if low_rank_rank is not None:
+        raise NotImplementedError("meads_adaptation: the MEADS-LRD low-rank momentum metric is outside the built "
+                                  "scope (diagonal metric, low_rank_rank=None)")
+    K, n = int(num_folds), num_chains // num_folds
+    kernel = _ghmc.build_kernel()
+    adapt_init, _ = base(K, step_size_multiplier, damping_slowdown)
+
+    def one_step(rng_key, states: _ghmc.GHMCState, ad: MEADSAdaptationState):
+        t = ad.current_iteration
+        N, D = states.position.shape
+        shuffle_key = bjx_random.split(rng_key, 1, offset=N)[0]  # keys[num_chains] of split(key, N + 1)
+        pos = states.position.reshape(K, n, D)
+        grads = states.logdensity_grad.reshape(K, n, D)
+        scales = _fold_std(pos)  # (K, D)
+        eps_own = _step_size(grads * scales[:, None, :], step_size_multiplier)  # (K,)
+        eps_rolled = torch.roll(eps_own, 1)  # fold k takes the step size of fold k - 1
+        scales_rolled = torch.roll(scales, 1, dims=0)
+        whitened = pos / scales[:, None, :]  # each fold by its OWN scale (618-622)
+        centred = whitened - whitened.double().mean(dim=1, keepdim=True).float()
+        alphas, deltas = _damping(maximum_eigenvalue(centred), eps_rolled, t, damping_slowdown)
+        skip = (t % K * n, (t % K + 1) * n) if K > 1 else None  # Algorithm 3 line 4
+        new_states, info = kernel(rng_key, states, logdensity_fn, eps_rolled.repeat_interleave(n),
+                                  scales_rolled.repeat_interleave(n, dim=0), alphas.repeat_interleave(n),
+                                  deltas.repeat_interleave(n), skip_chains=skip)
+        new_ad = MEADSAdaptationState(t + 1, eps_rolled, scales_rolled, alphas, deltas)
+        if K > 1 and (t + 1) % K == 0:
+            perm = torch.as_tensor(_permutation(shuffle_key, N), device=states.position.device)
+            new_states = _ghmc.GHMCState(*[a.index_select(0, perm) for a in new_states])
+        return new_states, new_ad, info
+
+    def run(rng_key, positions: torch.Tensor, num_steps: int = 1000):
+        if positions.shape[0] != num_chains:
+            raise ValueError(f"positions has {positions.shape[0]} chains, expected num_chains = {num_chains}")
+        key_init, key_adapt = bjx_random.split(rng_key, 2)
+        states = _ghmc.init(positions, logdensity_fn, key_init)
+        ad = adapt_init(states.position, states.logdensity_grad)
+        history = []
+        for key in bjx_random.split(key_adapt, int(num_steps)):
+            states, ad, info = one_step(key, states, ad)
+            if adaptation_info_fn is not None:
+                history.append(adaptation_info_fn(states, info, ad))
+        parameters = {
+            "step_size": ad.step_size.double().mean().float(),
+            "momentum_inverse_scale": ad.position_sigma.double().mean(dim=0).float(),
+            "alpha": ad.alpha.double().mean().float(),
+            "delta": ad.delta.double().mean().float(),
+        }
+        return AdaptationResults(states, parameters), stack_history(history)
+
+    return AdaptationAlgorithm(run)

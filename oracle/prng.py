@@ -195,3 +195,18 @@ def randint(k, minval: int, maxval: int) -> np.ndarray:
     with np.errstate(over="ignore"):
         off = ((hi % span) * mult + (lo % span)) % span
     return (np.int32(minval) + off.astype(np.int32)).astype(np.int32)
+
+
+def permutation(k, n: int) -> np.ndarray:
+    """jax.random.permutation(key, n) for an integer n (jax/_src/random.py::_shuffle): repeated
+    stable sorts by fresh 32-bit keys; rounds = ceil(3 ln n / ln(2^32 - 1)).  Each round
+    ``key, subkey = split(key)``; ``sort_keys = random_bits(subkey, 32, (n,))``."""
+    k = as_key(k)
+    x = np.arange(n, dtype=np.int64)
+    rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(float(2**32 - 1))))
+    for _ in range(rounds):
+        kk = split(k, 2)
+        k, sub = kk[0], kk[1]
+        bits = random_bits(sub, (n,))
+        x = x[np.argsort(bits, kind="stable")]
+    return x

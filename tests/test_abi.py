@@ -12,6 +12,7 @@ def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "bjx_hip.h")).read()
     text += open(os.path.join(ROOT, "include", "bjx_nuts.h")).read()
     text += open(os.path.join(ROOT, "include", "bjx_pool.h")).read()
+    text += open(os.path.join(ROOT, "include", "bjx_ghmc.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bjx_[a-z0-9_]+)\s*\(", text)))
 
