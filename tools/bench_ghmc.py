@@ -23,7 +23,9 @@ import blackjax_amd as bjx  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--chains", type=int, default=65536)
 ap.add_argument("--dim", type=int, default=1024)
-ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--warmup", type=int, default=30, help="untimed transitions: the caching allocator needs a\n"
+                "few dozen steps of 256 MiB temporaries before it stops calling hipMalloc")
 ap.add_argument("--meads-chains", type=int, default=4096)
 ap.add_argument("--meads-steps", type=int, default=40)
 args = ap.parse_args()
@@ -36,13 +38,13 @@ g.manual_seed(0)
 q0 = sig * torch.randn(N, D, device=dev, generator=g)
 alg = bjx.ghmc(fn, 0.3, sig, 0.3, 0.15)
 state = alg.init(q0, bjx.random.key(0))
-keys = bjx.random.split(bjx.random.key(1), args.steps + 5)
+keys = bjx.random.split(bjx.random.key(1), args.steps + args.warmup)
 acc = torch.zeros((), device=dev)
-for k in keys[:5]:
+for k in keys[:args.warmup]:
     state, info = alg.step(k, state)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for k in keys[5:]:
+for k in keys[args.warmup:]:
     state, info = alg.step(k, state)
     acc += info.acceptance_rate.mean()
 torch.cuda.synchronize()
