@@ -15,6 +15,9 @@ What it records (all under jax's default ``jax_threefry_partitionable``, float32
             L = 10, eps = 0.1, identity mass), vmapped with ``split(step_key, N)`` chain keys
   nuts_funnel  one ``blackjax.nuts`` transition, 16 chains on the 10-dim funnel (eps 0.2, depth <= 6)
   window_adaptation  a 40-step ``window_adaptation(hmc, L = 6)`` of 4 vmapped chains, 8 dims
+  ghmc_meads  ``jax.random.permutation`` / ``uniform(minval=-1, maxval=1)`` streams, three vmapped
+            ``blackjax.ghmc`` transitions (16 chains x 6 dims) and a 12-step ``meads_adaptation`` run
+            (16 chains, 4 folds: freezing, cross-fold roll, three reshuffles)
 
 tests/test_jax_fixtures.py loads the file when present and compares the oracle (CPU) and the HIP
 path (GPU) with it; until then the RNG bit stream stays "parity unpinned" (DESIGN.md section 3).
@@ -138,12 +141,53 @@ def window_adaptation():
             "acceptance_rate_per_step": f32hex(acc)}
 
 
+def ghmc_meads():
+    import blackjax
+
+    N, D = 16, 6
+    sig = 10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))
+    inv_var = jnp.asarray(1.0 / (sig * sig), jnp.float32)
+
+    def logdensity(q):
+        return -0.5 * jnp.sum(q * q * inv_var)
+
+    out = {"N": N, "D": D,
+           "permutation": {str(n): np.asarray(jax.random.permutation(jax.random.key(5), n)).tolist()
+                           for n in (1, 2, 16, 1000)},
+           "uniform_pm1": f32hex(jax.random.uniform(jax.random.key(6), (5,), jnp.float32, -1.0, 1.0))}
+    q0 = jnp.asarray(sig, jnp.float32) * jax.random.normal(jax.random.key(21), (N, D), jnp.float32)
+    alg = blackjax.ghmc(logdensity, 0.7, jnp.asarray(sig, jnp.float32), 0.4, 0.2)
+    init_key = jax.random.key(7)
+    states = jax.vmap(alg.init)(q0, jax.random.split(init_key, N))
+    out["init_key"] = words(init_key)
+    out["init_momentum"], out["init_slice"] = f32hex(states.momentum), f32hex(states.slice)
+    step_keys = jax.random.split(jax.random.key(9), 3)
+    out["step_keys"] = words(step_keys)
+    out["steps"] = []
+    for k in step_keys:
+        states, info = jax.jit(jax.vmap(alg.step))(jax.random.split(k, N), states)
+        out["steps"].append({"is_accepted": np.asarray(info.is_accepted).astype(int).tolist(),
+                             "acceptance_rate": f32hex(info.acceptance_rate), "position": f32hex(states.position),
+                             "momentum": f32hex(states.momentum), "slice": f32hex(states.slice)})
+    warm = blackjax.meads_adaptation(logdensity, num_chains=N, num_folds=4)
+    run_key = jax.random.key(5)
+    (last, params), info = warm.run(run_key, 1.5 * q0, num_steps=12)
+    out["meads"] = {"run_key": words(run_key), "num_steps": 12, "q0_scale": 1.5,
+                    "step_size_per_step": f32hex(info.adaptation_state.step_size),
+                    "alpha_per_step": f32hex(info.adaptation_state.alpha),
+                    "is_accepted_per_step": np.asarray(info.info.is_accepted).astype(int).tolist(),
+                    "final_position": f32hex(last.position),
+                    "parameters": {k: f32hex(v) for k, v in params.items()}}
+    return out
+
+
 def main():
     out = {"generator": "tests/golden/gen_jax_fixtures.py", "prng": prng_fixtures()}
     try:
         out["hmc_c1"] = hmc_c1()
         out["nuts_funnel"] = nuts_funnel()
         out["window_adaptation"] = window_adaptation()
+        out["ghmc_meads"] = ghmc_meads()
     except ImportError as e:
         print(f"blackjax not importable ({e}): wrote the prng section only", file=sys.stderr)
     path = os.path.join(HERE, "jax_fixtures.json")

@@ -132,6 +132,44 @@ def test_oracle_window_adaptation_matches_blackjax():
 
 
 @needs_fixture
+def test_oracle_ghmc_and_meads_match_blackjax():
+    """``jax.random.permutation`` / ``uniform(-1, 1)`` streams, three ``blackjax.ghmc`` transitions and a
+    12-step ``meads_adaptation`` run (fold freezing, cross-fold roll, three reshuffles)."""
+    from oracle import ghmc as oghmc
+    from oracle import meads as omeads
+
+    fx = load().get("ghmc_meads")
+    if fx is None:
+        pytest.skip("fixture file predates the ghmc_meads section")
+    for n, perm in fx["permutation"].items():
+        assert prng.permutation(prng.key(5), int(n)).tolist() == perm
+    assert np.array_equal(prng.uniform(prng.key(6), (5,), -1.0, 1.0), unhex(fx["uniform_pm1"]))
+    N, D = fx["N"], fx["D"]
+    sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(f32)
+    fn = otargets.diag_gaussian((f32(1) / (sig * sig)).astype(f32))
+    q0 = (sig * prng.normal(prng.key(21), (N, D))).astype(f32)
+    st = oghmc.init(q0, fn, np.asarray(fx["init_key"], np.uint32))
+    assert ulps(st.momentum, unhex(fx["init_momentum"])).max() <= 2
+    assert np.array_equal(st.slice, unhex(fx["init_slice"]))
+    for k, rec in zip(np.asarray(fx["step_keys"], np.uint32), fx["steps"]):
+        st, info = oghmc.kernel(k, st, fn, 0.7, sig, 0.4, 0.2)
+        assert info.is_accepted.astype(int).tolist() == rec["is_accepted"]
+        np.testing.assert_allclose(info.acceptance_rate, unhex(rec["acceptance_rate"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st.position, unhex(rec["position"]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st.momentum, unhex(rec["momentum"]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st.slice, unhex(rec["slice"]), rtol=1e-4, atol=1e-6)
+    m = fx["meads"]
+    last, params, hist = omeads.run(np.asarray(m["run_key"], np.uint32), (f32(m["q0_scale"]) * q0).astype(f32), fn,
+                                    m["num_steps"], num_folds=4)
+    np.testing.assert_allclose(np.stack([h[1].step_size for h in hist]), unhex(m["step_size_per_step"]), rtol=1e-4)
+    np.testing.assert_allclose(np.stack([h[1].alpha for h in hist]), unhex(m["alpha_per_step"]), rtol=1e-4)
+    assert np.stack([h[2].is_accepted for h in hist]).astype(int).tolist() == m["is_accepted_per_step"]
+    np.testing.assert_allclose(last.position, unhex(m["final_position"]), rtol=1e-3, atol=1e-5)
+    for name, v in m["parameters"].items():
+        np.testing.assert_allclose(params[name], unhex(v), rtol=1e-4)
+
+
+@needs_fixture
 @pytest.mark.gpu
 def test_hip_path_matches_blackjax(dev):
     """The HIP kernels against JAX's own numbers (no oracle in between)."""
