@@ -196,6 +196,8 @@ SIGNATURES.update({
     "bjx_ghmc_init": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, _f32p, _f32p],
     "bjx_ghmc_refresh": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p, c_int64,
                          c_float, _f32p, c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_ghmc_refresh_kick": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p, c_int64,
+                              c_float, _f32p, c_float, _f32p, c_float, _f32p] + [_f32p] * 9,
     "bjx_ghmc_finish": [c_void_p, c_int64, c_int64, c_float, _f32p, _f32p, c_int64, c_float]
                        + [_f32p] * 12 + [c_int64, c_int64] + [_f32p] * 6 + [_u8p, _u8p, _f32p, _f32p],
 })

@@ -57,13 +57,18 @@ k_ghmc_init(Key key, int64_t off, int64_t N, int64_t D, float* __restrict__ p_ou
 }
 
 // ghmc.py:168-176 (+ 203-223), metrics.py:260-270
-template <int VEC>
+// KICK: the opening half kick and the drift of the transition's one leapfrog ride along (the arithmetic of
+// k_leapfrog_diag with n_kicks = 1: p_half = fma(eps/2, g0, p); q1 = fma(eps, imm * p_half, q0)) -- the
+// refresh is bound by its RNG arithmetic, so the leapfrog's five words per element cost nothing here.
+template <int VEC, bool KICK>
 __global__ void __launch_bounds__(kBlock)
 k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
                int64_t imm_stride, float alpha_s, const float* __restrict__ alpha_pc, float delta_s,
                const float* __restrict__ delta_pc, const float* __restrict__ p_prev,
                const float* __restrict__ slice_prev, float* __restrict__ p_out,
-               float* __restrict__ slice_out, float* __restrict__ ke_out) {
+               float* __restrict__ slice_out, float* __restrict__ ke_out, float eps_s,
+               const float* __restrict__ eps_pc, const float* __restrict__ q0, const float* __restrict__ g0,
+               float* __restrict__ q1_out, float* __restrict__ p_half_out) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const Key kc = chain_key(key, (uint64_t)(r + off), fold);
@@ -72,6 +77,8 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
     const float s1 = sqrtf(1.0f - alpha), s2 = sqrtf(alpha);
     const float* im = imm + r * imm_stride;
     const int64_t base = r * D;
+    const float eps = KICK ? (eps_pc ? eps_pc[r] : eps_s) : 0.0f;
+    const float h = eps * 0.5f, ed = eps * 1.0f;
     double acc = 0.0;
     for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
       float m[VEC], pp[VEC], pn[VEC];
@@ -86,6 +93,18 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
         acc += (double)(m[e] * pn[e]) * (double)pn[e];
       }
       stv<VEC>(p_out + base + j, pn);
+      if constexpr (KICK) {
+        float gg[VEC], qq[VEC], ph[VEC], qn[VEC];
+        ldv<VEC>(g0 + base + j, gg);
+        ldv<VEC>(q0 + base + j, qq);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          ph[e] = fmaf(h, gg[e], pn[e]);
+          qn[e] = fmaf(ed, m[e] * ph[e], qq[e]);
+        }
+        stv<VEC>(p_half_out + base + j, ph);
+        stv<VEC>(q1_out + base + j, qn);
+      }
     }
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -186,6 +205,104 @@ k_ghmc_finish(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps_p
   }
 }
 
+// The same for rows of at most 256 * NI floats (16-byte accesses): the end momentum and the new gradient
+// stay in registers between the energy pass and the state select, so an accepted chain (the common
+// case) re-reads nothing -- 7 words per element instead of 9.
+template <int NI>
+__global__ void __launch_bounds__(kBlock)
+k_ghmc_finish_res(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps_pc,
+                  const float* __restrict__ imm, int64_t imm_stride, float thr, const float* __restrict__ q0,
+                  const float* __restrict__ logp0, const float* __restrict__ g0, const float* __restrict__ ke0,
+                  const float* __restrict__ p, const float* __restrict__ sl, const float* __restrict__ p_prev,
+                  const float* __restrict__ sl_prev, const float* __restrict__ q1,
+                  const float* __restrict__ p_half, const float* __restrict__ logp1,
+                  const float* __restrict__ g1, int64_t skip_begin, int64_t skip_end, float* __restrict__ q_out,
+                  float* __restrict__ p_out, float* __restrict__ logp_out, float* __restrict__ g_out,
+                  float* __restrict__ slice_out, float* __restrict__ acc_rate_out,
+                  uint8_t* __restrict__ is_acc_out, uint8_t* __restrict__ is_div_out,
+                  float* __restrict__ energy_out, float* __restrict__ p_end_out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    const float eps = eps_pc ? eps_pc[r] : eps_s;
+    const float h = eps * 0.5f;
+    const int64_t base = r * D;
+    const float* im = imm + r * imm_stride;
+    const bool skipped = r >= skip_begin && r < skip_end;
+    F4 M[NI], P1[NI], G1[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int64_t j = ((int64_t)lane + 64 * k) * 4;
+      ok[k] = j < D;
+      if (ok[k]) {
+        M[k] = ld4(im + j);
+        P1[k] = ld4(p_half + base + j);
+        G1[k] = ld4(g1 + base + j);
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        const int64_t j = ((int64_t)lane + 64 * k) * 4;
+        F4& pn = P1[k];
+        pn.x = fmaf(h, G1[k].x, pn.x); pn.y = fmaf(h, G1[k].y, pn.y);
+        pn.z = fmaf(h, G1[k].z, pn.z); pn.w = fmaf(h, G1[k].w, pn.w);
+        acc += (double)(M[k].x * pn.x) * (double)pn.x;
+        acc += (double)(M[k].y * pn.y) * (double)pn.y;
+        acc += (double)(M[k].z * pn.z) * (double)pn.z;
+        acc += (double)(M[k].w * pn.w) * (double)pn.w;
+        if (p_end_out) st4(p_end_out + base + j, F4{-1.0f * pn.x, -1.0f * pn.y, -1.0f * pn.z, -1.0f * pn.w});
+      }
+    acc = wave_sum(acc);
+    const float ke1 = 0.5f * (float)acc;
+    const float lp0 = logp0[r], lp1 = logp1[r];
+    const float H0 = -lp0 + ke0[r];
+    const float H1 = -lp1 + ke1;
+    float dE = H0 - H1;
+    if (dE != dE) dE = -__builtin_inff();
+    const bool is_div = (-dE) > thr;
+    const float p_acc = fminf(exp_cr(dE), 1.0f);
+    const float s = sl[r];
+    const float log_abs = (float)log((double)fabsf(s));
+    const bool accept = log_abs <= dE;
+    const float accf = accept ? 1.0f : 0.0f;
+    const float t1 = exp_cr(-dE) * accf, t2 = 1.0f - accf;
+    const float s_next = s * (t1 + t2);
+    if (lane == 0) {
+      acc_rate_out[r] = p_acc;
+      is_acc_out[r] = accept ? 1 : 0;
+      is_div_out[r] = is_div ? 1 : 0;
+      energy_out[r] = H1;
+      logp_out[r] = skipped ? lp0 : (accept ? lp1 : lp0);
+      slice_out[r] = skipped ? sl_prev[r] : s_next;
+    }
+    const bool take = accept && !skipped;
+    if (take) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          const int64_t j = ((int64_t)lane + 64 * k) * 4;
+          st4(q_out + base + j, ld4(q1 + base + j));
+          st4(g_out + base + j, G1[k]);
+          st4(p_out + base + j, P1[k]);
+        }
+    } else {
+      const float* ps = skipped ? p_prev : p;
+      const float sgn = skipped ? 1.0f : -1.0f;
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          const int64_t j = ((int64_t)lane + 64 * k) * 4;
+          const F4 pm = ld4(ps + base + j);
+          st4(q_out + base + j, ld4(q0 + base + j));
+          st4(g_out + base + j, ld4(g0 + base + j));
+          st4(p_out + base + j, skipped ? pm : F4{sgn * pm.x, sgn * pm.y, sgn * pm.z, sgn * pm.w});
+        }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -218,13 +335,38 @@ int bjx_ghmc_refresh(void* stream, uint32_t key0, uint32_t key1, int64_t chain_o
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
 #define BJX_REFRESH(V)                                                                                   \
-  hipLaunchKernelGGL(k_ghmc_refresh<V>, grid, block, 0, (hipStream_t)stream, key, chain_offset, step_fold, \
-                     N, D, imm, imm_stride, alpha, alpha_per_chain, delta, delta_per_chain, p_prev,        \
-                     slice_prev, p_out, slice_out, ke_out)
+  hipLaunchKernelGGL((k_ghmc_refresh<V, false>), grid, block, 0, (hipStream_t)stream, key, chain_offset,   \
+                     step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain, delta, delta_per_chain,     \
+                     p_prev, slice_prev, p_out, slice_out, ke_out, 0.0f, nullptr, nullptr, nullptr,        \
+                     nullptr, nullptr)
   if (bjx_vec4_ok(D, imm, p_prev, p_out)) BJX_REFRESH(4);
   else BJX_REFRESH(1);
 #undef BJX_REFRESH
   return bjx_check_launch("bjx_ghmc_refresh");
+}
+
+int bjx_ghmc_refresh_kick(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                          int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                          float alpha, const float* alpha_per_chain, float delta,
+                          const float* delta_per_chain, float eps, const float* eps_per_chain,
+                          const float* p_prev, const float* slice_prev, const float* q0, const float* g0,
+                          float* p_out, float* slice_out, float* ke_out, float* q1_out, float* p_half_out) {
+  BJX_CHECK_ARG(N >= 0 && D > 0, "bjx_ghmc_refresh_kick: bad sizes");
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(imm && p_prev && slice_prev && q0 && g0 && p_out && slice_out && ke_out && q1_out && p_half_out,
+                "bjx_ghmc_refresh_kick: null pointer");
+  BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_ghmc_refresh_kick: imm_stride must be 0 or D");
+  const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
+  const Key key{key0, key1};
+#define BJX_REFRESH_KICK(V)                                                                              \
+  hipLaunchKernelGGL((k_ghmc_refresh<V, true>), grid, block, 0, (hipStream_t)stream, key, chain_offset,    \
+                     step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain, delta, delta_per_chain,     \
+                     p_prev, slice_prev, p_out, slice_out, ke_out, eps, eps_per_chain, q0, g0, q1_out,     \
+                     p_half_out)
+  if (bjx_vec4_ok(D, imm, p_prev, p_out, q0, g0, q1_out, p_half_out)) BJX_REFRESH_KICK(4);
+  else BJX_REFRESH_KICK(1);
+#undef BJX_REFRESH_KICK
+  return bjx_check_launch("bjx_ghmc_refresh_kick");
 }
 
 int bjx_ghmc_finish(void* stream, int64_t N, int64_t D, float eps, const float* eps_per_chain,
@@ -249,8 +391,20 @@ int bjx_ghmc_finish(void* stream, int64_t N, int64_t D, float eps, const float* 
                      imm_stride, divergence_threshold, q0, logp0, g0, ke0, p, slice, p_prev, slice_prev,    \
                      q1, p_half, logp1, g1, skip_begin, skip_end, q_out, p_out, logp_out, g_out, slice_out, \
                      acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out, p_end_out)
-  if (bjx_vec4_ok(D, imm, q0, g0, p, p_prev, q1, p_half, g1, q_out, p_out, g_out, p_end_out)) BJX_FINISH(4);
-  else BJX_FINISH(1);
+#define BJX_FINISH_RES(NI_)                                                                                  \
+  hipLaunchKernelGGL(k_ghmc_finish_res<NI_>, grid, block, 0, (hipStream_t)stream, N, D, eps, eps_per_chain,     \
+                     imm, imm_stride, divergence_threshold, q0, logp0, g0, ke0, p, slice, p_prev, slice_prev,  \
+                     q1, p_half, logp1, g1, skip_begin, skip_end, q_out, p_out, logp_out, g_out, slice_out,    \
+                     acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out, p_end_out)
+  if (bjx_vec4_ok(D, imm, q0, g0, p, p_prev, q1, p_half, g1, q_out, p_out, g_out, p_end_out)) {
+    if (D <= 256) BJX_FINISH_RES(1);
+    else if (D <= 512) BJX_FINISH_RES(2);
+    else if (D <= 1024) BJX_FINISH_RES(4);
+    else BJX_FINISH(4);
+  } else {
+    BJX_FINISH(1);
+  }
+#undef BJX_FINISH_RES
 #undef BJX_FINISH
   return bjx_check_launch("bjx_ghmc_finish");
 }

@@ -14,7 +14,7 @@ momentum metric is built (ghmc.py:67-86, legacy branch: inverse mass matrix = sc
 low-rank momentum metrics (blackjax#950) are outside SURVEY.md section 8 and raise.
 
 The arithmetic runs in libbjxhip (include/bjx_ghmc.h, include/bjx_hip.h); this module sequences
-refresh -> kick + drift -> user callable -> finish.
+refresh + kick + drift (one launch) -> user callable -> finish.
 """
 from __future__ import annotations
 
@@ -114,12 +114,12 @@ def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
         p = torch.empty_like(q0)
         sl = torch.empty_like(sl_prev)
         ke0 = torch.empty_like(logp0)
-        _lib.call("bjx_ghmc_refresh", stream, k0, k1, int(chain_offset), fold, N, D, imm.data_ptr(), imm_stride,
-                  a_s, _lib.ptr(a_pc), d_s, _lib.ptr(d_pc), p_prev.data_ptr(), sl_prev.data_ptr(), p.data_ptr(),
-                  sl.data_ptr(), ke0.data_ptr())
         q1, p_half = torch.empty_like(q0), torch.empty_like(q0)
-        _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm.data_ptr(), imm_stride,
-                  q0.data_ptr(), p.data_ptr(), g0.data_ptr(), q1.data_ptr(), p_half.data_ptr())
+        # refresh + the opening kick and drift of the transition's one leapfrog, one launch
+        _lib.call("bjx_ghmc_refresh_kick", stream, k0, k1, int(chain_offset), fold, N, D, imm.data_ptr(), imm_stride,
+                  a_s, _lib.ptr(a_pc), d_s, _lib.ptr(d_pc), eps, _lib.ptr(eps_pc), p_prev.data_ptr(),
+                  sl_prev.data_ptr(), q0.data_ptr(), g0.data_ptr(), p.data_ptr(), sl.data_ptr(), ke0.data_ptr(),
+                  q1.data_ptr(), p_half.data_ptr())
         logp1, g1 = eval_logdensity(vg, q1)
         q_new, p_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         logp_new, sl_new = torch.empty_like(logp0), torch.empty_like(sl_prev)

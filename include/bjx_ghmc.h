@@ -3,7 +3,8 @@
  * reference recommends ChEES / MEADS for thousands of chains, howto_sample_multiple_chains.md:246).
  *
  * A transition is ONE velocity-Verlet step, so per chain and transition the engine runs
- *   bjx_ghmc_refresh -> bjx_leapfrog_diag (n_kicks = 1, bjx_hip.h) -> user callable -> bjx_ghmc_finish.
+ *   bjx_ghmc_refresh_kick (= bjx_ghmc_refresh + bjx_leapfrog_diag with n_kicks = 1, bjx_hip.h)
+ *   -> user callable -> bjx_ghmc_finish.
  * Every parameter may be per chain (MEADS hands every fold its own step size, scale, alpha, delta).
  * Only the per-dimension "inverse scale" form of ghmc's momentum metric is built (ghmc.py:67-86
  * legacy branch: inverse mass matrix = scale ** 2, squared by the caller).
@@ -38,6 +39,17 @@ int bjx_ghmc_refresh(void* stream, uint32_t key0, uint32_t key1, int64_t chain_o
                      float alpha, const float* alpha_per_chain, float delta,
                      const float* delta_per_chain, const float* p_prev, const float* slice_prev,
                      float* p_out, float* slice_out, float* ke_out);
+
+/* bjx_ghmc_refresh followed by bjx_leapfrog_diag(n_kicks = 1) in one launch (same arithmetic, same
+ * results): additionally  p_half = p + (eps_i / 2) g0 ;  q1 = q0 + eps_i * (imm_i * p_half)
+ * (integrators.py:104-150, first half of velocity Verlet).  The refresh is bound by its per-element
+ * RNG arithmetic, so the kick + drift traffic rides along.                                        */
+int bjx_ghmc_refresh_kick(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                          int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                          float alpha, const float* alpha_per_chain, float delta,
+                          const float* delta_per_chain, float eps, const float* eps_per_chain,
+                          const float* p_prev, const float* slice_prev, const float* q0, const float* g0,
+                          float* p_out, float* slice_out, float* ke_out, float* q1_out, float* p_half_out);
 
 /* Second half (hmc.py:153-176 with L = 1, proposal.py:243-264, ghmc.py:186-196), after
  * bjx_leapfrog_diag(n_kicks = 1) produced (q1, p_half) and the callable (logp1, g1):

@@ -41,7 +41,8 @@ def _assert_state(st_g, st_o, tol=1e-6):
     np.testing.assert_allclose(t2n(st_g.slice), st_o.slice, rtol=1e-5, atol=1e-7, equal_nan=True)
 
 
-@pytest.mark.parametrize("N,D,per_chain", [(37, 10, True), (24, 64, True), (16, 64, False), (5, 1, False), (33, 260, True)])
+@pytest.mark.parametrize("N,D,per_chain", [(37, 10, True), (24, 64, True), (16, 64, False), (5, 1, False), (33, 260, True),
+                                            (9, 1024, True), (6, 1032, False)])
 def test_ghmc_transitions_match_oracle(dev, N, D, per_chain):
     """init + 6 consecutive transitions (no re-sync): accept bits and divergence flags exact,
     positions / momenta / slices within 1e-6; per-chain step size, scale, alpha, delta."""

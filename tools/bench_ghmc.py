@@ -2,11 +2,11 @@
 """Secondary benchmark: Generalized HMC transitions (one leapfrog each) at the C2 shape, and a short MEADS
 warm-up at 4 096 chains x 1 024 dims (fold statistics = two D x D fp64 Gram matrices per fold and step).
 
-Algorithmic bytes of a GHMC transition per (chain, dim) element, per-chain scale:
-  refresh   r p_prev, imm         w p                        12 B
-  leapfrog  r q, p, g, imm        w q1, p_half               24 B
-  callable  r q1                  w g1                        8 B
-  finish    r p_half, g1, imm, {q1 | q0}, {g1 | g0}, (p on reject)   w q, g, p, p_end   ~38 B
+Algorithmic bytes of a GHMC transition per (chain, dim) element (shared scale; +4 per launch for a
+per-chain one):
+  refresh + kick + drift  r p_prev, g0, q0     w p, p_half, q1          24 B  (one normal draw per element: VALU-bound)
+  callable                r q1                 w g1                      8 B
+  finish                  r p_half, g1, q1     w q, g, p, p_end         28 B  (accepted chain, D <= 1 024)
 """
 import argparse
 import json
@@ -49,7 +49,7 @@ for k in keys[args.warmup:]:
     acc += info.acceptance_rate.mean()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-bytes_per_elem = 12 + 24 + 8 + 38
+bytes_per_elem = 24 + 8 + 28
 out = {
     "metric": "GHMC chain-leapfrog-steps/s (one leapfrog per transition)",
     "value": N * args.steps / dt, "unit": "chain-leapfrog-steps/s",
