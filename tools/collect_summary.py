@@ -37,7 +37,8 @@ for key, name in [("bench_py_C2", "bench_c2.json"), ("bench_py_C2_two_gloo_ranks
                   ("bench_py_C4_shard", "bench_c4.json"), ("nuts_C3_free_running_T20", "nuts_c3_T20.json"),
                   ("nuts_C3_free_running_T100", "nuts_c3_T100.json"), ("nuts_C3_free_running_T400", "nuts_c3_T400.json"),
                   ("nuts_C3_lockstep_step", "nuts_c3_lockstep.json"), ("dense_C5", "dense_c5.json"),
-                  ("chees_C2", "chees_c2.json"), ("nuts_C3_warmup", "nuts_warmup_c3.json"),
+                  ("chees_C2", "chees_c2.json"), ("ghmc_C2_shape_and_meads", "ghmc_c2.json"),
+                  ("nuts_C3_warmup", "nuts_warmup_c3.json"),
                   ("hmc_small_batches", "hmc_small.json")]:
     j = last_json(name)
     if j is not None:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-box summary of a round: full GPU test suite, smoke(), every bench (C2 default, C2 at 2 gloo ranks
 # on one GPU, C4 shard through bench.py --config c4, C3 NUTS free-running T = 20 / 100 / 400 + lockstep,
-# C5 dense, ChEES at C2, NUTS warm-up) and the rocprofv3 kernel stats of the NUTS and dense runs.
+# C5 dense, ChEES at C2, GHMC + MEADS, NUTS warm-up) and the rocprofv3 kernel stats of the NUTS and dense runs.
 # Outputs land in gpurun_out/round_summary/; tools/collect_summary.py <round> turns them into
 # profiles/<round>/summary_final_<round>.json and copies the kernel-stats CSVs.
 set -u
@@ -18,6 +18,7 @@ for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --
 timeout 600 python tools/bench_nuts.py --use-graph --steps 5 > $O/nuts_c3_lockstep.json 2>> $O/nuts.err
 python tools/bench_dense.py > $O/dense_c5.json 2> $O/dense.err
 python tools/bench_chees.py > $O/chees_c2.json 2> $O/chees.err
+python tools/bench_ghmc.py > $O/ghmc_c2.json 2> $O/ghmc.err
 python tools/bench_nuts_warmup.py > $O/nuts_warmup_c3.json 2> $O/nuts_warmup.err
 python tools/bench_small.py > $O/hmc_small.json 2> $O/small.err
 cd /tmp; export TMPDIR=/tmp
