@@ -24,6 +24,8 @@ SIGNATURES = {
     "bjx_rng_uniform": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, _f32p],
     "bjx_hmc_momentum_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p,
                               c_int64, _f32p, _f32p],
+    "bjx_hmc_momentum_kick_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p,
+                                   c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_leapfrog_diag": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, c_int64,
                           _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_hmc_finish_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_float,

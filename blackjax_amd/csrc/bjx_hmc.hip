@@ -41,16 +41,23 @@ __global__ void __launch_bounds__(kBlock) k_rng_uniform(Key key, int64_t off, in
 
 // ------------------------------------------------------------------------------ momentum draw
 // p0 = (1/sqrt(imm)) * normal(km, (D,)) ; ke0 = 0.5 * sum (imm*p0)*p0   (fp64 accumulate)
-template <int VEC>
+// KICK: the opening half kick and the drift of the trajectory's first leapfrog in the same launch (the
+// arithmetic of k_leapfrog_diag with n_kicks = 1) -- this kernel is bound by its per-element RNG
+// arithmetic, so the leapfrog's words ride along.
+template <int VEC, bool KICK>
 __global__ void __launch_bounds__(kBlock)
 k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
-                int64_t imm_stride, float* __restrict__ p_out, float* __restrict__ ke_out) {
+                int64_t imm_stride, float* __restrict__ p_out, float* __restrict__ ke_out, float eps_s,
+                const float* __restrict__ eps_pc, const float* __restrict__ q0, const float* __restrict__ g0,
+                float* __restrict__ q1_out, float* __restrict__ p_half_out) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const Key kc = chain_key(key, (uint64_t)(r + off), fold);
     const Key km = key_child(kc, 0);  // split(kc, 2)[0]
     const float* im = imm + r * imm_stride;
     float* pr = p_out + r * D;
+    const float eps = KICK ? (eps_pc ? eps_pc[r] : eps_s) : 0.0f;
+    const float h = eps * 0.5f, ed = eps * 1.0f;
     double acc = 0.0;
     for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
       float m[VEC], pv[VEC];
@@ -70,6 +77,29 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
       }
       if constexpr (VEC == 4) st4(pr + j, F4{pv[0], pv[1], pv[2], pv[3]});
       else pr[j] = pv[0];
+      if constexpr (KICK) {
+        float gg[VEC], qq[VEC], ph[VEC], qn[VEC];
+        if constexpr (VEC == 4) {
+          const F4 a = ld4(g0 + r * D + j), b = ld4(q0 + r * D + j);
+          gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w;
+          qq[0] = b.x; qq[1] = b.y; qq[2] = b.z; qq[3] = b.w;
+        } else {
+          gg[0] = g0[r * D + j];
+          qq[0] = q0[r * D + j];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          ph[e] = fmaf(h, gg[e], pv[e]);
+          qn[e] = fmaf(ed, m[e] * ph[e], qq[e]);
+        }
+        if constexpr (VEC == 4) {
+          st4(p_half_out + r * D + j, F4{ph[0], ph[1], ph[2], ph[3]});
+          st4(q1_out + r * D + j, F4{qn[0], qn[1], qn[2], qn[3]});
+        } else {
+          p_half_out[r * D + j] = ph[0];
+          q1_out[r * D + j] = qn[0];
+        }
+      }
     }
     acc = wave_sum(acc);
     if (lane == 0) ke_out[r] = 0.5f * (float)acc;
@@ -637,12 +667,35 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
     else BJX_MOM_SHORT(32);
 #undef BJX_MOM_SHORT
   } else if (bjx_vec4_ok(D, imm, p_out))
-    hipLaunchKernelGGL(k_momentum_diag<4>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
-                       step_fold, N, D, imm, imm_stride, p_out, ke_out);
+    hipLaunchKernelGGL((k_momentum_diag<4, false>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out, 0.0f, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
   else
-    hipLaunchKernelGGL(k_momentum_diag<1>, grid, block, 0, (hipStream_t)stream, key, chain_offset,
-                       step_fold, N, D, imm, imm_stride, p_out, ke_out);
+    hipLaunchKernelGGL((k_momentum_diag<1, false>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out, 0.0f, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
   return bjx_check_launch("bjx_hmc_momentum_diag");
+}
+
+int bjx_hmc_momentum_kick_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                               int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                               float eps, const float* eps_per_chain, const float* q0, const float* g0,
+                               float* p_out, float* ke_out, float* q1_out, float* p_half_out) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
+  BJX_CHECK_ARG(N >= 0 && D > 0 && imm && q0 && g0 && p_out && ke_out && q1_out && p_half_out,
+                "bjx_hmc_momentum_kick_diag: bad arguments");
+  BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_momentum_kick_diag: imm_stride must be 0 or D");
+  const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
+  const Key key{key0, key1};
+  if (bjx_vec4_ok(D, imm, q0, g0, p_out, q1_out, p_half_out))
+    hipLaunchKernelGGL((k_momentum_diag<4, true>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out, eps, eps_per_chain, q0, g0, q1_out,
+                       p_half_out);
+  else
+    hipLaunchKernelGGL((k_momentum_diag<1, true>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
+                       step_fold, N, D, imm, imm_stride, p_out, ke_out, eps, eps_per_chain, q0, g0, q1_out,
+                       p_half_out);
+  return bjx_check_launch("bjx_hmc_momentum_kick_diag");
 }
 
 int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, float kick_a,

@@ -62,6 +62,9 @@ def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:
     return HMCState(position, logp, grad)
 
 
+_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switch
+
+
 def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
     if metric.kind == "diag":
         _lib.call("bjx_leapfrog_diag", stream, N, D, n_kicks, eps, _lib.ptr(eps_pc),
@@ -384,7 +387,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                 m = metric if metric.imm_stride == 0 else metric._replace(imm=metric.imm[sl])
             eb = None if eps_pc is None else eps_pc[sl]
             boff = off + s
-            if m.kind == "diag":
+            # plain velocity-Verlet trajectory on a diagonal metric with rows long enough for the
+            # row-per-wave momentum kernel: the first kick + drift ride along with the momentum draw
+            fused_first = (m.kind == "diag" and L > 0 and not graphed and not general and D > 128 and _FUSE_FIRST)
+            if fused_first:
+                q, p = q_end[sl], p_work[sl]
+                _lib.call("bjx_hmc_momentum_kick_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
+                          m.imm_stride, eps, _lib.ptr(eb), q0[sl].data_ptr(), g0[sl].data_ptr(),
+                          p0[sl].data_ptr(), ke0[sl].data_ptr(), q.data_ptr(), p.data_ptr())
+            elif m.kind == "diag":
                 _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
                           m.imm_stride, p0[sl].data_ptr(), ke0[sl].data_ptr())
             else:
@@ -442,8 +453,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                         stream = _lib.current_stream()
                 eps_fin, eps_pc_fin = eps, eb
             else:
-                q, p = q_end[sl], p_work[sl]
-                p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
+                if not fused_first:
+                    q, p = q_end[sl], p_work[sl]
+                    p = _launch_leapfrog(stream, m, n, D, 1, eps, eb, q0[sl], p0[sl], g0[sl], q, p)
                 logp, g = eval_logdensity(vg, q)
                 for _ in range(L - 1):
                     yield

@@ -64,6 +64,15 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
                           int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
                           float* p_out, float* ke_out);
 
+/* bjx_hmc_momentum_diag followed by bjx_leapfrog_diag(n_kicks = 1) in ONE launch (same arithmetic,
+ * same results): additionally  p_half = p0 + (eps_i / 2) g0 ;  q1 = q0 + eps_i * (imm_i * p_half)
+ * (integrators.py:104-150, first half of the trajectory's first velocity-Verlet step).  The momentum
+ * draw is bound by its per-element RNG arithmetic, so the first kick + drift ride along.          */
+int bjx_hmc_momentum_kick_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                               int64_t step_fold, int64_t N, int64_t D, const float* imm, int64_t imm_stride,
+                               float eps, const float* eps_per_chain, const float* q0, const float* g0,
+                               float* p_out, float* ke_out, float* q1_out, float* p_half_out);
+
 /* Fused velocity-Verlet "kick(s) + drift" for a diagonal metric:
  *   n_kicks = 1:  p = p + (eps/2) g                       (first step of a trajectory)
  *   n_kicks = 2:  p = (p + (eps/2) g) + (eps/2) g         (closing half kick of the previous
