@@ -62,7 +62,8 @@ def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:
     return HMCState(position, logp, grad)
 
 
-_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switch
+_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switches
+_PREFETCH_MOMENTUM = __import__("os").environ.get("BJX_HMC_PREFETCH_MOMENTUM", "1") != "0"
 
 
 def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
@@ -373,28 +374,40 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         if L == 0:
             g_end, logp_end = g0, logp0
 
-        def run_block(b):
-            """One chain block's transition as a generator: yields after every log-density
-            evaluation so that several blocks can be advanced in turn on their own streams."""
-            nonlocal g_end, logp_end
-            stream = _lib.current_stream()
+        prefetched: dict = {}  # block -> event: its momentum draw + first kick was issued on the side stream
+
+        def block_args(b):
             s, e = b * blk, min(N, (b + 1) * blk)
-            n = e - s
             sl = slice(s, e)
             if metric.kind == "dense_pc":  # per-chain matrices travel with their chains
                 m = metric._replace(imm=metric.imm[sl], mass_sqrt_t=metric.mass_sqrt_t[sl])
             else:
                 m = metric if metric.imm_stride == 0 else metric._replace(imm=metric.imm[sl])
-            eb = None if eps_pc is None else eps_pc[sl]
-            boff = off + s
-            # plain velocity-Verlet trajectory on a diagonal metric with rows long enough for the
-            # row-per-wave momentum kernel: the first kick + drift ride along with the momentum draw
-            fused_first = (m.kind == "diag" and L > 0 and not graphed and not general and D > 128 and _FUSE_FIRST)
+            return e - s, sl, m, (None if eps_pc is None else eps_pc[sl]), off + s
+
+        # plain velocity-Verlet trajectory on a diagonal metric with rows long enough for the row-per-wave
+        # momentum kernel: the first kick + drift ride along with the (RNG-bound) momentum draw
+        fused_first = (metric.kind == "diag" and L > 0 and not graphed and not general and D > 128 and _FUSE_FIRST)
+
+        def launch_first(b, stream_):
+            n, sl, m, eb, boff = block_args(b)
+            _lib.call("bjx_hmc_momentum_kick_diag", stream_, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
+                      m.imm_stride, eps, _lib.ptr(eb), q0[sl].data_ptr(), g0[sl].data_ptr(),
+                      p0[sl].data_ptr(), ke0[sl].data_ptr(), q_end[sl].data_ptr(), p_work[sl].data_ptr())
+
+        def run_block(b):
+            """One chain block's transition as a generator: yields after every log-density
+            evaluation so that several blocks can be advanced in turn on their own streams."""
+            nonlocal g_end, logp_end
+            stream = _lib.current_stream()
+            n, sl, m, eb, boff = block_args(b)
             if fused_first:
                 q, p = q_end[sl], p_work[sl]
-                _lib.call("bjx_hmc_momentum_kick_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
-                          m.imm_stride, eps, _lib.ptr(eb), q0[sl].data_ptr(), g0[sl].data_ptr(),
-                          p0[sl].data_ptr(), ke0[sl].data_ptr(), q.data_ptr(), p.data_ptr())
+                ev = prefetched.pop(b, None)
+                if ev is None:
+                    launch_first(b, stream)
+                else:
+                    torch.cuda.current_stream(dev).wait_event(ev)
             elif m.kind == "diag":
                 _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
                           m.imm_stride, p0[sl].data_ptr(), ke0[sl].data_ptr())
@@ -509,7 +522,21 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         # HIP stream: one block's callable (bandwidth-bound), the start-up of its launches and the
         # output drain of a dense-metric GEMM then overlap another block's kernels.
         ns = 1 if (graphed or n_blocks <= 1) else min(int(n_streams), n_blocks)
-        if ns <= 1:
+        if ns <= 1 and fused_first and n_blocks > 1 and _PREFETCH_MOMENTUM:
+            # the NEXT block's momentum draw (VALU-bound: threefry + erf_inv per element) runs on a side
+            # stream under this block's leapfrogs (HBM-bound)
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams(dev, 1)[0]
+            side.wait_stream(main)
+            for b in range(n_blocks):
+                if b + 1 < n_blocks:
+                    with torch.cuda.stream(side):
+                        launch_first(b + 1, _lib.current_stream())
+                        prefetched[b + 1] = side.record_event()
+                for _ in run_block(b):
+                    pass
+            main.wait_stream(side)
+        elif ns <= 1:
             for b in range(n_blocks):
                 for _ in run_block(b):
                     pass
