@@ -415,14 +415,16 @@ def bench_c2(args, ctx):
                 alg_t = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, chain_block=cb, use_graph=gr,
                                 streams=ns_)
                 st_t = alg_t.init(q_init)
-                for kk in bjx.random.split(bjx.random.key(777), 2):  # priming (and graph recording)
+                # 3 priming transitions (graph recording, allocator) + 5 timed ones: with 2 + 2 the
+                # candidates within 3 % of each other were ranked by noise
+                for kk in bjx.random.split(bjx.random.key(777), 3):
                     st_t, _ = alg_t.step(kk, st_t)
                 torch.cuda.synchronize()
                 t_t = time.perf_counter()
-                for kk in bjx.random.split(bjx.random.key(778), 2):
+                for kk in bjx.random.split(bjx.random.key(778), 5):
                     st_t, _ = alg_t.step(kk, st_t)
                 torch.cuda.synchronize()
-                tuning[(cb, gr, ns_)] = (time.perf_counter() - t_t) / 2 * 1e3
+                tuning[(cb, gr, ns_)] = (time.perf_counter() - t_t) / 5 * 1e3
                 del alg_t, st_t
             except Exception as e:  # a mode that cannot run here is simply not a candidate
                 tuning[(cb, gr, ns_)] = float("inf")

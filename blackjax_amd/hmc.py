@@ -62,8 +62,7 @@ def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:
     return HMCState(position, logp, grad)
 
 
-_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switches
-_PREFETCH_MOMENTUM = __import__("os").environ.get("BJX_HMC_PREFETCH_MOMENTUM", "1") != "0"
+_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switch
 
 
 def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):
@@ -374,8 +373,6 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         if L == 0:
             g_end, logp_end = g0, logp0
 
-        prefetched: dict = {}  # block -> event: its momentum draw + first kick was issued on the side stream
-
         def block_args(b):
             s, e = b * blk, min(N, (b + 1) * blk)
             sl = slice(s, e)
@@ -403,11 +400,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             n, sl, m, eb, boff = block_args(b)
             if fused_first:
                 q, p = q_end[sl], p_work[sl]
-                ev = prefetched.pop(b, None)
-                if ev is None:
-                    launch_first(b, stream)
-                else:
-                    torch.cuda.current_stream(dev).wait_event(ev)
+                launch_first(b, stream)
             elif m.kind == "diag":
                 _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, boff, fold, n, D, m.imm.data_ptr(),
                           m.imm_stride, p0[sl].data_ptr(), ke0[sl].data_ptr())
@@ -522,21 +515,7 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         # HIP stream: one block's callable (bandwidth-bound), the start-up of its launches and the
         # output drain of a dense-metric GEMM then overlap another block's kernels.
         ns = 1 if (graphed or n_blocks <= 1) else min(int(n_streams), n_blocks)
-        if ns <= 1 and fused_first and n_blocks > 1 and _PREFETCH_MOMENTUM:
-            # the NEXT block's momentum draw (VALU-bound: threefry + erf_inv per element) runs on a side
-            # stream under this block's leapfrogs (HBM-bound)
-            main = torch.cuda.current_stream(dev)
-            side = _side_streams(dev, 1)[0]
-            side.wait_stream(main)
-            for b in range(n_blocks):
-                if b + 1 < n_blocks:
-                    with torch.cuda.stream(side):
-                        launch_first(b + 1, _lib.current_stream())
-                        prefetched[b + 1] = side.record_event()
-                for _ in run_block(b):
-                    pass
-            main.wait_stream(side)
-        elif ns <= 1:
+        if ns <= 1:
             for b in range(n_blocks):
                 for _ in run_block(b):
                     pass
