@@ -111,6 +111,10 @@ def test_ghmc_funnel_divergences_and_skipped_chains(dev):
 
 def test_ghmc_validation(dev):
     fn = bjx.targets.DiagGaussian(torch.ones(4, device=dev))
+    # an empty batch is a no-op with the right shapes (the HMC entry points behave the same)
+    e = bjx.ghmc(fn, 0.5, 1.0, 0.5, 0.2).init(torch.zeros(0, 4, device=dev), prng.key(0))
+    e2, info = bjx.ghmc(fn, 0.5, 1.0, 0.5, 0.2).step(prng.key(1), e)
+    assert e2.position.shape == (0, 4) and e2.slice.shape == (0,) and info.is_accepted.shape == (0,)
     with pytest.raises(ValueError):
         bjx.ghmc(fn, 0.5, 1.0, 0.5, 0.2).init(torch.zeros(3, 4, device=dev))  # no rng_key
     st = bjx.ghmc(fn, 0.5, 1.0, 0.5, 0.2).init(torch.zeros(3, 4, device=dev), prng.key(0))
