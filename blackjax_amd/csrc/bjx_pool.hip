@@ -387,6 +387,106 @@ __global__ __launch_bounds__(256) void k_chees_wcol(int64_t N, int64_t D, int tp
   }
 }
 
+// The same pass for rows of 129 ... 1 024 floats with whole rows per WAVE (lane l owns the 16-byte pieces
+// l, l + 64, ...): the non-finite test of a row is one wave ballot, its scalars are wave-uniform
+// (scalar loads), and nothing synchronises inside the row loop -- the four waves of a workgroup only
+// meet at the end, where they add their column sums into LDS one after the other (fixed order).
+// Measured at 65 536 x 1 024 against k_chees_wcol (a row spread over four waves, one barrier per eight
+// rows): see DESIGN.md section 11.
+template <int NI>
+__global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const float* __restrict__ qp,
+                                                    const float* __restrict__ qi, const float* __restrict__ acc,
+                                                    const uint8_t* __restrict__ is_div, float* __restrict__ w_out,
+                                                    double* __restrict__ partial) {
+  constexpr int U = NI >= 4 ? 2 : 4;  // rows in flight per wave
+  __shared__ double sm[3][NI * 256];
+  __shared__ double sm_w;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n_waves = (int)gridDim.x * 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);
+  const int n = (int)N;
+  bool ok[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) ok[k] = ((int64_t)lane + 64 * k) * 4 < D;
+  double a0[NI][4], a1[NI][4], a2[NI][4], aw = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a0[k][e] = a1[k][e] = a2[k][e] = 0.0;
+  for (int r0 = wave; r0 < n; r0 += n_waves * U) {
+    F4 x[U][NI], y[U][NI];
+    float an[U];
+    int dn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * n_waves;
+      const int rc = r < n ? r : n - 1;  // rows past the end shadow the last row and are not accumulated
+      an[u] = acc[rc];
+      dn[u] = is_div[rc];
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          const int64_t at = (int64_t)rc * D + ((int64_t)lane + 64 * k) * 4;
+          x[u][k] = ld4(qp + at);
+          y[u][k] = ld4(qi + at);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * n_waves;
+      bool nf = false;
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) nf |= !(isfinite(x[u][k].x) && isfinite(x[u][k].y) && isfinite(x[u][k].z) && isfinite(x[u][k].w));
+      const bool bad = __any(nf);
+      if (r < n) {  // wave uniform
+        const float wf = (dn[u] || bad) ? 0.0f : an[u];
+        if (lane == 0) w_out[r] = wf;
+        const double wr = (double)wf;
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+          if (ok[k]) {
+            const float xv[4] = {x[u][k].x, x[u][k].y, x[u][k].z, x[u][k].w};
+            const float yv[4] = {y[u][k].x, y[u][k].y, y[u][k].z, y[u][k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xs = isfinite(xv[e]) ? xv[e] : 0.0f;
+              a0[k][e] += wr * (double)xs;
+              const bool fin = !(yv[e] != yv[e]);
+              a1[k][e] += fin ? (double)yv[e] : 0.0;
+              a2[k][e] += fin ? 1.0 : 0.0;
+            }
+          }
+        aw += wr;
+      }
+    }
+  }
+  for (int w = 0; w < 4; ++w) {  // the four waves add their sums in wave order
+    if (wv == w) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = (lane + 64 * k) * 4 + e;
+          if (w == 0) {
+            sm[0][c] = a0[k][e]; sm[1][c] = a1[k][e]; sm[2][c] = a2[k][e];
+          } else {
+            sm[0][c] += a0[k][e]; sm[1][c] += a1[k][e]; sm[2][c] += a2[k][e];
+          }
+        }
+      if (lane == 0) sm_w = (w == 0) ? aw : sm_w + aw;
+    }
+    __syncthreads();
+  }
+  double* out = partial + (int64_t)blockIdx.x * 4 * D;
+  for (int64_t c = threadIdx.x; c < D; c += 256) {
+    out[c] = sm[0][c];
+    out[D + c] = sm[1][c];
+    out[2 * D + c] = sm[2][c];
+    out[3 * D + c] = sm_w;
+  }
+}
+
 // ------------------------------------------------------------------------------ row kernels
 template <int VEC>
 __global__ __launch_bounds__(256) void k_chees_weights(int64_t N, int64_t D, const float* __restrict__ qp,
@@ -701,14 +801,29 @@ int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const f
     return bjx_chees_colstats(stream, N, D, q_prop, w, q_init, workspace, stats);
   }
   double* partial = (double*)workspace;
+  int64_t nslab = g.nslab;
+  static const bool by_rows = !(getenv("BJX_CHEES_WCOL") && atoi(getenv("BJX_CHEES_WCOL")) != 0);
+  if (vec4 && D > 128 && D <= 1024 && N < ((int64_t)1 << 31) && by_rows) {  // whole rows per wave
+    const int u = D > 512 ? 2 : 4;
+    int64_t wgs = (N + 4 * u - 1) / (4 * u);
+    nslab = wgs < 512 ? wgs : 512;  // <= the slab count bjx_pool_workspace_bytes sizes the partials for
+#define BJX_WROW(NI_)                                                                                   \
+  hipLaunchKernelGGL(k_chees_wrow<NI_>, dim3((unsigned)nslab), dim3(256), 0, stream, N, D, q_prop, q_init, \
+                     acc, is_divergent, w, partial)
+    if (D <= 256) BJX_WROW(1);
+    else if (D <= 512) BJX_WROW(2);
+    else BJX_WROW(4);
+#undef BJX_WROW
+  } else {
 #define BJX_WCOL(V)                                                                                         \
   hipLaunchKernelGGL((k_chees_wcol<V, kColU>), dim3((unsigned)g.nslab), dim3(256), 0, stream, N, D, g.tpr_log2, \
                      q_prop, q_init, acc, is_divergent, w, partial)
-  if (vec4) BJX_WCOL(4);
-  else BJX_WCOL(1);
+    if (vec4) BJX_WCOL(4);
+    else BJX_WCOL(1);
 #undef BJX_WCOL
+  }
   const int64_t KD = 4 * D;
-  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 63) / 64)), dim3(1024), 0, stream, g.nslab, KD,
+  hipLaunchKernelGGL(k_colfinal, dim3((unsigned)((KD + 63) / 64)), dim3(1024), 0, stream, nslab, KD,
                      partial, stats);
   return bjx_check_launch("bjx_chees_weights_colstats");
 }

@@ -82,8 +82,9 @@ def test_pool_kernels_vs_oracle(dev, N, D, whiten, poison):
 @pytest.mark.parametrize("N,D", [(37, 6), (1000, 64), (77, 20), (2100, 256), (4200, 512), (9000, 1024), (33, 1028)])
 def test_fused_weights_colstats_equals_the_two_launches(dev, N, D):
     """bjx_chees_weights_colstats (one read of q') against bjx_chees_weights + bjx_chees_colstats:
-    weights and all 4*D fp64 column sums bit for bit, over every row-to-thread geometry (a row inside
-    one wave, across 2 and 4 waves, and the D > 1024 fall-back)."""
+    weights bit for bit and the 4*D fp64 column sums bit for bit (column-owner kernels) or to 1e-13
+    (rows-per-wave kernel, 128 < D <= 1024: a different fixed summation order), over every geometry (a
+    row inside one wave, whole rows per wave, and the D > 1024 fall-back)."""
     props, moms, inits, acc, div = _inputs(N, D, seed=3 * N + D)
     rows = np.random.default_rng(N).choice(N, size=max(N // 50, 1), replace=False)
     props[rows, (rows * 7) % D] = np.inf
@@ -100,7 +101,10 @@ def test_fused_weights_colstats_equals_the_two_launches(dev, N, D):
               w2.data_ptr(), ws.scratch.data_ptr(), s2.data_ptr())
     assert torch.equal(w1, w2) and float(w1.min()) >= 0.0
     assert (w1[torch.as_tensor(rows, device=dev)] == 0).all()
-    assert torch.equal(s1, s2)
+    if 128 < D <= 1024 and D % 4 == 0:  # whole rows per wave: another (fixed) summation order of the fp64 sums
+        torch.testing.assert_close(s2, s1, rtol=1e-13, atol=1e-11)
+    else:
+        assert torch.equal(s1, s2)
 
 
 def test_pool_empty_batch(dev):
