@@ -347,9 +347,9 @@ def auto_row_block(n_rows: int, dim: int) -> int:
     """Rows per group of the free-running schedule.  Default: ALL rows in one group.  Ticking the
     ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; set
     ``BJX_NUTS_ROW_BLOCK=n`` or pass ``row_block=n``) was measured SLOWER at the C3 shape (32 768 x
-    256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s): the
-    tick kernels are bound by instruction issue and dependent latency at 3 waves per SIMD, not by HBM
-    bandwidth, so cache residency buys nothing and the smaller launches cost."""
+    256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s; on the
+    final kernels 184-191 vs 164 / 131): a tick moves more than the cache holds between two uses of
+    a row whatever the grouping, and the smaller launches cost."""
     import os
 
     v = os.environ.get("BJX_NUTS_ROW_BLOCK", "")
