@@ -59,17 +59,19 @@ def init(position: torch.Tensor, logdensity_fn: Callable, rng_key, *, chain_offs
 
 def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, device):
     """ghmc.py:67-86, legacy branch: the per-dimension inverse scale, squared.  -> (imm tensor,
-    row stride 0 | D)."""
+    row stride 0 | D).  Accepted: a scalar, ``(D,)``, or one scale vector per chain ``(N, D)`` (what
+    the vmapped reference kernel sees as 1-D per chain).  The reference reads a single chain's 2-D
+    argument as a dense inverse mass matrix (blackjax#950): a ``(D, D)`` tensor that is not ``(N, D)``
+    is therefore refused rather than guessed at."""
     x = momentum_inverse_scale
-    if isinstance(x, (metrics.Metric,)) or callable(x):
+    if isinstance(x, metrics.Metric) or callable(x):
         raise NotImplementedError("ghmc: only the per-dimension inverse-scale form of the momentum metric is built")
     t = torch.as_tensor(x, dtype=torch.float32, device=device)
     if t.ndim == 0:
         t = t.expand(dim)
-    if t.ndim == 2 and t.shape == (dim, dim) and not isinstance(x, metrics.PerChainDiagTensor):
-        if n_chains != dim:
-            raise NotImplementedError("ghmc: a dense (d, d) momentum metric is outside the built scope "
-                                      "(per-dimension inverse scales: scalar, (D,) or per-chain (N, D))")
+    if t.shape == (dim, dim) and n_chains != dim:
+        raise NotImplementedError("ghmc: a dense (d, d) momentum metric is outside the built scope "
+                                  "(per-dimension inverse scales: scalar, (D,) or per-chain (N, D))")
     if t.shape not in ((dim,), (n_chains, dim)):
         raise ValueError(f"momentum_inverse_scale must be a scalar, ({dim},) or ({n_chains}, {dim}); got {tuple(t.shape)}")
     t = t.contiguous()
