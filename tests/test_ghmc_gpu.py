@@ -213,3 +213,26 @@ def test_meads_regression_posterior_with_an_autograd_callable(dev):
     xs = torch.stack(draws)
     assert abs(float(xs[..., 0].mean()) - 3.0) < 0.1
     assert abs(float(torch.exp(xs[..., 1]).mean()) - 1.0) < 0.1
+
+
+def test_ghmc_is_shard_invariant(dev):
+    """Chains are keyed by their GLOBAL index: two shards run with ``chain_offset`` reproduce the rows
+    of the unsharded run bit for bit (no exchange step in the sampling path)."""
+    N, D = 96, 32
+    fn = bjx.targets.DiagGaussian(torch.linspace(0.5, 2.0, D, device=dev))
+    q0 = dev_t(prng.normal(prng.key(3), (N, D)), dev)
+    eps = dev_t(np.random.default_rng(0).uniform(0.3, 0.8, N).astype(f32), dev)
+
+    def run(lo, hi):
+        alg = bjx.ghmc(fn, eps[lo:hi].contiguous(), 1.0, 0.4, 0.2, chain_offset=lo)
+        st = alg.init(q0[lo:hi].contiguous(), prng.key(5))
+        for k in prng.split(prng.key(6), 4):
+            st, info = alg.step(k, st)
+        return st, info
+
+    full, info_full = run(0, N)
+    a, info_a = run(0, 40)
+    b, info_b = run(40, N)
+    for f, x, y in zip(full, a, b):
+        assert same_bits(f, torch.cat([x, y]))
+    assert torch.equal(info_full.is_accepted, torch.cat([info_a.is_accepted, info_b.is_accepted]))
