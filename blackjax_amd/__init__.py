@@ -53,7 +53,8 @@ dynamic_hmc.chain_keys = _dynamic_hmc.chain_keys
 dynamic_hmc.halton_sequence = _dynamic_hmc.halton_sequence
 dynamic_hmc.halton_steps_fn = _dynamic_hmc.halton_steps_fn
 dhmc = dynamic_hmc  # blackjax/__init__.py alias used by the ChEES examples
+hmc_family = [hmc, nuts, mhmc]  # blackjax/__init__.py:188
 # Generalized HMC (blackjax/mcmc/ghmc.py), the sampler the MEADS warm-up tunes
 ghmc = GenerateSamplingAPI(_ghmc.as_top_level_api, _ghmc.init, _ghmc.build_kernel)
 
-__all__ = ["hmc", "nuts", "mhmc", "multinomial_hmc", "dynamic_hmc", "dhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]
+__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]
