@@ -53,8 +53,14 @@ dynamic_hmc.chain_keys = _dynamic_hmc.chain_keys
 dynamic_hmc.halton_sequence = _dynamic_hmc.halton_sequence
 dynamic_hmc.halton_steps_fn = _dynamic_hmc.halton_steps_fn
 dhmc = dynamic_hmc  # blackjax/__init__.py alias used by the ChEES examples
+# blackjax/__init__.py:155-163: dynamic trajectory lengths with the multinomial (whole-trajectory) proposal
+dmhmc = GenerateSamplingAPI(
+    _functools.partial(_dynamic_hmc.as_top_level_api, build_proposal=_hmc.multinomial_hmc_proposal),
+    _dynamic_hmc.init,
+    _functools.partial(_dynamic_hmc.build_kernel, build_proposal=_hmc.multinomial_hmc_proposal),
+)
 hmc_family = [hmc, nuts, mhmc]  # blackjax/__init__.py:188
 # Generalized HMC (blackjax/mcmc/ghmc.py), the sampler the MEADS warm-up tunes
 ghmc = GenerateSamplingAPI(_ghmc.as_top_level_api, _ghmc.init, _ghmc.build_kernel)
 
-__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]
+__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "dmhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable"]

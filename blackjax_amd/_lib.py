@@ -48,6 +48,12 @@ SIGNATURES = {
                            _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_mhmc_finish": [c_void_p, c_int64, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p,
                         _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
+    "bjx_mhmc_step_diag_masked": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                  c_int, c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p,
+                                  _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                  c_void_p],
+    "bjx_mhmc_finish_masked": [c_void_p, c_int64, c_int64, c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p,
+                               _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_dense_matmul": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
     "bjx_hmc_momentum_dense": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],

@@ -482,16 +482,25 @@ k_hmc_finish_diag_short(Key key, int64_t off, int64_t fold, int64_t N, int64_t D
 // Pass 2: reservoir update on accept; if do_next, opening half kick + drift of step i+1 in place.
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64_t step, int do_next,
+k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64_t step, int do_next_arg,
                  float eps_s, const float* __restrict__ eps_pc, const float* __restrict__ imm,
                  int64_t imm_stride, float thr, const float* __restrict__ logp0,
                  const float* __restrict__ ke0, float* q, float* p, const float* __restrict__ g,
                  const float* __restrict__ logp_new, float* __restrict__ W, float* __restrict__ S,
                  uint8_t* __restrict__ any_div, uint8_t* __restrict__ ever, float* __restrict__ Rq,
                  float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
-                 float* __restrict__ Renergy) {
+                 float* __restrict__ Renergy, const int32_t* __restrict__ n_steps) {
   const int lane = threadIdx.x & 63;
+  const int do_next_all = do_next_arg;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    // per-chain trajectory lengths (blackjax.dmhmc): a chain whose trajectory is complete is left
+    // alone, and the last step of a chain does not open another leapfrog
+    int do_next = do_next_all;
+    if (n_steps) {
+      const int ns = n_steps[r];
+      if (step >= ns) continue;
+      do_next = do_next_all && step + 1 < ns;
+    }
     const float eps = eps_pc ? eps_pc[r] : eps_s;
     const float h = eps * 0.5f;
     const int64_t base = r * D;
@@ -606,10 +615,11 @@ k_mhmc_finish(int64_t N, int64_t D, float n_steps, const float* __restrict__ q0,
               const float* __restrict__ logp0, const float* __restrict__ ke0,
               const uint8_t* __restrict__ ever, const float* __restrict__ S, float* __restrict__ Rq,
               float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
-              float* __restrict__ Renergy, float* __restrict__ acc_rate) {
+              float* __restrict__ Renergy, float* __restrict__ acc_rate,
+              const int32_t* __restrict__ n_steps_pc) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
-    if (lane == 0) acc_rate[r] = exp_cr(S[r]) / n_steps;
+    if (lane == 0) acc_rate[r] = exp_cr(S[r]) / (n_steps_pc ? (float)n_steps_pc[r] : n_steps);
     if (ever[r]) continue;
     const int64_t base = r * D;
     for (int64_t j = lane; j < D; j += 64) {
@@ -868,14 +878,14 @@ int bjx_hmc_finish_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                                   acceptance_rate_out, is_accepted_out, is_divergent_out, energy_out);
 }
 
-int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
-                       int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
-                       const float* eps_per_chain, const float* imm, int64_t imm_stride,
-                       float divergence_threshold, const float* logp0, const float* ke0, float* q,
-                       float* p, const float* g, const float* logp_new, float* weight,
-                       float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
-                       float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
-                       float* prop_energy) {
+static int mhmc_step_diag(const char* what, void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                          int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                          const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                          float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                          float* p, const float* g, const float* logp_new, float* weight,
+                          float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                          float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                          float* prop_energy, const int32_t* n_steps) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
                     weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q && prop_p &&
@@ -889,18 +899,47 @@ int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain
   hipLaunchKernelGGL(k_mhmc_step_diag<V>, grid, block, 0, s, key, chain_offset, step_fold, N, D, \
                      step, do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold,  \
                      logp0, ke0, q, p, g, logp_new, weight, sum_log_p_accept, any_divergent,    \
-                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy)
+                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy, n_steps)
   if (bjx_vec4_ok(D, imm, q, p, g, prop_q, prop_p, prop_g)) BJX_MH(4);
   else BJX_MH(1);
 #undef BJX_MH
-  return bjx_check_launch("bjx_mhmc_step_diag");
+  return bjx_check_launch(what);
 }
 
-int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_steps,
-                    const float* q0, const float* p0, const float* g0, const float* logp0,
-                    const float* ke0, const uint8_t* ever_accepted, const float* sum_log_p_accept,
-                    float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
-                    float* acceptance_rate_out) {
+int bjx_mhmc_step_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                       int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                       const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                       float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                       float* p, const float* g, const float* logp_new, float* weight,
+                       float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                       float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                       float* prop_energy) {
+  return mhmc_step_diag("bjx_mhmc_step_diag", stream, key0, key1, chain_offset, step_fold, N, D, step, do_next,
+                        eps, eps_per_chain, imm, imm_stride, divergence_threshold, logp0, ke0, q, p, g,
+                        logp_new, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q, prop_p,
+                        prop_g, prop_logp, prop_energy, nullptr);
+}
+
+int bjx_mhmc_step_diag_masked(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                              const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                              float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                              float* p, const float* g, const float* logp_new, float* weight,
+                              float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                              float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                              float* prop_energy, const int32_t* n_steps) {
+  BJX_CHECK_ARG(N == 0 || n_steps, "bjx_mhmc_step_diag_masked: n_steps is NULL");
+  return mhmc_step_diag("bjx_mhmc_step_diag_masked", stream, key0, key1, chain_offset, step_fold, N, D, step,
+                        do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold, logp0, ke0, q, p,
+                        g, logp_new, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q, prop_p,
+                        prop_g, prop_logp, prop_energy, n_steps);
+}
+
+static int mhmc_finish(const char* what, void* stream, int64_t N, int64_t D, int64_t num_integration_steps,
+                       const int32_t* n_steps, const float* q0, const float* p0, const float* g0,
+                       const float* logp0, const float* ke0, const uint8_t* ever_accepted,
+                       const float* sum_log_p_accept, float* prop_q, float* prop_p, float* prop_g,
+                       float* prop_logp, float* prop_energy, float* acceptance_rate_out) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && q0 && p0 && g0 && logp0 && ke0 && ever_accepted &&
                     sum_log_p_accept && prop_q && prop_p && prop_g && prop_logp && prop_energy &&
@@ -909,8 +948,28 @@ int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_
   hipLaunchKernelGGL(k_mhmc_finish, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, N, D, (float)num_integration_steps, q0, p0, g0, logp0, ke0,
                      ever_accepted, sum_log_p_accept, prop_q, prop_p, prop_g, prop_logp, prop_energy,
+                     acceptance_rate_out, n_steps);
+  return bjx_check_launch(what);
+}
+
+int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_steps,
+                    const float* q0, const float* p0, const float* g0, const float* logp0,
+                    const float* ke0, const uint8_t* ever_accepted, const float* sum_log_p_accept,
+                    float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
+                    float* acceptance_rate_out) {
+  return mhmc_finish("bjx_mhmc_finish", stream, N, D, num_integration_steps, nullptr, q0, p0, g0, logp0, ke0,
+                     ever_accepted, sum_log_p_accept, prop_q, prop_p, prop_g, prop_logp, prop_energy,
                      acceptance_rate_out);
-  return bjx_check_launch("bjx_mhmc_finish");
+}
+
+int bjx_mhmc_finish_masked(void* stream, int64_t N, int64_t D, const int32_t* n_steps, const float* q0,
+                           const float* p0, const float* g0, const float* logp0, const float* ke0,
+                           const uint8_t* ever_accepted, const float* sum_log_p_accept, float* prop_q,
+                           float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
+                           float* acceptance_rate_out) {
+  BJX_CHECK_ARG(N == 0 || n_steps, "bjx_mhmc_finish_masked: n_steps is NULL");
+  return mhmc_finish("bjx_mhmc_finish_masked", stream, N, D, 1, n_steps, q0, p0, g0, logp0, ke0, ever_accepted,
+                     sum_log_p_accept, prop_q, prop_p, prop_g, prop_logp, prop_energy, acceptance_rate_out);
 }
 
 }  // extern "C"

@@ -117,9 +117,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     """blackjax/mcmc/dynamic_hmc.py:65-126.  ``integration_steps_fn(random_generator_arg, *params)``
     returns an ``(N,)`` int32 device tensor of trajectory lengths (>= 1)."""
     integrators.check_supported(integrator)
-    if build_proposal is not None:
-        raise NotImplementedError("dynamic_hmc is implemented for the default hmc_proposal only")
+    from .hmc import hmc_proposal, multinomial_hmc_proposal
+
+    if build_proposal not in (None, hmc_proposal, multinomial_hmc_proposal):
+        raise NotImplementedError("dynamic_hmc: build_proposal must be hmc_proposal or multinomial_hmc_proposal")
     thr = float(divergence_threshold)
+    if build_proposal is multinomial_hmc_proposal:
+        if integrator is not integrators.velocity_verlet:
+            raise NotImplementedError("dmhmc is implemented for velocity_verlet")
+        return _build_multinomial_kernel(thr, next_random_arg_fn, integration_steps_fn)
 
     def kernel(rng_key, state: DynamicHMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, integration_steps_params: tuple = (), *, chain_offset: int = 0):
@@ -195,6 +201,64 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                        n_steps)
         new_arg = next_random_arg_fn(state.random_generator_arg)
         return DynamicHMCState(q_new, logp_new, g_new, new_arg), info
+
+    return kernel
+
+
+def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integration_steps_fn: Callable):
+    """blackjax.dmhmc (blackjax/__init__.py:155-163): every chain draws its own trajectory length and one
+    state of ITS trajectory proportionally to exp(-H) (hmc.py:181-248 over dynamic_hmc.py:85-118).  Diagonal
+    metric; the per-chain lengths mask the fused step kernel of ``blackjax_amd.mhmc``."""
+
+    def kernel(rng_key, state: DynamicHMCState, logdensity_fn: Callable, step_size,
+               inverse_mass_matrix, integration_steps_params: tuple = (), *, chain_offset: int = 0):
+        q0 = check_batch(state.position, "state.position")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        N, D = q0.shape
+        dev = q0.device
+        k0, k1, fold = key_spec(rng_key)
+        vg = value_and_grad(logdensity_fn)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+        if metric.kind != "diag":
+            raise NotImplementedError("dmhmc is implemented for diagonal metrics")
+        eps, eps_pc = step_size_args(step_size, N, dev)
+        stream = _lib.current_stream()
+        off = int(chain_offset)
+        imm_p, imm_s = metric.imm.data_ptr(), metric.imm_stride
+        n_steps = integration_steps_fn(state.random_generator_arg, *integration_steps_params)
+        n_steps = n_steps.to(device=dev, dtype=torch.int32).contiguous()
+        lo, hi = int(n_steps.min()), int(n_steps.max())  # one host sync per transition
+        if lo < 1:
+            raise ValueError("integration_steps_fn must return at least 1 step for every chain")
+        p0 = torch.empty_like(q0)
+        ke0 = torch.empty_like(logp0)
+        _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, off, fold, N, D, imm_p, imm_s, p0.data_ptr(),
+                  ke0.data_ptr())
+        weight = torch.zeros_like(logp0)
+        slpa = torch.full_like(logp0, float("-inf"))
+        any_div = torch.zeros(N, dtype=torch.bool, device=dev)
+        ever = torch.zeros(N, dtype=torch.bool, device=dev)
+        pq, pp, pg = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
+        plogp, penergy, acc_rate = torch.empty_like(logp0), torch.empty_like(logp0), torch.empty_like(logp0)
+        q, p = torch.empty_like(q0), torch.empty_like(q0)
+        _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s, q0.data_ptr(),
+                  p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
+        for i in range(hi):
+            logp, g = eval_logdensity(vg, q)  # finished chains keep their q: same (logp, g) again, unused
+            _lib.call("bjx_mhmc_step_diag_masked", stream, k0, k1, off, fold, N, D, i, 1 if i + 1 < hi else 0,
+                      eps, _lib.ptr(eps_pc), imm_p, imm_s, thr, logp0.data_ptr(), ke0.data_ptr(), q.data_ptr(),
+                      p.data_ptr(), g.data_ptr(), logp.data_ptr(), weight.data_ptr(), slpa.data_ptr(),
+                      any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
+                      plogp.data_ptr(), penergy.data_ptr(), n_steps.data_ptr())
+        _lib.call("bjx_mhmc_finish_masked", stream, N, D, n_steps.data_ptr(), q0.data_ptr(), p0.data_ptr(),
+                  g0.data_ptr(), logp0.data_ptr(), ke0.data_ptr(), ever.data_ptr(), slpa.data_ptr(),
+                  pq.data_ptr(), pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr(),
+                  acc_rate.data_ptr())
+        info = HMCInfo(p0, acc_rate, torch.ones(N, dtype=torch.bool, device=dev), any_div, penergy,
+                       IntegratorState(pq, pp, plogp, pg), n_steps)
+        new_arg = next_random_arg_fn(state.random_generator_arg)
+        return DynamicHMCState(pq, plogp, pg, new_arg), info
 
     return kernel
 

@@ -180,6 +180,25 @@ int bjx_mhmc_finish(void* stream, int64_t N, int64_t D, int64_t num_integration_
                     float* prop_q, float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
                     float* acceptance_rate_out);
 
+/* The same two entry points with one trajectory length PER CHAIN (blackjax.dmhmc =
+ * dynamic_hmc.build_kernel(build_proposal=multinomial_hmc_proposal), blackjax/__init__.py:155-163;
+ * dynamic_hmc.py:85-118 under vmap): chain i takes part in step `step` only while step < n_steps[i]
+ * (device (N,) int32), its last step opens no further leapfrog, and its acceptance rate is
+ * exp(sum_log_p_accept[i]) / n_steps[i]. */
+int bjx_mhmc_step_diag_masked(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                              int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                              const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                              float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                              float* p, const float* g, const float* logp_new, float* weight,
+                              float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                              float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                              float* prop_energy, const int32_t* n_steps);
+int bjx_mhmc_finish_masked(void* stream, int64_t N, int64_t D, const int32_t* n_steps, const float* q0,
+                           const float* p0, const float* g0, const float* logp0, const float* ke0,
+                           const uint8_t* ever_accepted, const float* sum_log_p_accept, float* prop_q,
+                           float* prop_p, float* prop_g, float* prop_logp, float* prop_energy,
+                           float* acceptance_rate_out);
+
 /* ---- dense Gaussian-Euclidean metric (one (D, D) inverse mass matrix shared by all chains) ----
  * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32, exact fp32 fma chains: "precision=highest",
  * blackjax/util.py:23-61).  All matrices row-major.

@@ -279,7 +279,7 @@ class DynamicHMCState(NamedTuple):  # blackjax/mcmc/dynamic_hmc.py:39-52
 
 def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size,
                        inverse_mass_matrix, divergence_threshold: float = 1000.0,
-                       chain_offset: int = 0, steps_bounds=(1, 10), metric=None):
+                       chain_offset: int = 0, steps_bounds=(1, 10), metric=None, multinomial=False):
     """blackjax/mcmc/dynamic_hmc.py:65-126 with the default callables
     ``integration_steps_fn = lambda key: randint(key, (), 1, 10)`` and
     ``next_random_arg_fn = lambda key: split(key)[1]``: every chain draws its own trajectory
@@ -300,8 +300,10 @@ def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size
             met_i = metric
             if metric.is_dense and metric.inverse_mass_matrix.ndim == 3:
                 met_i = Metric(metric.inverse_mass_matrix[i], metric.mass_matrix_sqrt[i], True, metric.dense_accum)
-        outs.append(kernel(None, st_i, logdensity_fn, eps[i], imm_i, int(n_steps[i]),
-                           divergence_threshold, chain_keys_override=keys[i:i + 1], metric=met_i))
+        # multinomial=True: blackjax.dmhmc (build_proposal=multinomial_hmc_proposal, __init__.py:155-163)
+        outs.append((mhmc_kernel if multinomial else kernel)(
+            None, st_i, logdensity_fn, eps[i], imm_i, int(n_steps[i]), divergence_threshold,
+            chain_keys_override=keys[i:i + 1], metric=met_i))
     cat = lambda f: np.concatenate([f(o) for o in outs], 0)
     new = DynamicHMCState(cat(lambda o: o[0].position), cat(lambda o: o[0].logdensity),
                           cat(lambda o: o[0].logdensity_grad),
