@@ -144,3 +144,26 @@ def test_meads_single_fold_never_freezes():
     for t in range(1, 5):
         assert not np.allclose(hist[t][0].position, hist[t - 1][0].position)
     assert np.ndim(params["step_size"]) == 0
+
+
+def test_dynamic_multinomial_hmc_oracle_structure():
+    """blackjax.dmhmc on the oracle (tests/mcmc/test_multinomial_hmc.py:151-199): per-chain trajectory
+    lengths from randint(key, 1, 10), ``is_accepted`` always True, the acceptance-rate diagnostic is
+    exp(sum_log_p_accept) / L of the chain's own L, and the next random_generator_arg is split(key)[1]."""
+    from oracle import hmc as ohmc
+
+    N, D = 12, 4
+    fn = lambda q: ((-0.5 * (q.astype(f64) ** 2).sum(1)).astype(f32), (-q).astype(f32))  # noqa: E731
+    st = ohmc.init(prng.normal(prng.key(1), (N, D)), fn)
+    rga = prng.split(prng.key(7), N)
+    st = ohmc.DynamicHMCState(st.position, st.logdensity, st.logdensity_grad, rga)
+    new, info = ohmc.dynamic_hmc_kernel(prng.key(3), st, fn, f32(0.2), np.ones(D, f32), multinomial=True)
+    assert info.is_accepted.all() and not info.is_divergent.any()
+    assert np.array_equal(info.num_integration_steps, prng.randint(rga, 1, 10))
+    assert len(set(info.num_integration_steps.tolist())) > 2
+    assert np.all(info.acceptance_rate > 0.5) and np.all(info.acceptance_rate <= 1.0)
+    assert np.array_equal(new.random_generator_arg, prng.split(rga, 2)[:, 1])
+    # the endpoint proposal on the same keys takes the same trajectory lengths but (generally) another state
+    new_e, info_e = ohmc.dynamic_hmc_kernel(prng.key(3), st, fn, f32(0.2), np.ones(D, f32))
+    assert np.array_equal(info_e.num_integration_steps, info.num_integration_steps)
+    assert not np.array_equal(new_e.position, new.position)
