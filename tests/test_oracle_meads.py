@@ -161,7 +161,7 @@ def test_dynamic_multinomial_hmc_oracle_structure():
     assert info.is_accepted.all() and not info.is_divergent.any()
     assert np.array_equal(info.num_integration_steps, prng.randint(rga, 1, 10))
     assert len(set(info.num_integration_steps.tolist())) > 2
-    assert np.all(info.acceptance_rate > 0.5) and np.all(info.acceptance_rate <= 1.0)
+    assert np.all(info.acceptance_rate > 0.5) and np.all(info.acceptance_rate <= 1.0 + 1e-6)  # fp32 rounding of exp(S) / L
     assert np.array_equal(new.random_generator_arg, prng.split(rga, 2)[:, 1])
     # the endpoint proposal on the same keys takes the same trajectory lengths but (generally) another state
     new_e, info_e = ohmc.dynamic_hmc_kernel(prng.key(3), st, fn, f32(0.2), np.ones(D, f32))
