@@ -1,0 +1,56 @@
+"""The reference's protocol checks (tests/test_api_protocols.py:148-240) for the samplers this engine
+exposes: the factory returns a SamplingAlgorithm, ``init``'s first parameter is ``position``, ``step``'s
+first two are ``rng_key, state``; the GPU half does the init -> step round trip with the reference's
+calling conventions (``init(position)`` or, for dhmc / dmhmc / ghmc, ``init(position, rng_key)``)."""
+import inspect
+
+import pytest
+import torch
+
+import blackjax_amd as bjx
+
+_NEEDS_RNG_KEY = {"ghmc", "dhmc", "dmhmc"}
+_ALGORITHMS = ["hmc", "nuts", "mhmc", "dhmc", "dmhmc", "ghmc"]
+
+
+def _make(name, fn, inv_mass):
+    if name in ("hmc", "mhmc"):
+        return getattr(bjx, name)(fn, step_size=0.1, inverse_mass_matrix=inv_mass, num_integration_steps=10)
+    if name == "nuts":
+        return bjx.nuts(fn, step_size=0.1, inverse_mass_matrix=inv_mass)
+    if name in ("dhmc", "dmhmc"):
+        return getattr(bjx, name)(fn, step_size=0.1, inverse_mass_matrix=inv_mass)
+    return bjx.ghmc(fn, step_size=0.1, momentum_inverse_scale=inv_mass, alpha=0.5, delta=0.5)
+
+
+def _std_normal(q):
+    return -0.5 * (q * q).sum(-1)
+
+
+@pytest.mark.parametrize("name", _ALGORITHMS)
+def test_factory_and_signatures(name):
+    alg = _make(name, _std_normal, torch.ones(3))
+    assert isinstance(alg, bjx.SamplingAlgorithm)
+    init, step = alg  # unpacks like the reference's two-field NamedTuple
+    assert init is alg.init and step is alg.step
+    assert list(inspect.signature(alg.init).parameters)[0] == "position"
+    assert list(inspect.signature(alg.step).parameters)[:2] == ["rng_key", "state"]
+
+
+def test_aliases_and_families():
+    assert bjx.multinomial_hmc is bjx.mhmc and bjx.dhmc is bjx.dynamic_hmc  # blackjax/__init__.py:152, 117
+    assert bjx.hmc_family == [bjx.hmc, bjx.nuts, bjx.mhmc]
+    for api in (bjx.hmc, bjx.nuts, bjx.mhmc, bjx.dhmc, bjx.dmhmc, bjx.ghmc):
+        assert callable(api.init) and callable(api.build_kernel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _ALGORITHMS)
+def test_init_step_roundtrip(dev, name):
+    alg = _make(name, _std_normal, torch.ones(3, device=dev))
+    init_key, step_key = bjx.random.split(bjx.random.key(0), 2)
+    position = torch.full((5, 3), 0.5, device=dev)
+    state = alg.init(position, init_key) if name in _NEEDS_RNG_KEY else alg.init(position)
+    new_state, info = alg.step(step_key, state)
+    assert new_state.position.shape == (5, 3) and bool(torch.isfinite(new_state.logdensity).all())
+    assert info.acceptance_rate.shape == (5,)
