@@ -42,12 +42,17 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
             return _autograd(q)
         if mode["kind"] == "pair":
             return logdensity_fn(q)
-        out = logdensity_fn(q)
-        if isinstance(out, (tuple, list)) and len(out) == 2:
-            mode["kind"] = "pair"
-            return out
-        mode["kind"] = "autograd"
-        return _autograd(q)
+        # first call: ONE evaluation decides which kind of callable this is (it is made under autograd, so
+        # a callable that returns only logp needs no second pass)
+        qg = q.detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = logdensity_fn(qg)
+            if isinstance(out, (tuple, list)) and len(out) == 2:
+                mode["kind"] = "pair"
+                return out[0].detach(), out[1].detach()
+            mode["kind"] = "autograd"
+            (g,) = torch.autograd.grad(out.sum(), qg)
+        return out.detach(), g
 
     vg._bjx_value_and_grad = True
     try:

@@ -54,3 +54,35 @@ def test_init_step_roundtrip(dev, name):
     new_state, info = alg.step(step_key, state)
     assert new_state.position.shape == (5, 3) and bool(torch.isfinite(new_state.logdensity).all())
     assert info.acceptance_rate.shape == (5,)
+
+
+@pytest.mark.gpu
+def test_logdensity_evaluations_per_transition(dev):
+    """The analogue of the reference's tests/test_compilation.py (how often the log-density is traced):
+    how often the user's callable is EVALUATED -- once at init, then exactly once per leapfrog of a
+    transition (per chain block), with no hidden extra calls (an undeclared callable is never recorded
+    into a HIP graph, so there are no warm-up evaluations either)."""
+    calls = {"n": 0}
+
+    def fn(q):
+        calls["n"] += 1
+        return -0.5 * (q * q).sum(-1)
+
+    q0 = torch.randn(64, 6, device=dev)
+    ones = torch.ones(6, device=dev)
+    for make, per_step in (
+        (lambda: bjx.hmc(fn, 0.1, ones, 7), 7),
+        (lambda: bjx.hmc(fn, 0.1, ones, 7, chain_block=16), 7 * 4),
+        (lambda: bjx.mhmc(fn, 0.1, ones, 5), 5),
+        (lambda: bjx.ghmc(fn, 0.1, ones, 0.5, 0.2), 1),
+    ):
+        alg = make()
+        calls["n"] = 0
+        try:
+            state = alg.init(q0)
+        except ValueError:  # ghmc draws its momentum and slice at init: it needs a key (raised before any evaluation)
+            state = alg.init(q0, bjx.random.key(1))
+        assert calls["n"] == 1
+        for k in bjx.random.split(bjx.random.key(2), 3):
+            state, _ = alg.step(k, state)
+        assert calls["n"] == 1 + 3 * per_step, (per_step, calls["n"])
