@@ -167,3 +167,12 @@ def test_dynamic_multinomial_hmc_oracle_structure():
     new_e, info_e = ohmc.dynamic_hmc_kernel(prng.key(3), st, fn, f32(0.2), np.ones(D, f32))
     assert np.array_equal(info_e.num_integration_steps, info.num_integration_steps)
     assert not np.array_equal(new_e.position, new.position)
+
+
+def test_product_permutation_matches_the_oracle():
+    """blackjax_amd.meads._permutation (host keys from the library's bjx_keys_split) against
+    oracle/prng.py::permutation -- two restatements of jax.random.permutation."""
+    from blackjax_amd.meads import _permutation
+
+    for seed, n in ((5, 1), (5, 2), (6, 128), (7, 1000), (8, 65536)):
+        assert np.array_equal(_permutation(prng.key(seed), n), prng.permutation(prng.key(seed), n)), (seed, n)
