@@ -30,11 +30,21 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
 
     mode = {"kind": None}
 
+    if getattr(logdensity_fn, "_bjx_returns_pair", False):
+        mode["kind"] = "pair"  # declared with blackjax_amd.returns_pair: never probed under autograd
+
+    def _grad(lp, q):
+        # chains are independent, so the vector-Jacobian product with ones IS the per-chain gradient:
+        # grad_outputs = an expanded 0-d one (no fill kernel, no sum kernel, no backward-of-sum kernel)
+        ones = _one(lp).expand_as(lp)
+        (g,) = torch.autograd.grad(lp, q, grad_outputs=ones)
+        return g
+
     def _autograd(q):
         q = q.detach().requires_grad_(True)
         with torch.enable_grad():
             lp = logdensity_fn(q)
-            (g,) = torch.autograd.grad(lp.sum(), q)
+            g = _grad(lp, q)
         return lp.detach(), g
 
     def vg(q):
@@ -42,16 +52,21 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
             return _autograd(q)
         if mode["kind"] == "pair":
             return logdensity_fn(q)
-        # first call: ONE evaluation decides which kind of callable this is (it is made under autograd, so
-        # a callable that returns only logp needs no second pass)
+        # First call of an UNDECLARED callable: one evaluation decides which kind it is.  It is made
+        # under autograd (so a callable that returns only logp needs no second pass); a callable that
+        # returns (logp, grad) itself should be declared with ``blackjax_amd.returns_pair`` -- it is
+        # then never run on a requires_grad leaf (no throw-away autograd graph over the (N, D) batch,
+        # in-place updates of q and host reads inside the callable keep working).
         qg = q.detach().requires_grad_(True)
         with torch.enable_grad():
             out = logdensity_fn(qg)
             if isinstance(out, (tuple, list)) and len(out) == 2:
                 mode["kind"] = "pair"
-                return out[0].detach(), out[1].detach()
+                lp, g = out[0].detach(), out[1].detach()
+                del out
+                return lp, g
             mode["kind"] = "autograd"
-            (g,) = torch.autograd.grad(out.sum(), qg)
+            g = _grad(out, qg)
         return out.detach(), g
 
     vg._bjx_value_and_grad = True
@@ -60,6 +75,51 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
     except TypeError:
         pass
     return vg
+
+
+_ONES: dict = {}
+
+
+def _one(like: torch.Tensor) -> torch.Tensor:
+    key = (like.device, like.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), device=like.device, dtype=like.dtype)
+    return t
+
+
+def returns_pair(logdensity_fn: Callable) -> Callable:
+    """Declare that ``logdensity_fn(q)`` returns ``(logp, grad)`` itself (hand-written gradient, a
+    fused kernel, ``torch.func`` ...).  Undeclared callables are classified by their first call, which
+    runs under autograd on a ``requires_grad`` leaf; a declared one is never probed."""
+    try:
+        logdensity_fn._bjx_returns_pair = True
+        return logdensity_fn
+    except AttributeError:
+        w = _Capturable(logdensity_fn)
+        w._bjx_capturable = False
+        w._bjx_returns_pair = True
+        return w
+
+
+_WARNED_EAGER: set = set()
+
+
+def warn_eager_driver(logdensity_fn, what: str) -> None:
+    """One-time note that an undeclared callable is driven with plain launches (host-bound for
+    short launches); ``blackjax_amd.capturable`` or ``use_graph=True`` selects the recorded driver."""
+    k = id(logdensity_fn)
+    if k in _WARNED_EAGER:
+        return
+    _WARNED_EAGER.add(k)
+    import warnings
+
+    warnings.warn(
+        f"blackjax_amd.{what}: this log-density callable is not declared recordable, so it is driven "
+        "with plain launches (several Python launches per leapfrog, host-bound when launches are short). "
+        "Wrap it in blackjax_amd.capturable(fn) if it has static shapes, does not synchronise with the "
+        "host and reads no Python state that changes between calls, or pass use_graph=True.",
+        RuntimeWarning, stacklevel=3)
 
 
 class _Capturable:

@@ -66,12 +66,20 @@ def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, dev
     x = momentum_inverse_scale
     if isinstance(x, metrics.Metric) or callable(x):
         raise NotImplementedError("ghmc: only the per-dimension inverse-scale form of the momentum metric is built")
+    tagged = False  # per-chain scales must be DECLARED when the array is square (N == D)
+    if isinstance(x, metrics.PerChainDiag):
+        x, tagged = x.imm, True
+    elif isinstance(x, metrics.PerChainDiagTensor):
+        x, tagged = x.as_subclass(torch.Tensor), True
     t = torch.as_tensor(x, dtype=torch.float32, device=device)
     if t.ndim == 0:
         t = t.expand(dim)
-    if t.shape == (dim, dim) and n_chains != dim:
+    if t.shape == (dim, dim) and not tagged:
+        # the reference reads ANY 2-d argument as a dense inverse mass matrix (ghmc.py:67-86): a square
+        # array is never silently taken for per-chain scales, whatever the number of chains
         raise NotImplementedError("ghmc: a dense (d, d) momentum metric is outside the built scope "
-                                  "(per-dimension inverse scales: scalar, (D,) or per-chain (N, D))")
+                                  "(per-dimension inverse scales: scalar, (D,), or per-chain (N, D) -- "
+                                  "wrapped in metrics.PerChainDiag when N == D)")
     if t.shape not in ((dim,), (n_chains, dim)):
         raise ValueError(f"momentum_inverse_scale must be a scalar, ({dim},) or ({n_chains}, {dim}); got {tuple(t.shape)}")
     t = t.contiguous()
@@ -92,7 +100,16 @@ def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
     """blackjax/mcmc/ghmc.py:89-200.  ``noise_fn`` other than the default (no noise on the slice
     translation) is out of scope."""
     if noise_fn is not None:
-        raise NotImplementedError("ghmc: a slice noise_fn is outside the built scope (default: none)")
+        # the reference's default is ``lambda _: 0.0`` (ghmc.py:90): accept any callable that returns an
+        # exact zero for a key, refuse real noise
+        try:
+            import numpy as _np
+
+            zero = float(noise_fn(_np.zeros(2, dtype=_np.uint32))) == 0.0
+        except Exception:
+            zero = False
+        if not zero:
+            raise NotImplementedError("ghmc: a slice noise_fn is outside the built scope (default: no noise)")
     thr = float(divergence_threshold)
 
     def kernel(rng_key, state: GHMCState, logdensity_fn: Callable, step_size, momentum_inverse_scale,

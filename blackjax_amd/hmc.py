@@ -17,7 +17,8 @@ from typing import Callable, NamedTuple
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad
+from ._util import (check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+                    warn_eager_driver)
 from .base import SamplingAlgorithm
 from .random import key_spec
 
@@ -363,6 +364,9 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
             except RuntimeError:  # the callable cannot be recorded (or is broken: the plain path re-raises)
                 not_capturable[fn_id] = logdensity_fn
                 torch.cuda.synchronize(dev)
+        if (use_graph == "auto" and L >= 2 and N > 0 and metric.kind == "diag" and not general
+                and blk * D <= (1 << 21) and not is_capturable(logdensity_fn)):
+            warn_eager_driver(logdensity_fn, "hmc")  # small launches from Python: say so once
         single = n_blocks <= 1 and not graphed
         # end-of-trajectory state (HMCInfo.proposal): per-block work buffers are copied out
         # unless the whole batch is one un-graphed block, in which case they ARE the result

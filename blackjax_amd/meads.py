@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import ghmc as _ghmc
+from . import metrics as _metrics
 from . import random as bjx_random
 from .adaptation import AdaptationResults, return_all_adapt_info
 from .base import AdaptationAlgorithm
@@ -158,7 +159,7 @@ def meads_adaptation(logdensity_fn: Callable, num_chains: int, num_folds: int = 
         alphas, deltas = _damping(maximum_eigenvalue(centred), eps_rolled, t, damping_slowdown)
         skip = (t % K * n, (t % K + 1) * n) if K > 1 else None  # Algorithm 3 line 4
         new_states, info = kernel(rng_key, states, logdensity_fn, eps_rolled.repeat_interleave(n),
-                                  scales_rolled.repeat_interleave(n, dim=0), alphas.repeat_interleave(n),
+                                  _metrics.PerChainDiag(scales_rolled.repeat_interleave(n, dim=0)), alphas.repeat_interleave(n),
                                   deltas.repeat_interleave(n), skip_chains=skip)
         new_ad = MEADSAdaptationState(t + 1, eps_rolled, scales_rolled, alphas, deltas)
         if K > 1 and (t + 1) % K == 0:

@@ -77,7 +77,12 @@ class PerChainDiagTensor(torch.Tensor):
     returns ``parameters["inverse_mass_matrix"]`` as this type, so the reference idiom
     ``nuts(logdensity_fn, **parameters)`` round-trips unambiguously even when ``N == D`` (where a
     plain square 2-d array means a dense matrix, metrics.py:180-218).  It is an ordinary tensor in
-    every other respect (indexing, ``.cpu()``, arithmetic keep working)."""
+    every other respect (indexing, ``.cpu()``, arithmetic keep working) -- but the TAG DOES NOT
+    PROPAGATE: every torch operation on it (slicing, ``torch.diag``, ``mean`` ...) returns a plain
+    ``torch.Tensor``, so a dense ``(D, D)`` matrix a user derives from the warm-up output is read as the
+    dense matrix it is.  Only the object ``window_adaptation`` returned carries the tag."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
 
     @staticmethod
     def tag(imm: torch.Tensor) -> "PerChainDiagTensor":

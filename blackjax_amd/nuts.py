@@ -30,7 +30,8 @@ from typing import Callable, NamedTuple, Optional
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad
+from ._util import (check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+                    warn_eager_driver)
 from .base import SamplingAlgorithm
 from .hmc import HMCState, IntegratorState, init
 from .random import key_spec
@@ -335,6 +336,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                 # `state`, which the graph driver never modifies
                 not_capturable[id(logdensity_fn)] = logdensity_fn
                 torch.cuda.synchronize(state.position.device)
+        elif not is_capturable(logdensity_fn):
+            warn_eager_driver(logdensity_fn, "nuts")
         return kernel_eager(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                             max_num_doublings, chain_offset=chain_offset)
 
@@ -520,6 +523,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
     can_record = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
+    if use_graph == "auto" and not can_record:
+        warn_eager_driver(logdensity_fn, "nuts.run")
 
     def make_run(rows, n_rows):
         r = _lib.NutsAsync()
@@ -579,17 +584,27 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     class _Tail:
         """The tail of a run (at most ``cap`` live rows) on FIXED-CAPACITY buffers: the kernels read
         the live-row count from device memory (``n_rows_dev``, include/bjx_nuts.h), so ONE recorded
-        chunk of ticks per buffer set serves every batch size the tail goes through -- compaction
-        only rewrites the row list, the pending positions and the count -- instead of a plain-launch
-        warm-up and a new recording at every halving of the batch.  Two buffer sets because a
-        compaction cannot work in place."""
+        chunk of ticks per (buffer set, view size) serves every batch size in between -- compaction
+        only rewrites the row list, the pending positions and the count.  Two buffer sets because a
+        compaction cannot work in place.
+
+        Round 3: the launch geometry and the callable's batch follow TIERS of the live-row count
+        (``cap``, then 512, 128, 32 rows: prefix views of the same buffers, one recording each) instead
+        of staying at ``cap`` to the end: with three live chains the callable used to be evaluated on
+        all ``cap`` (up to 2 048) rows every tick.  Rows of a view beyond the live count always hold a
+        VALID position (the buffers start as copies of a current chain state and are only ever
+        overwritten with pending positions), so a log-density that validates its support never sees
+        zeros or garbage there."""
+
+        TIERS = (32, 128, 512)
 
         def __init__(self, cap, n_ticks, reps):
             # a recorded sequence of n_ticks ticks, replayed `reps` times per host sync: recording
             # costs ~40 us per tick, so a short sequence pays for itself within a few hundred ticks
             self.cap, self.n_ticks, self.reps = cap, n_ticks, reps
+            self.tiered = _os.environ.get("BJX_NUTS_TAIL_TIERS", "1") != "0"
             self.rows = [torch.zeros(cap, **i32) for _ in range(2)]
-            self.qf = [torch.zeros((cap, D), **f32) for _ in range(2)]
+            self.qf = [q[:1].expand(cap, D).contiguous() for _ in range(2)]  # valid positions everywhere
             self.n_dev = [torch.zeros(1, **i32) for _ in range(2)]
             self.lp = [torch.zeros(cap, **f32) for _ in range(2)]
             self.g = [torch.zeros((cap, D), **f32) for _ in range(2)]
@@ -598,14 +613,23 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 r = make_run(self.rows[k], cap)
                 r.n_rows_dev = self.n_dev[k].data_ptr()
                 self.run.append(r)
-            self.graph = [None, None]
-            self.chunks = [0, 0]
-            self.cur, self.n_cur = 0, 0
+            self.graph = {}   # (buffer set, view rows) -> CUDAGraph
+            self.cur, self.n_cur, self.view = 0, 0, cap
+
+        def tier(self, n_active):
+            if not self.tiered:
+                return self.cap
+            for v in self.TIERS:
+                if n_active <= v and v < self.cap:
+                    return v
+            return self.cap
 
         def _after_compaction(self, k, n_active):
-            lp, g_ = eval_logdensity(vg, self.qf[k])  # the gathered positions, row for row
-            self.lp[k].copy_(lp)
-            self.g[k].copy_(g_)
+            v = self.view = self.tier(n_active)
+            self.run[k].n_rows = v
+            lp, g_ = eval_logdensity(vg, self.qf[k][:v])  # the gathered positions, row for row
+            self.lp[k][:v].copy_(lp)
+            self.g[k][:v].copy_(g_)
             self.cur, self.n_cur = k, n_active
 
         def enter(self, groups_in, n_active):
@@ -619,6 +643,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             self.n_dev[0].fill_(n_active)
             self._after_compaction(0, n_active)
 
+        def wants_compaction(self, n_active):
+            if self.tiered:
+                return self.tier(n_active) < self.view
+            return n_active <= self.n_cur // 2 and self.n_cur > 64
+
         def compact(self, n_active):
             x, y = self.cur, self.cur ^ 1
             _lib.call("bjx_nuts_async_compact", stream, dref, ctypes.byref(self.run[x]), self.qf[x].data_ptr(),
@@ -627,32 +656,34 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             self._after_compaction(y, n_active)
 
         def _body(self, k):
-            lp, g_ = self.lp[k], self.g[k]
+            v = self.view
+            qf_v = self.qf[k][:v]
+            lp, g_ = self.lp[k][:v], self.g[k][:v]
             rref_k = ctypes.byref(self.run[k])
             for i in range(self.n_ticks):
                 self.run[k].tick = i & 1
-                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, self.qf[k].data_ptr(),
+                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, qf_v.data_ptr(),
                           lp.data_ptr(), g_.data_ptr())
-                lp, g_ = eval_logdensity(vg, self.qf[k])
-            self.lp[k].copy_(lp)
-            self.g[k].copy_(g_)
+                lp, g_ = eval_logdensity(vg, qf_v)
+            self.lp[k][:v].copy_(lp)
+            self.g[k][:v].copy_(g_)
 
         def advance(self):
             nonlocal can_record
             k = self.cur
-            if self.graph[k] is not None:
+            cg = self.graph.get((k, self.view))
+            if cg is not None:
                 for _ in range(self.reps):
-                    self.graph[k].replay()
+                    cg.replay()
                 return
             for _ in range(self.reps):
                 self._body(k)
-            self.chunks[k] += 1
             if can_record:  # record after one plain chunk on this buffer set (kernels, allocator warm)
                 try:
                     cg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(cg):
                         self._body(k)
-                    self.graph[k] = cg
+                    self.graph[(k, self.view)] = cg
                 except Exception:
                     if use_graph is True:
                         raise
@@ -678,7 +709,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             n_active = N - int(n_done.item())  # one host sync per chunk
             if n_active == 0:
                 break
-            if n_active <= tail_ctx.n_cur // 2 and tail_ctx.n_cur > 64:
+            if tail_ctx.wants_compaction(n_active):
                 tail_ctx.compact(n_active)
             continue
         n_rows = sum(g_.n_rows for g_ in groups)

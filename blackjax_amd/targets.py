@@ -20,6 +20,7 @@ from ._util import check_batch
 
 class _Target:
     _bjx_value_and_grad = True
+    _bjx_returns_pair = True
     _bjx_capturable = True  # one kernel launch over static buffers: safe to record in a HIP graph
 
     def _alloc(self, q):

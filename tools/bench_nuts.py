@@ -58,8 +58,11 @@ if args.free_running:
     tot = int(rinfo.num_integration_steps.sum())
     per_chain = rinfo.num_integration_steps.sum(0).float()
     ticks = tick_timer.seen["bjx_nuts_async_tick"] or int(per_chain.max())
-    tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick") or [float("nan")]
-    avg_tick_us = sum(tick_ms) / len(tick_ms) * 1e3
+    # tick launches are only bracketed with events when no HIP graph is involved (--run-graph off);
+    # otherwise the per-launch fields are null and the wall-clock period per tick is what there is
+    tick_ms = tick_timer.durations_ms("bjx_nuts_async_tick")
+    avg_tick_us = sum(tick_ms) / len(tick_ms) * 1e3 if tick_ms else None
+    mean_us = lambda xs: (sum(xs) / len(xs) * 1e3) if xs else None  # noqa: E731
     # per window of 100 transitions: what a schedule that synchronised the chains every 100 transitions
     # could use at best = leapfrogs of the window / (N x the busiest chain's leapfrogs in it)
     util_windows = []
@@ -79,10 +82,12 @@ if args.free_running:
         "mean_leapfrogs_per_chain_transition": tot / (N * args.steps),
         "ticks": ticks, "max_chain_total_leapfrogs": int(per_chain.max()),
         "utilisation": tot / (N * ticks),
+        "tick_period_avg_us": dt / max(ticks, 1) * 1e6,
+        "tick_kernel_timed": bool(tick_ms),
         "tick_kernel_avg_us": avg_tick_us,
-        "tick_kernel_us_first_20_samples": sum(tick_ms[:20]) / max(len(tick_ms[:20]), 1) * 1e3,
-        "tick_kernel_us_last_20_samples": sum(tick_ms[-20:]) / max(len(tick_ms[-20:]), 1) * 1e3,
-        "tick_kernel_GBps_at_52B_per_element": 52.0 * N * D / (avg_tick_us * 1e-6) / 1e9,
+        "tick_kernel_us_first_20_samples": mean_us(tick_ms[:20]),
+        "tick_kernel_us_last_20_samples": mean_us(tick_ms[-20:]),
+        "tick_kernel_GBps_at_52B_per_element": (52.0 * N * D / (avg_tick_us * 1e-6) / 1e9) if avg_tick_us else None,
         "mean_depth": float(rinfo.num_trajectory_expansions.float().mean()),
         "frac_divergent": float(rinfo.is_divergent.float().mean()),
     }))
