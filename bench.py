@@ -197,8 +197,14 @@ class Ctx:
                              f"--nproc-per-node {args.gpus} (or drop the torchrun environment and let "
                              "bench.py spawn its ranks)")
         self.backend = None
-        if self.world > 1:
+        # BJX_BENCH_FORCE_PG=1: initialise the process group and run every collective of this file even
+        # with ONE rank (tests/test_rccl_gpu.py: RCCL loaded and used on a one-GPU box)
+        self.collective = self.world > 1 or os.environ.get("BJX_BENCH_FORCE_PG", "0") == "1"
+        if self.collective:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             # One rank per GPU over RCCL (backend "nccl").  BJX_BENCH_BACKEND=gloo exists only so the
             # multi-rank control flow can be exercised on a single-GPU or GPU-less box.
             self.backend = "gloo" if self.cpu_only else os.environ.get("BJX_BENCH_BACKEND", "nccl")
@@ -212,14 +218,14 @@ class Ctx:
             self.local_rank %= max(n_dev, 1)
             self.dev = torch.device("cuda", self.local_rank)
             torch.cuda.set_device(self.dev)
-        if self.world > 1:
+        if self.collective:
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
                 dist.init_process_group(self.backend)
 
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
 
     def sync(self):
@@ -228,7 +234,7 @@ class Ctx:
 
     def max_over_ranks(self, dt):
         """-> (max, [per-rank values])"""
-        if self.world == 1:
+        if not self.collective:
             return dt, [dt]
         t = torch.tensor([dt], device=self.coll_dev, dtype=torch.float64)
         out = [torch.empty_like(t) for _ in range(self.world)]
@@ -240,7 +246,7 @@ class Ctx:
         me = {"rank": self.rank, "local_rank": self.local_rank, "device": str(self.dev),
               "name": "cpu" if self.cpu_only else torch.cuda.get_device_name(self.dev),
               "pid": os.getpid()}
-        if self.world == 1:
+        if not self.collective:
             return [me]
         out = [None] * self.world
         self.dist.all_gather_object(out, me)
@@ -252,7 +258,7 @@ class Ctx:
         return self.dev if self.backend == "nccl" else torch.device("cpu")
 
     def gather_rows(self, x):
-        if self.world == 1:
+        if not self.collective:
             return x
         x = x.to(self.coll_dev).contiguous()
         out = [torch.empty_like(x) for _ in range(self.world)]
@@ -260,7 +266,7 @@ class Ctx:
         return torch.cat(out, 0)
 
     def finish(self):
-        if self.world > 1:
+        if self.collective:
             self.dist.destroy_process_group()
 
 
@@ -431,7 +437,7 @@ def bench_c2(args, ctx):
                 if rank == 0:
                     print(f"bench.py: candidate chain_block={cb} hip_graph={gr} streams={ns_} failed: {e!r}",
                           file=sys.stderr)
-        if world > 1:  # every rank must benchmark the same mode
+        if ctx.collective:  # every rank must benchmark the same mode
             t = torch.tensor([tuning[c] for c in candidates], device=ctx.coll_dev, dtype=torch.float64)
             ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
             tuning = {c: float(v) for c, v in zip(candidates, t.tolist())}
@@ -439,11 +445,21 @@ def bench_c2(args, ctx):
     else:
         best = candidates[0]
 
-    head = measure(best[0], best[1], True, streams=best[2])  # THE timed region
+    only_fn = None
+    if args.only_mode == "torch_autograd":
+        only_fn = lambda q: -0.5 * (q * q * inv_var).sum(-1)  # noqa: E731
+    elif args.only_mode == "torch_pair":
+        def only_fn(q):
+            g = -(q * inv_var)
+            return 0.5 * (q * g).sum(-1), g
+
+        bjx.returns_pair(only_fn)
+    head = measure(best[0], best[1], True, streams=best[2], fn=only_fn,
+                   timing=only_fn is None)  # THE timed region
     final_draws = ctx.gather_rows(head["state"].position[:256])  # the only thing that crosses xGMI
 
     # ---- extra regions (rank 0 timing only matters; all ranks run them so barriers line up)
-    extras = not args.headline_only
+    extras = not args.headline_only and not args.only_mode
     stream_m = cache_m = None
     # (every rank takes the same branches here: the extra regions contain barriers)
     if head["timed"] and head["streams"] == 1:  # concurrent blocks share the chip: not a clean per-launch time
@@ -507,23 +523,61 @@ def bench_c2(args, ctx):
         except Exception:
             pass
 
-    # ---- the user log-density as a plain PyTorch function (autograd): the path north_star names
-    torch_mode = None
-    if extras and not args.no_torch_callable:
-        def torch_logdensity(q):
-            return -0.5 * (q * q * inv_var).sum(-1)
+    # ---- the user log-density as PyTorch code: the path north_star names.  Three labelled lines:
+    #   torch_callable_mode        lambda q: -0.5 * (q*q*inv_var).sum(-1) through torch.autograd (plain launches)
+    #   torch_callable_graph_mode  the same callable with the block's inner loop recorded as a HIP graph
+    #   torch_pair_mode            a plain-torch (logp, grad) pair: g = -(q*iv); lp = 0.5*(q*g).sum(-1)
+    # bytes per element of each callable: measured with rocprofv3 --pmc over `--only-mode ...` runs and
+    # committed as profiles/torch_modes_latest.json (read here; estimates are labelled as such otherwise)
+    def torch_logdensity(q):
+        return -0.5 * (q * q * inv_var).sum(-1)
 
+    def torch_pair(q):
+        g = -(q * inv_var)
+        return 0.5 * (q * g).sum(-1), g
+
+    bjx.returns_pair(torch_pair)
+    measured_bpe = {}
+    mpath = os.path.join(ROOT, "profiles", "torch_modes_latest.json")
+    if os.path.exists(mpath):
+        try:
+            measured_bpe = json.load(open(mpath))
+        except Exception:
+            measured_bpe = {}
+
+    def torch_line(m, k_t, name, logdensity_text, est_callable_bpe):
+        pm = measured_bpe.get(name) or {}
+        total = pm.get("bytes_per_element_total")  # engine + callable, per chain-leapfrog element
+        line = {"value": m["value"], "unit": "chain-leapfrog-steps/s", "ms_per_step": m["ms_per_step"],
+                "steps": k_t, "chain_block": m["chain_block"], "hip_graph": m["hip_graph"],
+                "logdensity": logdensity_text, "engine_bytes_per_element": 20,
+                "callable_bytes_per_element_estimate": est_callable_bpe,
+                "bytes_per_element_measured": total,
+                "bytes_per_element_source": (pm.get("source") if total else
+                                             "estimate (no PMC summary committed for this mode)"),
+                "mean_acceptance": m["mean_acceptance"]}
+        bpe = total if total else 20.0 + est_callable_bpe
+        line["frac_of_roofline_at_those_bytes"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (bpe * D))
+        return line
+
+    torch_mode = torch_graph_mode = torch_pair_mode = None
+    if extras and not args.no_torch_callable:
         k_t = max(2, args.steps // 4)
         m = measure(blk_auto, False, False, steps=k_t, fn=torch_logdensity, timing=False)
         # elementwise autograd passes (fp32 words per element): q*q r1 w1, *inv_var r1 w1, sum r1,
-        # backward through sum/mul/mul r3 w3 (+ accumulation) -> ~12 words vs 2 for a fused callable
-        torch_mode = {"value": m["value"], "unit": "chain-leapfrog-steps/s", "ms_per_step": m["ms_per_step"],
-                      "steps": k_t, "chain_block": blk_auto,
-                      "logdensity": "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad)",
-                      "callable_bytes_per_element_estimate": 48,
-                      "engine_bytes_per_element": 20,
-                      "frac_of_68B_roofline": m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D)),
-                      "mean_acceptance": m["mean_acceptance"]}
+        # backward through mul/mul r3 w3 (+ accumulation) -> ~12 words vs 2 for a fused callable
+        torch_mode = torch_line(m, k_t, "torch_autograd",
+                                "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad, grad_outputs=ones)", 48)
+        torch_mode["frac_of_68B_roofline"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D))
+        try:
+            mg = measure(blk_auto, True, False, steps=k_t, fn=torch_logdensity, timing=False)
+            torch_graph_mode = torch_line(mg, k_t, "torch_autograd", torch_mode["logdensity"] + ", inner loop as a HIP graph", 48)
+        except Exception as e:  # a callable torch cannot record is driven with plain launches: say why
+            torch_graph_mode = {"value": None, "error": repr(e)[:300]}
+        mp = measure(blk_auto, False, False, steps=k_t, fn=torch_pair, timing=False)
+        # g = -(q*iv): r1 w1 (+ neg fused or r1 w1); q*g: r2 w1; sum: r1 -> ~6-8 words
+        torch_pair_mode = torch_line(mp, k_t, "torch_pair",
+                                     "g = -(q * inv_var); lp = 0.5 * (q * g).sum(-1); return lp, g  (no autograd)", 32)
 
     # ---- ESS/sec (second half of BASELINE.json's metric)
     def ess_of(draws, dt):
@@ -560,7 +614,8 @@ def bench_c2(args, ctx):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"C2: HMC diag mass, {N} chains/GPU x {D}-dim Gaussian (sigma ladder 0.1..10), "
-                        f"L={L}, eps={args.eps}, user log-density = HIP DiagGaussian callable",
+                        f"L={L}, eps={args.eps}, user log-density = " +
+                        ("HIP DiagGaussian callable" if not args.only_mode else f"PyTorch code ({args.only_mode}; NOT the headline)"),
             "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
             "chain_block": head["chain_block"], "hip_graph": head["hip_graph"], "streams": head["streams"],
             "parallelism": f"chains sharded x{world}, no data-path collective",
@@ -579,6 +634,8 @@ def bench_c2(args, ctx):
         "scheduling_autotune_ms_per_step": {f"chain_block={cb},hip_graph={gr},streams={ns_}": v
                                             for (cb, gr, ns_), v in tuning.items()} or None,
         "torch_callable_mode": torch_mode,
+        "torch_callable_graph_mode": torch_graph_mode,
+        "torch_pair_mode": torch_pair_mode,
         "roofline": roofline,
     }
     return out
@@ -668,7 +725,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # 40 timed transitions = 0.6 s: a single host/driver hiccup (one 28 ms step among 14.5 ms ones was
     # seen in 1 of 8 back-to-back runs) moves a 10-step region by 8 %, a 40-step region by 2 %
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps (0 = the config's default: c2 40 transitions, c4 the 1 000-step warm-up "
+                         "BASELINE.json configs[3] names)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "c4"], default="c2")
     ap.add_argument("--chains", type=int, default=0, help="chains PER GPU (0 = the config's: 65 536 / 32 768)")
@@ -687,6 +746,10 @@ def main():
     ap.add_argument("--no-ess-nonresonant", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--no-rng-pin", action="store_true",
+                    help="skip the jax.random self-check (it only does anything where `import jax` works)")
+    ap.add_argument("--only-mode", choices=["torch_autograd", "torch_pair"], default=None,
+                    help="c2: run ONLY this user-callable mode as the timed region (for rocprofv3 passes)")
     ap.add_argument("--time-every", type=int, default=0,
                     help="bracket every k-th leapfrog launch with HIP events (0 = 16 for short launches, else 1)")
     ap.add_argument("--selftest-control-flow", action="store_true",
@@ -694,8 +757,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
-    if args.steps < 1:
+    if args.steps < 0:
         ap.error("--steps must be >= 1")
+    if args.steps == 0:
+        args.steps = 1000 if args.config == "c4" else 40
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)  # does not return
@@ -709,6 +774,21 @@ def main():
         if ctx.rank == 0:
             out["ranks_seen"] = seen
             out["backend"] = ctx.backend
+            # n_gpus = DISTINCT devices the ranks ran on (one node: the device string identifies the GPU);
+            # "ranks" = processes.  They can only differ under the gloo test knob (several ranks sharing
+            # cuda:0 on a one-GPU box); under RCCL that would be a launch error, not a figure to report.
+            distinct = len({r["device"] for r in seen})
+            out["ranks"] = ctx.world
+            out["devices_distinct"] = distinct
+            out["n_gpus"] = distinct
+            if ctx.backend == "nccl" and distinct != ctx.world:
+                raise SystemExit(f"bench.py: {ctx.world} RCCL ranks ran on {distinct} distinct device(s): {seen}")
+            if distinct != ctx.world:
+                out["n_gpus_note"] = (f"{ctx.world} ranks shared {distinct} device(s) (BJX_BENCH_BACKEND=gloo "
+                                      "control-flow test): NOT a multi-GPU figure")
+            if not args.no_rng_pin:
+                from tools import rng_pin
+                out["rng_pin"] = rng_pin.check(ctx.dev)
             if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
                 try:
                     out["cpu_baseline"] = cpu_baseline(args.dim or 1024, args.leapfrogs, args.eps)

@@ -158,6 +158,29 @@ struct alignas(16) F4 {
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) = v; }
 
+// Nontemporal forms (global_load/store_dwordx4 ... nt): for data that streams through HBM once per
+// launch and is not re-read before the caches have turned over.  Measured with tools/membw2.hip on
+// MI355X (2 GiB arrays, one 16-byte piece per lane): 3-read / 2-write mix 6.17 -> 6.55 TB/s, read-only
+// 6.81 -> 7.06, copy 6.32 -> 6.69 (profiles/r03/membw.json).  NOT for Infinity-Cache-sized blocks:
+// there the point is that the lines stay.
+typedef float bjx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F4 ld4_nt(const float* p) {
+  const bjx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const bjx_f4v*>(p));
+  return F4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4_nt(float* p, F4 v) {
+  const bjx_f4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<bjx_f4v*>(p));
+}
+template <bool NT> __device__ __forceinline__ F4 ld4_t(const float* p) {
+  if constexpr (NT) return ld4_nt(p);
+  else return ld4(p);
+}
+template <bool NT> __device__ __forceinline__ void st4_t(float* p, F4 v) {
+  if constexpr (NT) st4_nt(p, v);
+  else st4(p, v);
+}
+
 // One wavefront sweeps a row of D floats (D % 4 == 0) 16 bytes per lane: for every span of
 // U x 1 KB, `load(u, j)` is called for all its 16-byte pieces first and `body(u, j)` afterwards,
 // both in ascending j (so fp64 accumulations keep their order).  Written this way because a loop

@@ -236,7 +236,7 @@ k_leapfrog_diag(int64_t N, int64_t D, float eps_s, const float* __restrict__ eps
 // wave per row (measured on pseudo-random data, tools/lf_variants: 46.6 vs 48.3 us for 16 384 rows
 // of 1 024, 233 vs 241 us for 65 536).  Workgroups are numbered from the END of the arrays for the
 // same Infinity-Cache reason as above.
-template <int KICKS>
+template <int KICKS, bool NT = false>
 __global__ void __launch_bounds__(kBlock)
 k_leapfrog_diag_flat(int64_t D, int bpr, float eps_s, const float* __restrict__ eps_pc,
                      const float* __restrict__ imm, int64_t imm_stride, const float* q_in,
@@ -256,8 +256,10 @@ k_leapfrog_diag_flat(int64_t D, int bpr, float eps_s, const float* __restrict__ 
   }
   const float eps = eps_pc ? eps_pc[r] : eps_s;
   const float h = eps * kick_a, h2 = eps * kick_b, ed = eps * drift;
-  const F4 pp = ld4(p_in + at), gg = ld4(g + at), qq = ld4(q_in + at);
-  const F4 mm = ld4(imm + r * imm_stride + j);
+  // NT: the launch streams more than the Infinity Cache holds -- nontemporal loads and stores of the
+  // three state arrays (the shared inverse mass vector stays a plain, cached load)
+  const F4 pp = ld4_t<NT>(p_in + at), gg = ld4_t<NT>(g + at), qq = ld4_t<NT>(q_in + at);
+  const F4 mm = imm_stride ? ld4_t<NT>(imm + r * imm_stride + j) : ld4(imm + j);
   F4 pn, qn;
   pn.x = fmaf(h, gg.x, pp.x); pn.y = fmaf(h, gg.y, pp.y);
   pn.z = fmaf(h, gg.z, pp.z); pn.w = fmaf(h, gg.w, pp.w);
@@ -267,8 +269,8 @@ k_leapfrog_diag_flat(int64_t D, int bpr, float eps_s, const float* __restrict__ 
   }
   qn.x = fmaf(ed, mm.x * pn.x, qq.x); qn.y = fmaf(ed, mm.y * pn.y, qq.y);
   qn.z = fmaf(ed, mm.z * pn.z, qq.z); qn.w = fmaf(ed, mm.w * pn.w, qq.w);
-  st4(p_out + at, pn);
-  st4(q_out + at, qn);
+  st4_t<NT>(p_out + at, pn);
+  st4_t<NT>(q_out + at, qn);
 }
 
 // The same one-piece-per-lane stage for ANY row length that is a multiple of 4 floats: lane i of
@@ -732,12 +734,18 @@ int bjx_leapfrog_diag_coef(void* stream, int64_t N, int64_t D, int n_kicks, floa
       bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     const int bpr = (int)(D / 1024);
     const dim3 fgrid((unsigned)(N * bpr));
-    if (n_kicks == 1)
-      hipLaunchKernelGGL(k_leapfrog_diag_flat<1>, fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm,
-                         imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
-    else
-      hipLaunchKernelGGL(k_leapfrog_diag_flat<2>, fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm,
-                         imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift);
+    // nontemporal accesses when ONE launch moves more than the 256 MiB Infinity Cache holds (q, p, g
+    // [, per-chain imm] of all its rows): such a launch streams from HBM whatever the caches do.
+    // BJX_LF_NT=0 / 1 forces plain / nontemporal (A/B: tools/README.md).
+    static const int nt_mode = [] { const char* e = getenv("BJX_LF_NT"); return e ? atoi(e) : -1; }();
+    const int64_t launch_bytes = N * D * 4 * (3 + (imm_stride ? 1 : 0));
+    const bool nt = nt_mode < 0 ? launch_bytes > ((int64_t)256 << 20) : nt_mode != 0;
+#define BJX_LFF(K, T)                                                                                    \
+  hipLaunchKernelGGL((k_leapfrog_diag_flat<K, T>), fgrid, block, 0, s, D, bpr, eps, eps_per_chain, imm, \
+                     imm_stride, q_in, p_in, g, q_out, p_out, n_steps, step_idx, kick_a, kick_b, drift)
+    if (n_kicks == 1) { if (nt) BJX_LFF(1, true); else BJX_LFF(1, false); }
+    else { if (nt) BJX_LFF(2, true); else BJX_LFF(2, false); }
+#undef BJX_LFF
   } else if (flat_ok && (D / 4) % 64 != 0 && N * (D / 4) < ((int64_t)1 << 31) &&
              bjx_vec4_ok(D, imm, q_in, p_in, g, q_out, p_out)) {
     // rows that do not fill whole waves: one 16-byte piece per lane over the flattened arrays

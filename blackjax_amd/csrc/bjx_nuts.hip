@@ -1979,12 +1979,17 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     const dim3 wgrid((unsigned)(run->n_rows < (int64_t)1 << 20 ? run->n_rows : (int64_t)1 << 20));  // one wave per workgroup
     static const int leaf_waves = [] { const char* e = getenv("BJX_LEAF2_WAVES"); return e ? atoi(e) : 3; }();
     static const int fused_waves = [] { const char* e = getenv("BJX_FUSED2_WAVES"); return e ? atoi(e) : 3; }();
+    // Few live rows (the tail of a run, small ensembles): occupancy is irrelevant, the LATENCY of one
+    // wave is everything -- the one-launch tick needs 168 VGPRs + 18 spilled ones (scratch) when capped
+    // for three waves per SIMD; uncapped (two waves, up to 256 VGPRs) it spills nothing.
+    static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
 #define BJX_TICK2_L(NI_, MODE_, W_) \
   hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf)
 #define BJX_TICK2(NI_)                                                                     \
   do {                                                                                     \
     if (fused) {                                                                           \
-      if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);           \
+      if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
+      else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
       if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);            \
       if (run->end_list && run->end_count)                                                 \

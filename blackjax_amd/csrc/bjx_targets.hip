@@ -19,7 +19,7 @@ __device__ __forceinline__ int64_t wave_row0() {
 __device__ __forceinline__ int64_t wave_row_stride() { return (int64_t)gridDim.x * kWavesPerBlock; }
 
 // g = -(q*inv_var) ; logp = 0.5 * sum q*g
-template <int VEC>
+template <int VEC, bool NT = false>
 __global__ void __launch_bounds__(kBlock)
 k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float* __restrict__ q,
                 float* __restrict__ logp, float* __restrict__ g) {
@@ -37,7 +37,7 @@ k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float*
         for (int u = 0; u < U; ++u) {
           const int64_t j = j0 + 256 * u;
           if (j < D) {
-            qq[u] = ld4(q + base + j);
+            qq[u] = ld4_t<NT>(q + base + j);  // NT: the batch streams through HBM (see ld4_nt)
             vv[u] = ld4(iv + j);
           }
         }
@@ -50,7 +50,7 @@ k_diag_gaussian(int64_t N, int64_t D, const float* __restrict__ iv, const float*
             acc += (double)qq[u].y * (double)gg.y;
             acc += (double)qq[u].z * (double)gg.z;
             acc += (double)qq[u].w * (double)gg.w;
-            st4(g + base + j, gg);
+            st4_t<NT>(g + base + j, gg);
           }
         }
       }
@@ -223,10 +223,18 @@ int bjx_target_diag_gaussian(void* stream, int64_t N, int64_t D, const float* in
   else if (bjx_vec4_ok(D, inv_var, q, g_out) && D <= 128)
     hipLaunchKernelGGL(k_diag_gaussian_short<32>, dim3(bjx_row_grid((N + 1) / 2, kWavesPerBlock)), block, 0,
                        (hipStream_t)stream, N, D, inv_var, q, logp_out, g_out);
-  else if (bjx_vec4_ok(D, inv_var, q, g_out))
-    hipLaunchKernelGGL(k_diag_gaussian<4>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
-                       logp_out, g_out);
-  else
+  else if (bjx_vec4_ok(D, inv_var, q, g_out)) {
+    // a batch larger than the Infinity Cache streams from HBM: nontemporal q loads / g stores
+    // (BJX_LF_NT=0 / 1 forces plain / nontemporal, the switch of the leapfrog kernel)
+    static const int nt_mode = [] { const char* e = getenv("BJX_LF_NT"); return e ? atoi(e) : -1; }();
+    const bool nt = nt_mode < 0 ? N * D * 8 > ((int64_t)256 << 20) : nt_mode != 0;
+    if (nt)
+      hipLaunchKernelGGL((k_diag_gaussian<4, true>), grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
+                         logp_out, g_out);
+    else
+      hipLaunchKernelGGL((k_diag_gaussian<4, false>), grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
+                         logp_out, g_out);
+  } else
     hipLaunchKernelGGL(k_diag_gaussian<1>, grid, block, 0, (hipStream_t)stream, N, D, inv_var, q,
                        logp_out, g_out);
   return bjx_check_launch("bjx_target_diag_gaussian");

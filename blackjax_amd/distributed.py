@@ -19,6 +19,16 @@ __all__ = ["ChainShard", "shard_chains", "all_gather_chains", "all_reduce_sum_",
            "merge_moment_blocks", "all_reduce_moments"]
 
 
+# World-size-1 shortcuts skip the collective altogether.  Setting this to True keeps the collective
+# calls even then -- used by tests/test_rccl_gpu.py to run every exchange of this module through RCCL
+# on a one-GPU box (a 1-rank communicator still initialises RCCL and launches its kernels).
+FORCE_COLLECTIVES = False
+
+
+def _single(group) -> bool:
+    return not dist.is_initialized() or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES)
+
+
 class ChainShard(NamedTuple):
     offset: int  # first global chain index owned by this rank  (-> chain_offset=)
     count: int  # number of chains owned by this rank
@@ -40,7 +50,7 @@ def shard_chains(n_chains_total: int, rank: int | None = None, world_size: int |
 def all_gather_chains(local: torch.Tensor, shard: ChainShard, group=None) -> torch.Tensor:
     """All-gather per-chain data (chain axis 0) from every rank into global chain order.
     Handles ragged shards by padding to the largest block (one collective)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return local
     world = dist.get_world_size(group)
     counts = [shard_chains(shard.total, r, world).count for r in range(world)]
@@ -58,7 +68,7 @@ def all_reduce_sum_(buf: torch.Tensor, group=None) -> torch.Tensor:
     single process (``group is None`` means "this process only", NOT the default group, so that
     rank-local runs never issue a collective by accident).  This is the exchange step of the pooled
     (cross-chain) warmup, include/bjx_pool.h."""
-    if group is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if group is None or _single(group):
         return buf
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
@@ -95,7 +105,7 @@ def merge_moment_blocks(a: MomentBlock, b: MomentBlock) -> MomentBlock:
 def all_reduce_moments(local: MomentBlock, group=None) -> MomentBlock:
     """Pool moment blocks over ranks with ONE all-reduce(sum) of the sufficient statistics
     ``(n, n*mean, m2 + n*mean^2)``."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return local
     d = local.mean.numel()
     buf = torch.cat([local.n.reshape(1), (local.n * local.mean).reshape(-1),

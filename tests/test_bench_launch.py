@@ -73,6 +73,12 @@ def test_bench_c2_tiny_single_rank_json_contract():
     assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["value"] > 0
     tc = j["torch_callable_mode"]
     assert tc["value"] > 0 and "autograd" in tc["logdensity"]
+    # the three labelled user-callable lines (autograd, autograd under a HIP graph, plain-torch pair)
+    assert j["torch_pair_mode"]["value"] > 0 and "no autograd" in j["torch_pair_mode"]["logdensity"]
+    tg = j["torch_callable_graph_mode"]
+    assert tg["value"] is None or (tg["value"] > 0 and tg["hip_graph"] is True)
+    assert j["ranks"] == 1 and j["devices_distinct"] == 1
+    assert j["rng_pin"].split(":")[0].split(" ")[0] in ("verified", "mismatch", "unavailable")
     assert j["ess"] is not None and j["ess_nonresonant"]["eps"] == 0.21
     assert 0.3 < j["mean_acceptance"] <= 1.0
 
@@ -84,7 +90,9 @@ def test_bench_two_gloo_ranks_share_one_gpu():
     r = _run(["--gpus", "2", "--no-cpu-baseline"] + TINY, {"BJX_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
-    assert j["n_gpus"] == 2 and j["config"]["global_chains"] == 8192
+    # two gloo ranks on ONE device: n_gpus counts distinct devices, `ranks` the processes
+    assert j["n_gpus"] == 1 and j["ranks"] == 2 and j["devices_distinct"] == 1 and "n_gpus_note" in j
+    assert j["config"]["global_chains"] == 8192
     assert [x["rank"] for x in j["ranks_seen"]] == [0, 1] and len(j["per_rank_ms_per_step"]) == 2
     assert j["final_draws_gathered"] == [512, 256]
     assert "cpu_baseline" not in j

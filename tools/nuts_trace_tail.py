@@ -9,10 +9,16 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
-tick_idx = [i for i, r in enumerate(rows) if "async_fused" in r["Kernel_Name"]]
+def is_tick(name):  # the one-launch tick: round-1 k_nuts_async_fused or k_nuts_async_tick2<NI, 2, WAVES>
+    if "async_fused" in name:
+        return True
+    return "async_tick2<" in name and name.split("async_tick2<")[1].split(",")[1].strip() == "2"
+
+
+tick_idx = [i for i, r in enumerate(rows) if is_tick(r["Kernel_Name"])]
 if not tick_idx:
-    sys.exit("no k_nuts_async_fused launches in the trace")
-n_tail = min(400, len(tick_idx) - 1)
+    sys.exit("no one-launch ticks in the trace")
+n_tail = min(int(sys.argv[2]) if len(sys.argv) > 2 else 400, len(tick_idx) - 1)
 first = tick_idx[-n_tail - 1]
 tail = rows[first:tick_idx[-1]]
 dur = collections.defaultdict(list)
