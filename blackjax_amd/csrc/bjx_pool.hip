@@ -393,12 +393,14 @@ __global__ __launch_bounds__(256) void k_chees_wcol(int64_t N, int64_t D, int tp
 // meet at the end, where they add their column sums into LDS one after the other (fixed order).
 // Measured at 65 536 x 1 024 against k_chees_wcol (a row spread over four waves, one barrier per eight
 // rows): see DESIGN.md section 11.
-template <int NI>
+// FULL: D == NI * 256, every lane owns NI valid pieces -- no exec-masked branches around the loads, so
+// the compiler counts the outstanding loads exactly (with them it falls back to vmcnt(0) and the
+// pipeline degenerates).
+template <int NI, bool FULL>
 __global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const float* __restrict__ qp,
                                                     const float* __restrict__ qi, const float* __restrict__ acc,
                                                     const uint8_t* __restrict__ is_div, float* __restrict__ w_out,
                                                     double* __restrict__ partial) {
-  constexpr int U = NI >= 4 ? 2 : 4;  // rows in flight per wave
   __shared__ double sm[3][NI * 256];
   __shared__ double sm_w;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -407,58 +409,83 @@ __global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const 
   const int n = (int)N;
   bool ok[NI];
 #pragma unroll
-  for (int k = 0; k < NI; ++k) ok[k] = ((int64_t)lane + 64 * k) * 4 < D;
-  double a0[NI][4], a1[NI][4], a2[NI][4], aw = 0.0;
+  for (int k = 0; k < NI; ++k) ok[k] = FULL || ((int64_t)lane + 64 * k) * 4 < D;
+  double a0[NI][4], a1[NI][4], aw = 0.0;
+  int a2[NI][4];  // counts of finite initial entries: exact integers (converted once at the end)
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a0[k][e] = a1[k][e] = a2[k][e] = 0.0;
-  for (int r0 = wave; r0 < n; r0 += n_waves * U) {
-    F4 x[U][NI], y[U][NI];
-    float an[U];
-    int dn[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = r0 + u * n_waves;
-      const int rc = r < n ? r : n - 1;  // rows past the end shadow the last row and are not accumulated
-      an[u] = acc[rc];
-      dn[u] = is_div[rc];
-#pragma unroll
-      for (int k = 0; k < NI; ++k)
-        if (ok[k]) {
-          const int64_t at = (int64_t)rc * D + ((int64_t)lane + 64 * k) * 4;
-          x[u][k] = ld4(qp + at);
-          y[u][k] = ld4(qi + at);
-        }
+    for (int e = 0; e < 4; ++e) {
+      a0[k][e] = a1[k][e] = 0.0;
+      a2[k][e] = 0;
     }
+  // Round 3: an explicit two-stage pipeline (two register sets, A and B, no copies between them): the
+  // loads of row r + n_waves are in flight while row r is accumulated, so a wave always has 8 KB
+  // (D = 1 024) outstanding instead of alternating between a load phase and a ~1 500-cycle arithmetic
+  // phase -- with two waves per SIMD (the accumulators need ~190 VGPRs) nothing else hides that.
+  // Nontemporal loads: both arrays are read once (tools/membw2.hip: 6.45 -> 6.79 TB/s for this mix).
+  // A wave still takes rows wave, wave + n_waves, ... in ascending order: the sums are those of the
+  // round-2 kernel bit for bit.
+  struct Stage {
+    F4 x[NI], y[NI];
+    float an;
+    int dn;
+  };
+  auto issue = [&](Stage& st, int r) {
+    st.an = acc[r];
+    st.dn = is_div[r];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = r0 + u * n_waves;
-      bool nf = false;
-#pragma unroll
-      for (int k = 0; k < NI; ++k)
-        if (ok[k]) nf |= !(isfinite(x[u][k].x) && isfinite(x[u][k].y) && isfinite(x[u][k].z) && isfinite(x[u][k].w));
-      const bool bad = __any(nf);
-      if (r < n) {  // wave uniform
-        const float wf = (dn[u] || bad) ? 0.0f : an[u];
-        if (lane == 0) w_out[r] = wf;
-        const double wr = (double)wf;
-#pragma unroll
-        for (int k = 0; k < NI; ++k)
-          if (ok[k]) {
-            const float xv[4] = {x[u][k].x, x[u][k].y, x[u][k].z, x[u][k].w};
-            const float yv[4] = {y[u][k].x, y[u][k].y, y[u][k].z, y[u][k].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float xs = isfinite(xv[e]) ? xv[e] : 0.0f;
-              a0[k][e] += wr * (double)xs;
-              const bool fin = !(yv[e] != yv[e]);
-              a1[k][e] += fin ? (double)yv[e] : 0.0;
-              a2[k][e] += fin ? 1.0 : 0.0;
-            }
-          }
-        aw += wr;
+    for (int k = 0; k < NI; ++k)
+      if (FULL || ok[k]) {
+        const int64_t at = (int64_t)r * D + ((int64_t)lane + 64 * k) * 4;
+        st.x[k] = ld4_nt(qp + at);
+        st.y[k] = ld4_nt(qi + at);
       }
+  };
+  auto consume = [&](const Stage& st, int r) {
+    bool nf = false;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (FULL || ok[k]) nf |= !(isfinite(st.x[k].x) && isfinite(st.x[k].y) && isfinite(st.x[k].z) && isfinite(st.x[k].w));
+    const bool bad = __any(nf);
+    const float wf = (st.dn || bad) ? 0.0f : st.an;
+    if (lane == 0) w_out[r] = wf;
+    const double wr = (double)wf;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (FULL || ok[k]) {
+        const float xv[4] = {st.x[k].x, st.x[k].y, st.x[k].z, st.x[k].w};
+        const float yv[4] = {st.y[k].x, st.y[k].y, st.y[k].z, st.y[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xs = isfinite(xv[e]) ? xv[e] : 0.0f;
+          a0[k][e] += wr * (double)xs;
+          const bool fin = !(yv[e] != yv[e]);
+          a1[k][e] += fin ? (double)yv[e] : 0.0;
+          a2[k][e] += fin ? 1 : 0;
+        }
+      }
+    aw += wr;
+  };
+  Stage A, B;
+  // Every iteration issues its loads UNCONDITIONALLY (past the end it re-requests the last row and
+  // drops it): a conditional issue gives the two paths different outstanding-load counts, the compiler
+  // then waits for the smaller one and the row just requested is waited for before the previous one is
+  // consumed.
+  const int last = n - 1;
+  int r = wave;
+  if (r < n) {
+    issue(A, r);
+    for (;;) {
+      const int r1 = r + n_waves;
+      issue(B, r1 < n ? r1 : last);
+      consume(A, r);
+      if (r1 >= n) break;
+      const int r2 = r1 + n_waves;
+      issue(A, r2 < n ? r2 : last);
+      consume(B, r1);
+      if (r2 >= n) break;
+      r = r2;
     }
   }
   for (int w = 0; w < 4; ++w) {  // the four waves add their sums in wave order
@@ -469,9 +496,9 @@ __global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const 
         for (int e = 0; e < 4; ++e) {
           const int c = (lane + 64 * k) * 4 + e;
           if (w == 0) {
-            sm[0][c] = a0[k][e]; sm[1][c] = a1[k][e]; sm[2][c] = a2[k][e];
+            sm[0][c] = a0[k][e]; sm[1][c] = a1[k][e]; sm[2][c] = (double)a2[k][e];
           } else {
-            sm[0][c] += a0[k][e]; sm[1][c] += a1[k][e]; sm[2][c] += a2[k][e];
+            sm[0][c] += a0[k][e]; sm[1][c] += a1[k][e]; sm[2][c] += (double)a2[k][e];
           }
         }
       if (lane == 0) sm_w = (w == 0) ? aw : sm_w + aw;
@@ -808,8 +835,14 @@ int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const f
     int64_t wgs = (N + 4 * u - 1) / (4 * u);
     nslab = wgs < 512 ? wgs : 512;  // <= the slab count bjx_pool_workspace_bytes sizes the partials for
 #define BJX_WROW(NI_)                                                                                   \
-  hipLaunchKernelGGL(k_chees_wrow<NI_>, dim3((unsigned)nslab), dim3(256), 0, stream, N, D, q_prop, q_init, \
-                     acc, is_divergent, w, partial)
+  do {                                                                                                  \
+    if (D == (NI_) * 256)                                                                               \
+      hipLaunchKernelGGL((k_chees_wrow<NI_, true>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D,  \
+                         q_prop, q_init, acc, is_divergent, w, partial);                                \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_chees_wrow<NI_, false>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D, \
+                         q_prop, q_init, acc, is_divergent, w, partial);                                \
+  } while (0)
     if (D <= 256) BJX_WROW(1);
     else if (D <= 512) BJX_WROW(2);
     else BJX_WROW(4);

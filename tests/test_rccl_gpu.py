@@ -36,6 +36,13 @@ def _env():
     return env
 
 
+def _last_json(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in: " + text[-500:])
+
+
 WORKER = textwrap.dedent("""
     import json, sys
     sys.path.insert(0, %r)
@@ -69,7 +76,7 @@ WORKER = textwrap.dedent("""
 def test_engine_exchanges_run_through_rccl_with_one_rank():
     r = subprocess.run([sys.executable, "-c", WORKER], env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = _last_json(r.stdout)  # RCCL prints its own "Librccl path : ..." line to stdout
     assert out == {"backend": "nccl", "ok_gather": True, "ok_mom": True, "ok_sum": True, "rccl_mapped": True}
 
 
@@ -80,6 +87,6 @@ def test_bench_control_flow_over_rccl_with_one_rank():
                         "--chains", "4096", "--headline-only", "--no-cpu-baseline", "--no-rng-pin"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    j = _last_json(r.stdout)
     assert j["backend"] == "nccl" and j["n_gpus"] == 1 and j["ranks"] == 1 and j["devices_distinct"] == 1
     assert j["value"] > 0 and j["final_draws_gathered"] == [256, 1024]
