@@ -52,6 +52,10 @@ SIGNATURES = {
                                   c_int, c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p,
                                   _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                   c_void_p],
+    "bjx_mhmc_step_diag_coef": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                c_int, c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p,
+                                _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                c_void_p, c_float, c_float],
     "bjx_mhmc_finish_masked": [c_void_p, c_int64, c_int64, c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p,
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_dense_matmul": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
@@ -118,6 +122,7 @@ class NutsDesc(ctypes.Structure):
         ("fs", c_void_p), ("is_", c_void_p),
         ("Mdense", c_void_p), ("Mdense_stride", c_int64), ("v0", c_void_p),
         ("Lv", c_void_p), ("Rv", c_void_p), ("ckpt_v", c_void_p),
+        ("int_kick", c_float), ("int_drift", c_float),
     ]
 
 
@@ -135,6 +140,7 @@ SIGNATURES.update({
     "bjx_nuts_pre": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p],
     "bjx_nuts_post": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p,
                       _f32p, _f32p, ctypes.c_int32],
+    "bjx_nuts_mid": [c_void_p, POINTER(NutsDesc), c_int64, c_void_p, c_void_p, _f32p, _f32p, c_float, c_float],
     "bjx_nuts_pre_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p],
     "bjx_nuts_post_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p,
                           _f32p, _f32p, ctypes.c_int32],

@@ -491,7 +491,11 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
                  const float* __restrict__ logp_new, float* __restrict__ W, float* __restrict__ S,
                  uint8_t* __restrict__ any_div, uint8_t* __restrict__ ever, float* __restrict__ Rq,
                  float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
-                 float* __restrict__ Renergy, const int32_t* __restrict__ n_steps) {
+                 float* __restrict__ Renergy, const int32_t* __restrict__ n_steps, float kick_c,
+                 float drift_c) {
+  // kick_c / drift_c: coefficients b_1 / a_1 of a palindromic integrator (integrators.py:104-150): the
+  // closing kick of step i and the opening kick of step i + 1 are both (eps * b_1) g, the drift that
+  // follows is (eps * a_1) M^{-1} p.  Velocity Verlet = (0.5, 1.0): eps * 1.0f == eps, the former bits.
   const int lane = threadIdx.x & 63;
   const int do_next_all = do_next_arg;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
@@ -504,7 +508,8 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
       do_next = do_next_all && step + 1 < ns;
     }
     const float eps = eps_pc ? eps_pc[r] : eps_s;
-    const float h = eps * 0.5f;
+    const float h = eps * kick_c;
+    const float ed = eps * drift_c;
     const int64_t base = r * D;
     const float* im = imm + r * imm_stride;
     double acc = 0.0;
@@ -584,8 +589,8 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
             if (do_next) {
               const F4 M = mm[u];
               F4 pn{fmaf(h, G.x, pf.x), fmaf(h, G.y, pf.y), fmaf(h, G.z, pf.z), fmaf(h, G.w, pf.w)};
-              F4 qn{fmaf(eps, M.x * pn.x, Q.x), fmaf(eps, M.y * pn.y, Q.y),
-                    fmaf(eps, M.z * pn.z, Q.z), fmaf(eps, M.w * pn.w, Q.w)};
+              F4 qn{fmaf(ed, M.x * pn.x, Q.x), fmaf(ed, M.y * pn.y, Q.y),
+                    fmaf(ed, M.z * pn.z, Q.z), fmaf(ed, M.w * pn.w, Q.w)};
               st4(p + base + j, pn);
               st4(q + base + j, qn);
             }
@@ -602,7 +607,7 @@ k_mhmc_step_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int64
         if (do_next) {
           const float pn = fmaf(h, gg, pf);
           p[base + j] = pn;
-          q[base + j] = fmaf(eps, im[j] * pn, qq);
+          q[base + j] = fmaf(ed, im[j] * pn, qq);
         }
       }
     }
@@ -893,7 +898,8 @@ static int mhmc_step_diag(const char* what, void* stream, uint32_t key0, uint32_
                           float* p, const float* g, const float* logp_new, float* weight,
                           float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
                           float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
-                          float* prop_energy, const int32_t* n_steps) {
+                          float* prop_energy, const int32_t* n_steps, float kick_c = 0.5f,
+                          float drift_c = 1.0f) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
                     weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q && prop_p &&
@@ -907,7 +913,7 @@ static int mhmc_step_diag(const char* what, void* stream, uint32_t key0, uint32_
   hipLaunchKernelGGL(k_mhmc_step_diag<V>, grid, block, 0, s, key, chain_offset, step_fold, N, D, \
                      step, do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold,  \
                      logp0, ke0, q, p, g, logp_new, weight, sum_log_p_accept, any_divergent,    \
-                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy, n_steps)
+                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy, n_steps, kick_c, drift_c)
   if (bjx_vec4_ok(D, imm, q, p, g, prop_q, prop_p, prop_g)) BJX_MH(4);
   else BJX_MH(1);
 #undef BJX_MH
@@ -941,6 +947,20 @@ int bjx_mhmc_step_diag_masked(void* stream, uint32_t key0, uint32_t key1, int64_
                         do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold, logp0, ke0, q, p,
                         g, logp_new, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q, prop_p,
                         prop_g, prop_logp, prop_energy, n_steps);
+}
+
+int bjx_mhmc_step_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                            int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                            const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                            float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                            float* p, const float* g, const float* logp_new, float* weight,
+                            float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                            float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                            float* prop_energy, const int32_t* n_steps, float kick_coef, float drift_coef) {
+  return mhmc_step_diag("bjx_mhmc_step_diag_coef", stream, key0, key1, chain_offset, step_fold, N, D, step,
+                        do_next, eps, eps_per_chain, imm, imm_stride, divergence_threshold, logp0, ke0, q, p,
+                        g, logp_new, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q, prop_p,
+                        prop_g, prop_logp, prop_energy, n_steps, kick_coef, drift_coef);
 }
 
 static int mhmc_finish(const char* what, void* stream, int64_t N, int64_t D, int64_t num_integration_steps,

@@ -134,6 +134,10 @@ __device__ __forceinline__ Key integrator_key(const StepCtx& cx, int64_t c) {
   return key_child(kc, 1);  // split(kc, 2)[1]   (nuts.py:133)
 }
 
+// coefficients b_1 / a_1 of the palindromic integrator (both 0 in the descriptor = velocity Verlet)
+__device__ __forceinline__ float int_kick(const bjx_nuts_t& nt) { return nt.int_kick != 0.0f ? nt.int_kick : 0.5f; }
+__device__ __forceinline__ float int_drift(const bjx_nuts_t& nt) { return nt.int_drift != 0.0f ? nt.int_drift : 1.0f; }
+
 __device__ __forceinline__ float chain_eps(const bjx_nuts_t& nt, int64_t c) {
   return nt.eps_per_chain ? nt.eps_per_chain[c] : nt.eps;
 }
@@ -310,9 +314,27 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
       dir = IS(BJX_NUTS_I_DIR, c);
     }
     const float deps = (float)dir * chain_eps(nt, c);  // direction * step_size (trajectory.py:323)
-    const float h = deps * 0.5f;
+    const float h = deps * int_kick(nt);               // step_size * coef (integrators.py:236)
     const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
-    nuts_open_half<VEC, DENSE>(nt, c, dir, deps, h, fg, qf + b * nt.D);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), h, fg, qf + b * nt.D);
+  }
+}
+
+// Stage 2 .. K of a multi-stage palindromic integrator (integrators.py:128-146) on the integrating end
+// of every chain whose subtree is still running: the arithmetic of nuts_open_half with the stage's
+// coefficients and the callable's latest gradient.
+template <int VEC, bool DENSE>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_mid(bjx_nuts_t nt, int64_t n_rows_arg, const int32_t* __restrict__ idx,
+           const int64_t* __restrict__ ctl, float* __restrict__ qf, const float* __restrict__ gf, float kick,
+           float drift) {
+  const int64_t n_rows = ctl ? (ctl[2] < n_rows_arg ? ctl[2] : n_rows_arg) : n_rows_arg;
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
+    const int dir = IS(BJX_NUTS_I_DIR, c);
+    const float deps = (float)dir * chain_eps(nt, c);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * drift, deps * kick, gf + b * nt.D, qf + b * nt.D);
   }
 }
 
@@ -331,7 +353,8 @@ __device__ __forceinline__ bool nuts_post_chain_resident(const bjx_nuts_t& nt, c
   const int lane = threadIdx.x & 63;
   const int dir = IS(BJX_NUTS_I_DIR, c);
   const float deps = (float)dir * chain_eps(nt, c);
-  const float h = deps * 0.5f;
+  const float h = deps * int_kick(nt);    // closing kick b_K = b_1 (and the next leaf's opening kick)
+  const float dd = deps * int_drift(nt);  // first drift a_1 of the next leaf
   const int64_t base = c * nt.D;
   float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
   float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
@@ -471,7 +494,7 @@ __device__ __forceinline__ bool nuts_post_chain_resident(const bjx_nuts_t& nt, c
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           P[k].v[e] = fmaf(h, G[k].v[e], P[k].v[e]);
-          Q[k].v[e] = fmaf(deps, M[k].v[e] * P[k].v[e], Q[k].v[e]);
+          Q[k].v[e] = fmaf(dd, M[k].v[e] * P[k].v[e], Q[k].v[e]);
         }
         str<VEC>(fq + j0[k], Q[k]);
         str<VEC>(qn + j0[k], Q[k]);
@@ -494,7 +517,7 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
   const int lane = threadIdx.x & 63;
   const int dir = IS(BJX_NUTS_I_DIR, c);
   const float deps = (float)dir * chain_eps(nt, c);
-  const float h = deps * 0.5f;
+  const float h = deps * int_kick(nt);
   const int64_t base = c * nt.D;
   float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
   float* fg = (dir > 0 ? nt.Rg : nt.Lg) + base;
@@ -645,7 +668,7 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
 
   // Fused opening half of the NEXT leapfrog (same arithmetic as k_nuts_pre at s + 1): saves a
   // launch and the re-read of p, g, q.  Only when the subtree keeps integrating.
-  if (fuse_next && !(sdiv || turning)) nuts_open_half<VEC, DENSE>(nt, c, dir, deps, h, gn, qn);
+  if (fuse_next && !(sdiv || turning)) nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), h, gn, qn);
   return sdiv || turning;
 }
 
@@ -1842,6 +1865,18 @@ int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_
   BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
                   *nuts, 0, s_off, n_cap, idx, ctl, qf);
   return bjx_check_launch("bjx_nuts_pre_ctl");
+}
+
+int bjx_nuts_mid(void* stream, const bjx_nuts_t* nuts, int64_t n_rows, const int32_t* idx,
+                 const int64_t* ctl, float* qf, const float* gf, float kick, float drift) {
+  if (check_nuts(nuts, "bjx_nuts_mid")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
+  BJX_CHECK_ARG(n_rows >= 0 && n_rows <= nuts->N && qf && gf && (idx || !ctl), "bjx_nuts_mid: bad arguments");
+  if (n_rows == 0) return 0;
+  const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
+  BJX_NUTS_LAUNCH(k_nuts_mid, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr,
+                  *nuts, n_rows, idx, ctl, qf, gf, kick, drift);
+  return bjx_check_launch("bjx_nuts_mid");
 }
 
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,

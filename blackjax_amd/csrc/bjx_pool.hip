@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_chees_wcol(int64_t N, int64_t D, int tp
 // FULL: D == NI * 256, every lane owns NI valid pieces -- no exec-masked branches around the loads, so
 // the compiler counts the outstanding loads exactly (with them it falls back to vmcnt(0) and the
 // pipeline degenerates).
-template <int NI, bool FULL>
+template <int NI, bool FULL, bool NT>
 __global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const float* __restrict__ qp,
                                                     const float* __restrict__ qi, const float* __restrict__ acc,
                                                     const uint8_t* __restrict__ is_div, float* __restrict__ w_out,
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(256) void k_chees_wrow(int64_t N, int64_t D, const 
     for (int k = 0; k < NI; ++k)
       if (FULL || ok[k]) {
         const int64_t at = (int64_t)r * D + ((int64_t)lane + 64 * k) * 4;
-        st.x[k] = ld4_nt(qp + at);
-        st.y[k] = ld4_nt(qi + at);
+        st.x[k] = ld4_t<NT>(qp + at);
+        st.y[k] = ld4_t<NT>(qi + at);
       }
   };
   auto consume = [&](const Stage& st, int r) {
@@ -831,16 +831,22 @@ int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const f
   int64_t nslab = g.nslab;
   static const bool by_rows = !(getenv("BJX_CHEES_WCOL") && atoi(getenv("BJX_CHEES_WCOL")) != 0);
   if (vec4 && D > 128 && D <= 1024 && N < ((int64_t)1 << 31) && by_rows) {  // whole rows per wave
+    // nontemporal loads make THIS pass faster (tools/membw2.hip) but leave nothing of q' / q in the
+    // Infinity Cache for the criterion kernel that follows: BJX_CHEES_NT=1 to try (default plain)
+    static const bool chees_nt = getenv("BJX_CHEES_NT") && atoi(getenv("BJX_CHEES_NT")) != 0;
     const int u = D > 512 ? 2 : 4;
     int64_t wgs = (N + 4 * u - 1) / (4 * u);
     nslab = wgs < 512 ? wgs : 512;  // <= the slab count bjx_pool_workspace_bytes sizes the partials for
 #define BJX_WROW(NI_)                                                                                   \
   do {                                                                                                  \
-    if (D == (NI_) * 256)                                                                               \
-      hipLaunchKernelGGL((k_chees_wrow<NI_, true>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D,  \
+    if (D == (NI_) * 256 && chees_nt)                                                                   \
+      hipLaunchKernelGGL((k_chees_wrow<NI_, true, true>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D, \
+                         q_prop, q_init, acc, is_divergent, w, partial);                                \
+    else if (D == (NI_) * 256)                                                                          \
+      hipLaunchKernelGGL((k_chees_wrow<NI_, true, false>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D, \
                          q_prop, q_init, acc, is_divergent, w, partial);                                \
     else                                                                                                \
-      hipLaunchKernelGGL((k_chees_wrow<NI_, false>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D, \
+      hipLaunchKernelGGL((k_chees_wrow<NI_, false, false>), dim3((unsigned)nslab), dim3(256), 0, stream, N, D, \
                          q_prop, q_init, acc, is_divergent, w, partial);                                \
   } while (0)
     if (D <= 256) BJX_WROW(1);

@@ -116,16 +116,18 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                  integration_steps_fn: Callable = randint_steps_fn, build_proposal=None):
     """blackjax/mcmc/dynamic_hmc.py:65-126.  ``integration_steps_fn(random_generator_arg, *params)``
     returns an ``(N,)`` int32 device tensor of trajectory lengths (>= 1)."""
-    integrators.check_supported(integrator)
+    # any palindromic coefficient list (integrators.py:62-152; dynamic_hmc.py:65-71 takes `integrator=`)
+    integrators.check_supported(integrator, allow_general=True)
+    general = integrator is not integrators.velocity_verlet
+    kick_c = integrator.coefficients[0::2]   # b1 .. b1
+    drift_c = integrator.coefficients[1::2]  # a1 ..
     from .hmc import hmc_proposal, multinomial_hmc_proposal
 
     if build_proposal not in (None, hmc_proposal, multinomial_hmc_proposal):
         raise NotImplementedError("dynamic_hmc: build_proposal must be hmc_proposal or multinomial_hmc_proposal")
     thr = float(divergence_threshold)
     if build_proposal is multinomial_hmc_proposal:
-        if integrator is not integrators.velocity_verlet:
-            raise NotImplementedError("dmhmc is implemented for velocity_verlet")
-        return _build_multinomial_kernel(thr, next_random_arg_fn, integration_steps_fn)
+        return _build_multinomial_kernel(thr, next_random_arg_fn, integration_steps_fn, kick_c, drift_c)
 
     def kernel(rng_key, state: DynamicHMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, integration_steps_params: tuple = (), *, chain_offset: int = 0):
@@ -165,11 +167,17 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         # is unchanged, so the callable keeps returning the same (logp, g) for them)
         ns = None if lo == hi else n_steps
 
-        def stage(n_k, l, q_in, p_in, g_in, p_out):
+        def stage(n_k, ka, kb, a_c, l, q_in, p_in, g_in, p_out):
+            """One position update: kicks (eps*ka) g [, (eps*kb) g], drift (eps*a_c) M^{-1} p, for the
+            chains whose trajectory has more than ``l`` steps."""
             if not is_diag:  # dense metric: kick + GEMM / mat-vec + drift, masked by the chain's length
-                return dense.leapfrog_coef(stream, metric, N, D, n_k, 0.5, 0.5, 1.0, eps, eps_pc, q_in,
+                return dense.leapfrog_coef(stream, metric, N, D, n_k, ka, kb, a_c, eps, eps_pc, q_in,
                                            p_in, g_in, q, p_out, ns, l)
-            if ns is None:
+            if general:
+                _lib.call("bjx_leapfrog_diag_coef", stream, N, D, n_k, ka, kb, a_c, eps, _lib.ptr(eps_pc),
+                          imm_p, imm_s, q_in.data_ptr(), p_in.data_ptr(), g_in.data_ptr(), q.data_ptr(),
+                          p_out.data_ptr(), _lib.ptr(ns), l)
+            elif ns is None:
                 _lib.call("bjx_leapfrog_diag", stream, N, D, n_k, eps, _lib.ptr(eps_pc), imm_p, imm_s,
                           q_in.data_ptr(), p_in.data_ptr(), g_in.data_ptr(), q.data_ptr(), p_out.data_ptr())
             else:
@@ -178,22 +186,42 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
                           p_out.data_ptr(), ns.data_ptr(), l)
             return p_out
 
-        p = stage(1, 0, q0, p0, g0, p)
-        logp, g = eval_logdensity(vg, q)
-        for l in range(1, hi):
-            p = stage(2, l, q, p, g, p)
-            logp, g = eval_logdensity(vg, q)
+        # generalized_two_stage_integrator (integrators.py:104-150): one launch per position update; the
+        # closing kick b_K of a step merges with the opening kick b_1 of the next (two separately
+        # rounded fmas); a chain that has finished keeps its state -- its last closing kick is the
+        # finish kernel's, as for velocity Verlet
+        first = True
+        for l in range(hi):
+            for si, a_c in enumerate(drift_c):
+                if first:
+                    p = stage(1, kick_c[0], 0.0, a_c, 0, q0, p0, g0, p)
+                    first = False
+                elif si == 0:
+                    p = stage(2, kick_c[-1], kick_c[0], a_c, l, q, p, g, p)
+                else:
+                    p = stage(1, kick_c[si], 0.0, a_c, l, q, p, g, p)
+                logp, g = eval_logdensity(vg, q)
 
         p_end, q_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         logp_new, acc_rate, energy = (torch.empty_like(logp0) for _ in range(3))
         is_acc = torch.empty(N, dtype=torch.bool, device=dev)
         is_div = torch.empty(N, dtype=torch.bool, device=dev)
-        if is_diag:
+        if is_diag and general:
+            _lib.call("bjx_hmc_finish_diag_coef", stream, k0, k1, off, fold, N, D, kick_c[-1], eps,
+                      _lib.ptr(eps_pc), imm_p, imm_s, thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(),
+                      ke0.data_ptr(), q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(),
+                      p_end.data_ptr(), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
+                      acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        elif is_diag:
             _lib.call("bjx_hmc_finish_diag", stream, k0, k1, off, fold, N, D, eps, _lib.ptr(eps_pc), imm_p,
                       imm_s, thr, q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), ke0.data_ptr(),
                       q.data_ptr(), logp.data_ptr(), g.data_ptr(), p.data_ptr(), p_end.data_ptr(),
                       q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(),
                       is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        elif general:
+            dense.finish_coef(stream, metric, k0, k1, off, fold, N, D, kick_c[-1], eps, eps_pc, thr, q0, logp0,
+                              g0, ke0, q, logp, g, p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div,
+                              energy)
         else:
             dense.finish(stream, metric, k0, k1, off, fold, N, D, eps, eps_pc, thr, q0, logp0, g0, ke0, q,
                          logp, g, p, p_end, q_new, logp_new, g_new, acc_rate, is_acc, is_div, energy)
@@ -205,7 +233,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     return kernel
 
 
-def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integration_steps_fn: Callable):
+def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integration_steps_fn: Callable,
+                              kick_c=(0.5, 0.5), drift_c=(1.0,)):
     """blackjax.dmhmc (blackjax/__init__.py:155-163): every chain draws its own trajectory length and one
     state of ITS trajectory proportionally to exp(-H) (hmc.py:181-248 over dynamic_hmc.py:85-118).  Diagonal
     metric; the per-chain lengths mask the fused step kernel of ``blackjax_amd.mhmc``."""
@@ -242,15 +271,21 @@ def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integrat
         pq, pp, pg = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         plogp, penergy, acc_rate = torch.empty_like(logp0), torch.empty_like(logp0), torch.empty_like(logp0)
         q, p = torch.empty_like(q0), torch.empty_like(q0)
-        _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s, q0.data_ptr(),
-                  p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
+        b1, a1 = float(kick_c[0]), float(drift_c[0])
+        _lib.call("bjx_leapfrog_diag_coef", stream, N, D, 1, b1, 0.0, a1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
+                  q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)
         for i in range(hi):
             logp, g = eval_logdensity(vg, q)  # finished chains keep their q: same (logp, g) again, unused
-            _lib.call("bjx_mhmc_step_diag_masked", stream, k0, k1, off, fold, N, D, i, 1 if i + 1 < hi else 0,
+            for si in range(1, len(drift_c)):  # stages 2 .. K of a multi-stage integrator, masked by length
+                _lib.call("bjx_leapfrog_diag_coef", stream, N, D, 1, float(kick_c[si]), 0.0, float(drift_c[si]),
+                          eps, _lib.ptr(eps_pc), imm_p, imm_s, q.data_ptr(), p.data_ptr(), g.data_ptr(),
+                          q.data_ptr(), p.data_ptr(), n_steps.data_ptr(), i)
+                logp, g = eval_logdensity(vg, q)
+            _lib.call("bjx_mhmc_step_diag_coef", stream, k0, k1, off, fold, N, D, i, 1 if i + 1 < hi else 0,
                       eps, _lib.ptr(eps_pc), imm_p, imm_s, thr, logp0.data_ptr(), ke0.data_ptr(), q.data_ptr(),
                       p.data_ptr(), g.data_ptr(), logp.data_ptr(), weight.data_ptr(), slpa.data_ptr(),
                       any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
-                      plogp.data_ptr(), penergy.data_ptr(), n_steps.data_ptr())
+                      plogp.data_ptr(), penergy.data_ptr(), n_steps.data_ptr(), b1, a1)
         _lib.call("bjx_mhmc_finish_masked", stream, N, D, n_steps.data_ptr(), q0.data_ptr(), p0.data_ptr(),
                   g0.data_ptr(), logp0.data_ptr(), ke0.data_ptr(), ever.data_ptr(), slpa.data_ptr(),
                   pq.data_ptr(), pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr(),

@@ -90,7 +90,7 @@ hmc_proposal = _ProposalKind("hmc_proposal")
 multinomial_hmc_proposal = _ProposalKind("multinomial_hmc_proposal")
 
 
-def _build_mhmc_kernel(thr: float):
+def _build_mhmc_kernel(thr: float, kick_c=(0.5, 0.5), drift_c=(1.0,)):
     """blackjax.mhmc: ``build_kernel(build_proposal=multinomial_hmc_proposal)`` (hmc.py:181-248 with
     trajectory.static_progressive_integration 170-232).  Instead of the trajectory end point, one
     state of the whole trajectory is drawn proportionally to exp(-H) by progressive (reservoir)
@@ -132,7 +132,32 @@ def _build_mhmc_kernel(thr: float):
         pq, pp, pg = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         plogp, penergy = torch.empty_like(logp0), torch.empty_like(logp0)
         acc_rate = torch.empty_like(logp0)
-        if L > 0 and is_diag:
+        general = tuple(kick_c) != (0.5, 0.5) or tuple(drift_c) != (1.0,)
+        if L > 0 and is_diag and general:
+            # any palindromic integrator [b1, a1, ..., b1] (integrators.py:104-150): the fused step kernel
+            # closes a step with (eps b1) g and opens the next with (eps b1) g, (eps a1) M^{-1} p; the
+            # stages in between are plain kick + drift launches, each followed by the callable
+            b1, a1 = float(kick_c[0]), float(drift_c[0])
+            q, p = torch.empty_like(q0), torch.empty_like(q0)
+            _lib.call("bjx_leapfrog_diag_coef", stream, N, D, 1, b1, 0.0, a1, eps, _lib.ptr(eps_pc), imm_p,
+                      imm_s, q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)
+            for i in range(L):
+                logp, g = eval_logdensity(vg, q)
+                for si in range(1, len(drift_c)):
+                    _lib.call("bjx_leapfrog_diag_coef", stream, N, D, 1, float(kick_c[si]), 0.0,
+                              float(drift_c[si]), eps, _lib.ptr(eps_pc), imm_p, imm_s, q.data_ptr(),
+                              p.data_ptr(), g.data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)
+                    logp, g = eval_logdensity(vg, q)
+                _lib.call("bjx_mhmc_step_diag_coef", stream, k0, k1, off, fold, N, D, i,
+                          1 if i + 1 < L else 0, eps, _lib.ptr(eps_pc), imm_p, imm_s, thr,
+                          logp0.data_ptr(), ke0.data_ptr(), q.data_ptr(), p.data_ptr(), g.data_ptr(),
+                          logp.data_ptr(), weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(),
+                          ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
+                          plogp.data_ptr(), penergy.data_ptr(), None, b1, a1)
+        elif L > 0 and general:
+            raise NotImplementedError("mhmc with a dense metric is implemented for velocity_verlet "
+                                      "(mclachlan / yoshida / omelyan: diagonal metrics)")
+        elif L > 0 and is_diag:
             q, p = torch.empty_like(q0), torch.empty_like(q0)
             _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
                       q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr())
@@ -286,8 +311,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
         raise ValueError("use_graph must be True, False or 'auto'")
     thr = float(divergence_threshold)
     if build_proposal is multinomial_hmc_proposal:
-        integrators.check_supported(integrator)
-        return _build_mhmc_kernel(thr)
+        integrators.check_supported(integrator, allow_general=True)
+        return _build_mhmc_kernel(thr, integrator.coefficients[0::2], integrator.coefficients[1::2])
     if build_proposal not in (None, hmc_proposal):
         raise NotImplementedError(
             "build_proposal must be hmc_proposal (default) or multinomial_hmc_proposal")

@@ -2,10 +2,13 @@
 
 An integrator is its coefficient list ``[b1, a1, b2, a2, ..., b1]`` (momentum / position updates
 alternating, ``generalized_two_stage_integrator`` 62-152).  ``velocity_verlet`` is implemented for
-every sampler and metric; ``mclachlan``, ``yoshida`` and ``omelyan`` are implemented for
-``blackjax_amd.hmc`` with a diagonal metric through the general-coefficient kernels
-(``bjx_leapfrog_diag_coef`` / ``bjx_hmc_finish_diag_coef``); the non-Euclidean integrators of the
-reference (isokinetic, maruyama, implicit midpoint) are out of scope.
+every sampler and metric; ``mclachlan``, ``yoshida`` and ``omelyan`` (any palindromic list) run through
+the general-coefficient kernels: ``hmc`` and ``dynamic_hmc`` with diagonal and dense metrics
+(``bjx_leapfrog_*_coef`` / ``bjx_hmc_finish_*_coef``), ``mhmc`` / ``dmhmc`` with diagonal metrics
+(``bjx_mhmc_step_diag_coef``), and ``nuts`` -- lockstep ``step`` and ``run`` -- with diagonal and dense
+metrics (``bjx_nuts_t.int_kick / int_drift`` + ``bjx_nuts_mid``); the free-running NUTS tick kernels
+and ``window_adaptation(..., free_running=True)`` integrate with velocity Verlet.  The non-Euclidean
+integrators of the reference (isokinetic, maruyama, implicit midpoint) are out of scope.
 """
 from __future__ import annotations
 
@@ -46,5 +49,5 @@ def check_supported(integrator, allow_general: bool = False):
         return
     raise NotImplementedError(
         "this sampler/metric implements the velocity_verlet integrator only; got %r "
-        "(mclachlan / yoshida / omelyan are available for blackjax_amd.hmc with a diagonal metric)"
+        "(mclachlan / yoshida / omelyan: see blackjax_amd.integrators for where they are available)"
         % (integrator,))

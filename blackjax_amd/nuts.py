@@ -91,8 +91,10 @@ class _GraphWorkspace:
     MAX_CHUNK = 16
     MIN_BUCKET = 256
 
-    def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device, owner=None):
+    def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device, owner=None,
+                 kick_c=(0.5, 0.5), drift_c=(1.0,)):
         self.N, self.D, self.max_depth, self.vg = N, D, max_depth, vg
+        self.kick_c, self.drift_c = tuple(kick_c), tuple(drift_c)  # palindromic integrator [b1, a1, ..., b1]
         self.owner = owner  # the user's callable: held so that id(owner) in the workspace key stays unique
         f32 = dict(dtype=torch.float32, device=device)
         self.bufs = {n: torch.empty((N, D), **f32) for n in _BUFS}
@@ -113,7 +115,8 @@ class _GraphWorkspace:
             divergence_threshold=thr, key0=0, key1=0, chain_offset=0, step_fold=-1,
             q0=0, g0=0, p0=0, ckpt_r=self.ck_r.data_ptr(), ckpt_rs=self.ck_rs.data_ptr(),
             fs=self.fs.data_ptr(), is_=self.is_.data_ptr(),
-            **{n: b.data_ptr() for n, b in self.bufs.items()}, **self.dense["fields"])
+            **{n: b.data_ptr() for n, b in self.bufs.items()}, **self.dense["fields"],
+            int_kick=self.kick_c[0], int_drift=self.drift_c[0])
         self.graphs: dict = {}
 
     def bucket(self, n_rows: int) -> int:
@@ -130,6 +133,10 @@ class _GraphWorkspace:
                   self.ctl.data_ptr(), qf.data_ptr())
         for i in range(k):
             logp_f, gf = eval_logdensity(self.vg, qf)
+            for si in range(1, len(self.drift_c)):  # stages 2 .. K of a multi-stage integrator
+                _lib.call("bjx_nuts_mid", stream, dref, n_cap, self.idx.data_ptr(), self.ctl.data_ptr(),
+                          qf.data_ptr(), gf.data_ptr(), self.kick_c[si], self.drift_c[si])
+                logp_f, gf = eval_logdensity(self.vg, qf)
             # post(i) fused with pre(i+1) inside the chunk (row order is fixed within a chunk)
             _lib.call("bjx_nuts_post_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
                       self.ctl.data_ptr(), qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr(),
@@ -175,7 +182,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     batch); compaction itself happens on the device every chunk."""
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
-    integrators.check_supported(integrator)
+    # any palindromic coefficient list [b1, a1, ..., b1] (integrators.py:62-152, nuts.py:150-158): a leaf
+    # is then pre (kick b1, drift a1) -> callable -> [mid (kick b_i, drift a_i) -> callable] ... -> post
+    integrators.check_supported(integrator, allow_general=True)
+    kick_c = integrator.coefficients[0::2]
+    drift_c = integrator.coefficients[1::2]
     thr = float(divergence_threshold)
     I = _lib.NUTS_I
     workspaces: dict = {}
@@ -226,7 +237,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             divergence_threshold=thr, key0=k0, key1=k1, chain_offset=int(chain_offset),
             step_fold=fold, q0=q0.data_ptr(), g0=g0.data_ptr(), p0=p0.data_ptr(),
             ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(), is_=is_.data_ptr(),
-            **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"])
+            **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"],
+            int_kick=kick_c[0], int_drift=drift_c[0])
         dref = ctypes.byref(desc)
         _lib.call("bjx_nuts_init", stream, dref, logp0.data_ptr(), ke0.data_ptr())
 
@@ -260,6 +272,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     _lib.call("bjx_nuts_pre", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
                               qf.data_ptr())
                 logp_f, gf = eval_logdensity(vg, qf)
+                for si in range(1, len(drift_c)):  # stages 2 .. K of a multi-stage integrator
+                    _lib.call("bjx_nuts_mid", stream, dref, n_step, _lib.ptr(idx_step), None, qf.data_ptr(),
+                              gf.data_ptr(), kick_c[si], drift_c[si])
+                    logp_f, gf = eval_logdensity(vg, qf)
                 # fuse the next leaf's opening half into post unless rows are re-compacted before it
                 nxt = s + 1
                 fuse = nxt < n_leaves and not (recompact_every and nxt % recompact_every == 0)
@@ -279,7 +295,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         ws = workspaces.get(wkey)
         if ws is None:
             ws = workspaces[wkey] = _GraphWorkspace(N, D, max_depth, vg, tuple(metric.imm.shape),
-                                                    metric.kind, thr, q0.device, owner=logdensity_fn)
+                                                    metric.kind, thr, q0.device, owner=logdensity_fn,
+                                                    kick_c=kick_c, drift_c=drift_c)
         if eps_pc is None:
             ws.eps.fill_(eps)
         else:
@@ -759,6 +776,38 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     return HMCState(q, logp, g), positions, info
 
 
+def _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions):
+    """``run`` through ``num_steps`` lockstep steps (same keys, same draws as ``run_free``)."""
+    from . import random as bjx_random
+
+    T = int(num_steps)
+    N, D = state.position.shape
+    dev = state.position.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    info = NUTSRunInfo(torch.empty((T, N), **f32), torch.empty((T, N), **f32), torch.empty((T, N), **f32),
+                       torch.empty((T, N), **i32), torch.empty((T, N), **i32),
+                       torch.empty((T, N), dtype=torch.bool, device=dev),
+                       torch.empty((T, N), dtype=torch.bool, device=dev), None)
+    positions = torch.empty((T, N, D), **f32) if store_positions else None
+    if key_layout not in ("step_major", "chain_major"):
+        raise ValueError("key_layout must be 'step_major' or 'chain_major'")
+    keys = bjx_random.split(rng_key, T) if key_layout == "step_major" else None
+    for t in range(T):
+        k = keys[t] if keys is not None else bjx_random.ChainMajorKey(rng_key, t)
+        state, inf = step_fn(k, state)
+        if positions is not None:
+            positions[t] = state.position
+        info.logdensity[t] = state.logdensity
+        info.acceptance_rate[t] = inf.acceptance_rate
+        info.energy[t] = inf.energy
+        info.num_integration_steps[t] = inf.num_integration_steps
+        info.num_trajectory_expansions[t] = inf.num_trajectory_expansions
+        info.is_divergent[t] = inf.is_divergent
+        info.is_turning[t] = inf.is_turning
+    return state, positions, info
+
+
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
@@ -768,7 +817,8 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
     ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
     should be driven on this engine."""
-    integrators.check_supported(integrator)
+    integrators.check_supported(integrator, allow_general=True)
+    general = integrator is not integrators.velocity_verlet
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
                           use_graph=use_graph, graph_sync_every=graph_sync_every)
 
@@ -782,6 +832,11 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
 
     def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
                store_positions: bool = True):
+        if general:
+            # the free-running tick kernels integrate with velocity Verlet; with another integrator the
+            # same num_steps transitions run as lockstep steps (identical draws, chain c at transition t
+            # uses the same key either way)
+            return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,

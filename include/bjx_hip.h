@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BJX_ABI_VERSION 1
+#define BJX_ABI_VERSION 2 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3) */
 
 const char* bjx_last_error(void);
 int bjx_abi_version(void);
@@ -193,6 +193,21 @@ int bjx_mhmc_step_diag_masked(void* stream, uint32_t key0, uint32_t key1, int64_
                               float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
                               float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
                               float* prop_energy, const int32_t* n_steps);
+/* bjx_mhmc_step_diag[_masked] for any palindromic integrator [b_1, a_1, ..., b_1] (blackjax.mhmc /
+ * dmhmc with integrator=mclachlan / yoshida / omelyan; blackjax/mcmc/integrators.py:335-369 through
+ * trajectory.py:170-232): the closing kick of the step and -- with do_next -- the opening kick of the
+ * next one are (eps * kick_coef) g, the drift that follows is (eps * drift_coef) imm p; the stages in
+ * between (b_2, a_2 ...) are bjx_leapfrog_diag_coef launches with n_kicks = 1.  n_steps may be NULL
+ * (every chain advances).  (0.5, 1.0) reproduces bjx_mhmc_step_diag bit for bit. */
+int bjx_mhmc_step_diag_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                            int64_t step_fold, int64_t N, int64_t D, int64_t step, int do_next, float eps,
+                            const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                            float divergence_threshold, const float* logp0, const float* ke0, float* q,
+                            float* p, const float* g, const float* logp_new, float* weight,
+                            float* sum_log_p_accept, uint8_t* any_divergent, uint8_t* ever_accepted,
+                            float* prop_q, float* prop_p, float* prop_g, float* prop_logp,
+                            float* prop_energy, const int32_t* n_steps, float kick_coef, float drift_coef);
+
 int bjx_mhmc_finish_masked(void* stream, int64_t N, int64_t D, const int32_t* n_steps, const float* q0,
                            const float* p0, const float* g0, const float* logp0, const float* ke0,
                            const uint8_t* ever_accepted, const float* sum_log_p_accept, float* prop_q,

@@ -97,6 +97,13 @@ typedef struct {
   const float* v0;            /* (N, D) M^{-1} p0 from the momentum draw */
   float *Lv, *Rv;             /* (N, D) velocities of the leftmost / rightmost state */
   float* ckpt_v;              /* (N, max_depth, D) velocities of the checkpointed momenta */
+  /* Palindromic integrator [b_1, a_1, b_2, ..., b_1] (blackjax/mcmc/nuts.py:150-158 `integrator=`,
+   * integrators.py:104-150, 335-369): int_kick = b_1 (the opening AND the closing kick of a leaf are
+   * (dir * eps * b_1) g), int_drift = a_1 (the first drift, (dir * eps * a_1) M^{-1} p).  The stages
+   * in between (b_2, a_2, ...), each followed by a callable evaluation, are bjx_nuts_mid launches.
+   * Both 0: velocity Verlet (0.5, 1.0).  Lockstep entry points only (bjx_nuts_pre / post / _ctl);
+   * the free-running tick kernels integrate with velocity Verlet. */
+  float int_kick, int_drift;
 } bjx_nuts_t;
 
 /* Start of a transition: trajectory = (z0, z0, momentum_sum = p0, num_states = 0), proposal =
@@ -121,6 +128,15 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
 int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
                   const int32_t* idx, float* qf, const float* logp_f, const float* gf,
                   int32_t fuse_next);
+
+/* Intermediate stage of a multi-stage integrator on the trajectory end that is integrating, for the
+ * rows idx[0..n_rows) whose subtree is still running: p += (dir * eps * kick) gf[b] ;
+ * q += (dir * eps * drift) M^{-1} p ; the new position also goes to qf[b] for the next callable
+ * evaluation (integrators.py:128-146, stages 2 .. K of generalized_two_stage_integrator).  gf = the
+ * callable's gradient at the previous stage's position.  ctl != NULL: replayable form, row count from
+ * ctl[2] (at most n_rows) as in bjx_nuts_pre_ctl.  Diagonal and dense metrics. */
+int bjx_nuts_mid(void* stream, const bjx_nuts_t* nuts, int64_t n_rows, const int32_t* idx,
+                 const int64_t* ctl, float* qf, const float* gf, float kick, float drift);
 
 /* HIP-graph-replayable variants of bjx_nuts_pre / bjx_nuts_post.  The per-launch parameters that
  * change between replays are read from a DEVICE control block

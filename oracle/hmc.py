@@ -173,9 +173,20 @@ def chain_keys(rng_key, n, chain_offset=0):
     return prng.split(rng_key, n, offset=chain_offset)
 
 
+def integrator_step(z: IntegratorState, step_size, logdensity_fn, metric: Metric, coefficients=None):
+    """One step of the palindromic integrator ``coefficients`` ([b1, a1, ..., b1], integrators.py:104-150;
+    ``None`` = velocity Verlet)."""
+    if coefficients is None:
+        return velocity_verlet(z, step_size, logdensity_fn, metric)
+    from . import integrators as _oi  # (imports this module)
+
+    return _oi.one_step(z, step_size, logdensity_fn, metric, coefficients)
+
+
 def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
            num_integration_steps: int, divergence_threshold: float = 1000.0,
-           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None):
+           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None,
+           coefficients=None):
     """hmc.py:279-312 with hmc_proposal.generate 153-176, batched over chains.  ``metric``: a
     prepared ``Metric`` (e.g. ``default_metric(..., dense_accum="f32chain")``) instead of
     classifying ``inverse_mass_matrix`` again."""
@@ -190,7 +201,7 @@ def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matr
     z0 = IntegratorState(state.position, p0, state.logdensity, state.logdensity_grad)
     z = z0
     for _ in range(num_integration_steps):  # trajectory.py:155-165
-        z = velocity_verlet(z, step_size, logdensity_fn, metric)
+        z = integrator_step(z, step_size, logdensity_fn, metric, coefficients)
     end = IntegratorState(z.position, (f32(-1.0) * z.momentum).astype(f32), z.logdensity,
                           z.logdensity_grad)  # flip_momentum hmc.py:95-112
     e0 = hmc_energy(metric, z0)
@@ -211,7 +222,8 @@ def kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matr
 
 def mhmc_kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass_matrix,
                 num_integration_steps: int, divergence_threshold: float = 1000.0,
-                chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None):
+                chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, metric=None,
+                coefficients=None):
     """blackjax.mhmc: hmc.build_kernel(build_proposal=multinomial_hmc_proposal)
     (hmc.py:181-248, 279-312) with static_progressive_integration (trajectory.py:170-232) and
     progressive_uniform_sampling (proposal.py:118-143), batched over chains."""
@@ -235,7 +247,7 @@ def mhmc_kernel(rng_key, state: HMCState, logdensity_fn, step_size, inverse_mass
     z = z0
     for i in range(L):  # trajectory.py:214-225
         step_keys = prng.fold_in(key_integrator, np.uint32(i))
-        z = velocity_verlet(z, step_size, logdensity_fn, metric)
+        z = integrator_step(z, step_size, logdensity_fn, metric, coefficients)
         e_new = hmc_energy(metric, z)
         w = safe_energy_diff(e0, e_new)  # proposal.py:91-95
         s_new = np.minimum(w, f32(0.0))
@@ -279,7 +291,8 @@ class DynamicHMCState(NamedTuple):  # blackjax/mcmc/dynamic_hmc.py:39-52
 
 def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size,
                        inverse_mass_matrix, divergence_threshold: float = 1000.0,
-                       chain_offset: int = 0, steps_bounds=(1, 10), metric=None, multinomial=False):
+                       chain_offset: int = 0, steps_bounds=(1, 10), metric=None, multinomial=False,
+                       coefficients=None):
     """blackjax/mcmc/dynamic_hmc.py:65-126 with the default callables
     ``integration_steps_fn = lambda key: randint(key, (), 1, 10)`` and
     ``next_random_arg_fn = lambda key: split(key)[1]``: every chain draws its own trajectory
@@ -303,7 +316,7 @@ def dynamic_hmc_kernel(rng_key, state: DynamicHMCState, logdensity_fn, step_size
         # multinomial=True: blackjax.dmhmc (build_proposal=multinomial_hmc_proposal, __init__.py:155-163)
         outs.append((mhmc_kernel if multinomial else kernel)(
             None, st_i, logdensity_fn, eps[i], imm_i, int(n_steps[i]), divergence_threshold,
-            chain_keys_override=keys[i:i + 1], metric=met_i))
+            chain_keys_override=keys[i:i + 1], metric=met_i, coefficients=coefficients))
     cat = lambda f: np.concatenate([f(o) for o in outs], 0)
     new = DynamicHMCState(cat(lambda o: o[0].position), cat(lambda o: o[0].logdensity),
                           cat(lambda o: o[0].logdensity_grad),

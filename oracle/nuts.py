@@ -72,7 +72,7 @@ def _chain_metric(metric: ohmc.Metric, i: int) -> ohmc.Metric:
     return ohmc.Metric(metric.inverse_mass_matrix[i:i + 1], metric.mass_matrix_sqrt[i:i + 1], False)
 
 
-def _one_chain(key_integrator, z0, logdensity_fn, eps, metric, max_depth, thr):
+def _one_chain(key_integrator, z0, logdensity_fn, eps, metric, max_depth, thr, coefficients=None):
     """iterative_nuts_proposal.propose for ONE chain (arrays of shape (1, D) / (1,))."""
     D = z0.position.shape[1]
     ckpt_r = np.zeros((max_depth, 1, D), f32)  # termination.py:46-54
@@ -93,7 +93,7 @@ def _one_chain(key_integrator, z0, logdensity_fn, eps, metric, max_depth, thr):
         s, sdiv, sturn = 0, False, False
         sub_first = None
         while s < 2 ** depth and not sturn and not sdiv:
-            znew = ohmc.velocity_verlet(zr, deps, logdensity_fn, metric)
+            znew = ohmc.integrator_step(zr, deps, logdensity_fn, metric, coefficients)  # trajectory.py:323
             e_new = ohmc.hmc_energy(metric, znew)
             w = ohmc.safe_energy_diff(H0, e_new)[0]  # proposal.py:91-95
             new_slpa = np.minimum(w, f32(0.0))
@@ -149,8 +149,9 @@ def _one_chain(key_integrator, z0, logdensity_fn, eps, metric, max_depth, thr):
 
 def kernel(rng_key, state: ohmc.HMCState, logdensity_fn, step_size, inverse_mass_matrix,
            max_num_doublings: int = 10, divergence_threshold: float = 1000.0,
-           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False):
-    """nuts.py:113-145, batched by looping over chains."""
+           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, coefficients=None):
+    """nuts.py:113-145, batched by looping over chains.  ``coefficients``: palindromic integrator
+    (nuts.py:150-158 ``integrator=``; None = velocity Verlet)."""
     N, D = state.position.shape
     metric = ohmc.default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
     keys = (ohmc.chain_keys(rng_key, N, chain_offset) if chain_keys_override is None
@@ -163,7 +164,7 @@ def kernel(rng_key, state: ohmc.HMCState, logdensity_fn, step_size, inverse_mass
         z0 = ohmc.IntegratorState(state.position[i:i + 1], p0[i:i + 1], state.logdensity[i:i + 1],
                                   state.logdensity_grad[i:i + 1])
         outs.append(_one_chain(kk[i, 1], z0, logdensity_fn, eps[i], _chain_metric(metric, i),
-                               max_num_doublings, divergence_threshold))
+                               max_num_doublings, divergence_threshold, coefficients))
 
     def cat_state(idx):
         return ohmc.IntegratorState(*[np.concatenate([getattr(o[idx], f) for o in outs], 0)
