@@ -215,7 +215,15 @@ SIGNATURES.update({
     "bjx_ghmc_finish": [c_void_p, c_int64, c_int64, c_float, _f32p, _f32p, c_int64, c_float]
                        + [_f32p] * 12 + [c_int64, c_int64] + [_f32p] * 6 + [_u8p, _u8p, _f32p, _f32p],
 })
-INT64_FUNCTIONS = {"bjx_pool_workspace_bytes": [c_int64, c_int64]}
+SIGNATURES.update({
+    "bjx_meads_fold_moments": [c_void_p, c_int64, c_int64, c_int64, _f32p, c_void_p, _f32p, _f32p, _f32p],
+    "bjx_meads_fold_build": [c_void_p, c_int64, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                             c_void_p],
+    "bjx_meads_fold_params": [c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_float, c_int64, _f32p,
+                              c_void_p, _f32p, c_void_p] + [_f32p] * 8,
+})
+INT64_FUNCTIONS = {"bjx_pool_workspace_bytes": [c_int64, c_int64],
+                   "bjx_meads_workspace_bytes": [c_int64, c_int64]}
 
 _lib = None
 

@@ -588,6 +588,72 @@ __global__ __launch_bounds__(256) void k_chees_weights_short(int64_t N, int64_t 
   }
 }
 
+// The same criterion for rows of exactly NI KiB-pieces per lane (D == 256 NI, 16-byte aligned), one
+// wave per row: EVERY load of the row -- 3 NI nontemporal 16-byte row pieces and the shared vectors --
+// is issued before the first use (the general kernel's run-time loop keeps 2 in flight), and the rows
+// stream past the caches (round 3; tools/membw2.hip read-only ceilings).  Per-lane accumulation order
+// and the butterfly are those of k_chees_criterion<4, W, 64>: identical results.
+template <int NI, bool WHITEN, bool NT>
+__global__ __launch_bounds__(256) void k_chees_criterion_rows(
+    int64_t N, int64_t D, const float* __restrict__ qp, const float* __restrict__ pp,
+    const float* __restrict__ qi, const float* __restrict__ pm, const float* __restrict__ im,
+    const float* __restrict__ imm, const float* __restrict__ isq, float* __restrict__ crit) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int64_t base = n * D;
+  F4 a[NI], b[NI], m[NI], ma[NI], mb[NI], sg[NI], sq[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int64_t c = ((int64_t)lane + 64 * k) * 4;
+    a[k] = ld4_t<NT>(qp + base + c);
+    b[k] = ld4_t<NT>(qi + base + c);
+    m[k] = ld4_t<NT>(pp + base + c);
+    ma[k] = ld4(pm + c);
+    mb[k] = ld4(im + c);
+    if constexpr (WHITEN) {
+      sg[k] = ld4(imm + c);
+      sq[k] = ld4(isq + c);
+    }
+  }
+  double s_pp = 0.0, s_ii = 0.0, s_pv = 0.0;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const float av[4] = {a[k].x, a[k].y, a[k].z, a[k].w}, bv[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+    const float mv[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
+    const float mav[4] = {ma[k].x, ma[k].y, ma[k].z, ma[k].w}, mbv[4] = {mb[k].x, mb[k].y, mb[k].z, mb[k].w};
+    float sgv[4] = {1, 1, 1, 1}, sqv[4] = {1, 1, 1, 1};
+    if constexpr (WHITEN) {
+      sgv[0] = sg[k].x; sgv[1] = sg[k].y; sgv[2] = sg[k].z; sgv[3] = sg[k].w;
+      sqv[0] = sq[k].x; sqv[1] = sq[k].y; sqv[2] = sq[k].z; sqv[3] = sq[k].w;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float pc = av[v] - mav[v];
+      float ic = bv[v] - mbv[v];
+      float vel = mv[v];
+      if constexpr (WHITEN) {
+        pc = pc * sqv[v];
+        ic = ic * sqv[v];
+        vel = (vel * sgv[v]) * sqv[v];
+      }
+      s_pp += (double)pc * (double)pc;
+      s_ii += (double)ic * (double)ic;
+      s_pv += (double)pc * (double)vel;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s_pp += __shfl_xor(s_pp, o, 64);
+    s_ii += __shfl_xor(s_ii, o, 64);
+    s_pv += __shfl_xor(s_pv, o, 64);
+  }
+  if (lane == 0) {
+    const float diff = (float)s_pp - (float)s_ii;
+    crit[n] = diff * (float)s_pv;
+  }
+}
+
 // G lanes per chain row (64 = one wave per row; 4 ... 32 for rows of at most 16 ... 128 floats, VEC == 4)
 template <int VEC, bool WHITEN, int G = 64>
 __global__ __launch_bounds__(256) void k_chees_criterion(
@@ -831,9 +897,13 @@ int bjx_chees_weights_colstats(hipStream_t stream, int64_t N, int64_t D, const f
   int64_t nslab = g.nslab;
   static const bool by_rows = !(getenv("BJX_CHEES_WCOL") && atoi(getenv("BJX_CHEES_WCOL")) != 0);
   if (vec4 && D > 128 && D <= 1024 && N < ((int64_t)1 << 31) && by_rows) {  // whole rows per wave
-    // nontemporal loads make THIS pass faster (tools/membw2.hip) but leave nothing of q' / q in the
-    // Infinity Cache for the criterion kernel that follows: BJX_CHEES_NT=1 to try (default plain)
-    static const bool chees_nt = getenv("BJX_CHEES_NT") && atoi(getenv("BJX_CHEES_NT")) != 0;
+    // nontemporal loads when the two arrays exceed the Infinity Cache (tools/membw2.hip: 6.45 -> 6.79
+    // TB/s for this mix).  They leave nothing of q' / q in the cache for the criterion kernel that
+    // follows, which therefore streams with nontemporal loads too (k_chees_criterion_rows); with plain
+    // loads here that kernel found half of its input cached (round 3 A/B: 136 + 128 us plain / plain,
+    // 96 + 163 us nontemporal / plain).  BJX_CHEES_NT=0 / 1 forces plain / nontemporal in both.
+    static const int chees_nt_mode = [] { const char* e = getenv("BJX_CHEES_NT"); return e ? atoi(e) : -1; }();
+    const bool chees_nt = chees_nt_mode < 0 ? N * D * 8 > ((int64_t)256 << 20) : chees_nt_mode != 0;
     const int u = D > 512 ? 2 : 4;
     int64_t wgs = (N + 4 * u - 1) / (4 * u);
     nslab = wgs < 512 ? wgs : 512;  // <= the slab count bjx_pool_workspace_bytes sizes the partials for
@@ -902,7 +972,27 @@ int bjx_chees_criterion(hipStream_t stream, int64_t N, int64_t D, const float* q
     else if (D <= 64) BJX_LAUNCH_CRIT_G(W, 16); \
     else BJX_LAUNCH_CRIT_G(W, 32);            \
   } while (0)
-  if (v4 && D > 0 && D <= 128) {  // short rows: several chains per wave
+  // rows of 1 / 2 / 4 KiB-pieces per lane: every load up front; nontemporal when the three arrays
+  // exceed the Infinity Cache (BJX_CHEES_NT=0 / 1 forces plain / nontemporal)
+  static const int nt_mode = [] { const char* e = getenv("BJX_CHEES_NT"); return e ? atoi(e) : -1; }();
+  static const bool rows_ok = !(getenv("BJX_CHEES_CRIT_ROWS") && atoi(getenv("BJX_CHEES_CRIT_ROWS")) == 0);
+  if (rows_ok && v4 && (D == 256 || D == 512 || D == 1024)) {
+    const bool nt = nt_mode < 0 ? N * D * 12 > ((int64_t)256 << 20) : nt_mode != 0;
+    const dim3 rg((unsigned)((N + 3) / 4));
+#define BJX_CRIT_ROWS(NI_, W_, T_)                                                                      \
+  hipLaunchKernelGGL((k_chees_criterion_rows<NI_, W_, T_>), rg, dim3(256), 0, stream, N, D, q_prop, p_prop, \
+                     q_init, proposals_mean, initials_mean, imm, inv_sqrt_imm, crit)
+#define BJX_CRIT_ROWS_W(NI_)                                                          \
+  do {                                                                                \
+    if (imm != nullptr) { if (nt) BJX_CRIT_ROWS(NI_, true, true); else BJX_CRIT_ROWS(NI_, true, false); } \
+    else { if (nt) BJX_CRIT_ROWS(NI_, false, true); else BJX_CRIT_ROWS(NI_, false, false); }               \
+  } while (0)
+    if (D == 256) BJX_CRIT_ROWS_W(1);
+    else if (D == 512) BJX_CRIT_ROWS_W(2);
+    else BJX_CRIT_ROWS_W(4);
+#undef BJX_CRIT_ROWS_W
+#undef BJX_CRIT_ROWS
+  } else if (v4 && D > 0 && D <= 128) {  // short rows: several chains per wave
     if (imm != nullptr) BJX_LAUNCH_CRIT_SHORT(true); else BJX_LAUNCH_CRIT_SHORT(false);
   } else if (imm != nullptr) {
     if (v4) BJX_LAUNCH_CRIT(4, true); else BJX_LAUNCH_CRIT(1, true);

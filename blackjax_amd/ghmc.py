@@ -57,6 +57,14 @@ def init(position: torch.Tensor, logdensity_fn: Callable, rng_key, *, chain_offs
     return GHMCState(position, momentum, logp, grad, sl)
 
 
+class SquaredScale:
+    """Marker: a per-chain ``(N, D)`` inverse mass matrix that is ALREADY the squared inverse scale (what
+    ``bjx_meads_fold_params`` writes for the MEADS folds) -- passed through to the kernels as is."""
+
+    def __init__(self, imm: torch.Tensor):
+        self.imm = imm
+
+
 def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, device):
     """ghmc.py:67-86, legacy branch: the per-dimension inverse scale, squared.  -> (imm tensor,
     row stride 0 | D).  Accepted: a scalar, ``(D,)``, or one scale vector per chain ``(N, D)`` (what
@@ -64,6 +72,10 @@ def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, dev
     argument as a dense inverse mass matrix (blackjax#950): a ``(D, D)`` tensor that is not ``(N, D)``
     is therefore refused rather than guessed at."""
     x = momentum_inverse_scale
+    if isinstance(x, SquaredScale):
+        if tuple(x.imm.shape) != (n_chains, dim) or x.imm.dtype != torch.float32 or not x.imm.is_contiguous():
+            raise ValueError(f"SquaredScale needs a contiguous float32 ({n_chains}, {dim}) tensor")
+        return x.imm, dim
     if isinstance(x, metrics.Metric) or callable(x):
         raise NotImplementedError("ghmc: only the per-dimension inverse-scale form of the momentum metric is built")
     tagged = False  # per-chain scales must be DECLARED when the array is square (N == D)

@@ -13,7 +13,10 @@ original behavior"); the MEADS-LRD low-rank extension raises.  Single process: t
 reshuffle span the whole ensemble, so under chain sharding this warm-up would exchange entire states
 every ``K`` steps -- run it on one GPU.
 
-Where the work is: the GHMC transition is HIP (include/bjx_ghmc.h).  The fold statistics are three
+Where the work is: the GHMC transition is HIP (include/bjx_ghmc.h), and since round 3 so are the
+per-step fold statistics (``bjx_meads_fold_moments / _build / _params``; the two Gram matrices per fold
+are plain batched fp32 library GEMMs).  ``base()`` (the single-batch API of the reference, used for the
+initial state only) keeps the torch formulation below.  Round-2 note: the fold statistics were three
 reductions over chains per fold and step -- a standard deviation and two Gram-matrix traces for
 ``maximum_eigenvalue`` (790-817; ``||X X^T||_F = ||X^T X||_F``, so the smaller Gram matrix is formed)
 -- done here as library GEMMs / reductions in fp64 (``torch``: rocBLAS), rounded once, which is this
@@ -26,6 +29,7 @@ from typing import Callable, NamedTuple, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import ghmc as _ghmc
 from . import metrics as _metrics
 from . import random as bjx_random
@@ -144,26 +148,61 @@ def meads_adaptation(logdensity_fn: Callable, num_chains: int, num_folds: int = 
     kernel = _ghmc.build_kernel()
     adapt_init, _ = base(K, step_size_multiplier, damping_slowdown)
 
+    work: dict = {}  # per (device, D): buffers reused from step to step (nothing the history keeps)
+
+    def _buffers(N, D, dev):
+        key = (dev.index, N, D)
+        w = work.get(key)
+        if w is None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            m = min(n, D)  # |X X^T|_F = |X^T X|_F: the smaller Gram matrix
+            w = work[key] = dict(
+                ws=torch.empty(int(_lib.load().bjx_meads_workspace_bytes(K, D)), dtype=torch.uint8, device=dev),
+                mean=torch.empty((K, D), **f32), mw=torch.empty((K, D), **f32),
+                A=torch.empty((N, D), **f32), B=torch.empty((N, D), **f32),
+                rowsq=torch.empty((2, N), dtype=torch.float64, device=dev),
+                gram=torch.empty((2, K, m, m), **f32),
+                eps_pc=torch.empty(N, **f32), alpha_pc=torch.empty(N, **f32), delta_pc=torch.empty(N, **f32),
+                imm_pc=torch.empty((N, D), **f32))
+        return w
+
     def one_step(rng_key, states: _ghmc.GHMCState, ad: MEADSAdaptationState):
+        """One adaptation step (meads_adaptation.py:560-700).  The fold statistics are four C-ABI calls
+        and two batched library GEMMs, all stream-ordered (include/bjx_ghmc.h "MEADS fold statistics");
+        nothing is read back to the host."""
         t = ad.current_iteration
         N, D = states.position.shape
+        dev = states.position.device
         shuffle_key = bjx_random.split(rng_key, 1, offset=N)[0]  # keys[num_chains] of split(key, N + 1)
-        pos = states.position.reshape(K, n, D)
-        grads = states.logdensity_grad.reshape(K, n, D)
-        scales = _fold_std(pos)  # (K, D)
-        eps_own = _step_size(grads * scales[:, None, :], step_size_multiplier)  # (K,)
-        eps_rolled = torch.roll(eps_own, 1)  # fold k takes the step size of fold k - 1
-        scales_rolled = torch.roll(scales, 1, dims=0)
-        whitened = pos / scales[:, None, :]  # each fold by its OWN scale (618-622)
-        centred = whitened - whitened.double().mean(dim=1, keepdim=True).float()
-        alphas, deltas = _damping(maximum_eigenvalue(centred), eps_rolled, t, damping_slowdown)
+        w = _buffers(N, D, dev)
+        stream = _lib.current_stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        pos, grads = states.position.contiguous(), states.logdensity_grad.contiguous()
+        scales = torch.empty((K, D), **f32)  # per-fold std of the positions (kept by nothing: rolled below)
+        _lib.call("bjx_meads_fold_moments", stream, K, n, D, pos.data_ptr(), w["ws"].data_ptr(),
+                  w["mean"].data_ptr(), scales.data_ptr(), w["mw"].data_ptr())
+        _lib.call("bjx_meads_fold_build", stream, K, n, D, pos.data_ptr(), grads.data_ptr(), scales.data_ptr(),
+                  w["mw"].data_ptr(), w["A"].data_ptr(), w["B"].data_ptr(), w["rowsq"].data_ptr())
+        for mtx, name in enumerate(("A", "B")):  # Gram matrices: plain batched fp32 GEMMs
+            x3 = w[name].view(K, n, D)
+            if n <= D:
+                torch.bmm(x3, x3.transpose(1, 2), out=w["gram"][mtx])
+            else:
+                torch.bmm(x3.transpose(1, 2), x3, out=w["gram"][mtx])
+        eps_rolled, alphas, deltas = torch.empty(K, **f32), torch.empty(K, **f32), torch.empty(K, **f32)
+        scales_rolled = torch.empty((K, D), **f32)
+        m = w["gram"].shape[-1]
+        _lib.call("bjx_meads_fold_params", stream, K, n, D, int(t), float(step_size_multiplier),
+                  float(damping_slowdown), m * m, w["gram"].data_ptr(), w["rowsq"].data_ptr(), scales.data_ptr(),
+                  w["ws"].data_ptr(), eps_rolled.data_ptr(), alphas.data_ptr(), deltas.data_ptr(),
+                  scales_rolled.data_ptr(), w["eps_pc"].data_ptr(), w["alpha_pc"].data_ptr(),
+                  w["delta_pc"].data_ptr(), w["imm_pc"].data_ptr())
         skip = (t % K * n, (t % K + 1) * n) if K > 1 else None  # Algorithm 3 line 4
-        new_states, info = kernel(rng_key, states, logdensity_fn, eps_rolled.repeat_interleave(n),
-                                  _metrics.PerChainDiag(scales_rolled.repeat_interleave(n, dim=0)), alphas.repeat_interleave(n),
-                                  deltas.repeat_interleave(n), skip_chains=skip)
+        new_states, info = kernel(rng_key, states, logdensity_fn, w["eps_pc"], _ghmc.SquaredScale(w["imm_pc"]),
+                                  w["alpha_pc"], w["delta_pc"], skip_chains=skip)
         new_ad = MEADSAdaptationState(t + 1, eps_rolled, scales_rolled, alphas, deltas)
         if K > 1 and (t + 1) % K == 0:
-            perm = torch.as_tensor(_permutation(shuffle_key, N), device=states.position.device)
+            perm = torch.as_tensor(_permutation(shuffle_key, N), device=dev)
             new_states = _ghmc.GHMCState(*[a.index_select(0, perm) for a in new_states])
         return new_states, new_ad, info
 

@@ -15,6 +15,7 @@
 #ifndef BJX_GHMC_H
 #define BJX_GHMC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -71,6 +72,34 @@ int bjx_ghmc_finish(void* stream, int64_t N, int64_t D, float eps, const float* 
                     int64_t skip_begin, int64_t skip_end, float* q_out, float* p_out, float* logp_out,
                     float* g_out, float* slice_out, float* acceptance_rate_out, uint8_t* is_accepted_out,
                     uint8_t* is_divergent_out, float* energy_out, float* p_end_out);
+
+/* ---- MEADS fold statistics (blackjax/adaptation/meads_adaptation.py:560-640, 790-817) ------------
+ * The per-step quantities of the K-fold cross-chain adaptation as stream-ordered launches (no host
+ * synchronisation): chains are fold-major, fold k = rows [k n, (k + 1) n) of the (N = K n, D) arrays.
+ *   bjx_meads_fold_moments : mean_out, sd_out (K, D) = per-fold mean / population std of x (jnp.std,
+ *                            ddof 0; fp64 sums of x - x_first), whitened_mean_out (K, D) = fp64 mean of
+ *                            x / sd_k (the centring of fold_damping, 604-606)
+ *   bjx_meads_fold_build   : A = g * sd_k (583-588), B = x / sd_k - whitened_mean_k (616-622), both
+ *                            (N, D) fp32; rowsq (2, N) doubles = row sums of squares of A and B
+ *   -- the caller forms the Gram matrices of A_k and B_k with a plain library GEMM (fp32), laid out
+ *      gram[mtx][k] with gram_elems floats each (D x D or n x n, |X X^T|_F = |X^T X|_F) --
+ *   bjx_meads_fold_params  : maximum_eigenvalue of every matrix (812-817: (sum S^2 - sum diag S^2) /
+ *                            (n (n - 1)) / (sum diag S / n)), step size min(multiplier / sqrt(lambda_A), 1)
+ *                            of fold k - 1 -> fold k, gamma = max(1 / sqrt(lambda_B), slowdown /
+ *                            ((t + 1) eps)), alpha = 1 - exp(-2 eps gamma) (fp64 exp, rounded once),
+ *                            delta = alpha / 2, sigma_fold (K, D) = sd rolled by one fold; per-chain
+ *                            broadcasts eps_pc / alpha_pc / delta_pc (N,) and imm_pc (N, D) = the SQUARED
+ *                            rolled scale (ghmc.py:67-86: inverse mass = scale ** 2).
+ * workspace: bjx_meads_workspace_bytes(K, D) bytes, shared by the three calls of one step. */
+size_t bjx_meads_workspace_bytes(int64_t K, int64_t D);
+int bjx_meads_fold_moments(void* stream, int64_t K, int64_t n, int64_t D, const float* x, void* workspace,
+                           float* mean_out, float* sd_out, float* whitened_mean_out);
+int bjx_meads_fold_build(void* stream, int64_t K, int64_t n, int64_t D, const float* x, const float* g,
+                         const float* sd, const float* whitened_mean, float* A, float* B, double* rowsq);
+int bjx_meads_fold_params(void* stream, int64_t K, int64_t n, int64_t D, int64_t t, float step_size_multiplier,
+                          float damping_slowdown, int64_t gram_elems, const float* gram, const double* rowsq,
+                          const float* sd, void* workspace, float* eps_fold, float* alpha_fold, float* delta_fold,
+                          float* sigma_fold, float* eps_pc, float* alpha_pc, float* delta_pc, float* imm_pc);
 
 #ifdef __cplusplus
 }

@@ -64,12 +64,15 @@ def test_dense_f32chain_vs_f64_at_c5_shape_ten_transitions():
     Linv = torch.linalg.solve_triangular(Lt, torch.eye(D, dtype=torch.float64), upper=False)
     factor_t = Linv.T.contiguous().numpy().astype(f32)  # L^{-T}
     n_diff = int((factor_t != m32.mass_matrix_sqrt).sum())
-    ulp = np.abs(factor_t.view(np.int32).astype(np.int64) - m32.mass_matrix_sqrt.view(np.int32).astype(np.int64))
+    # entries that are structurally zero come out as 1e-17-size noise in both builds: compare on the
+    # scale of the matrix, not in ulps of each entry
+    err = np.abs(factor_t.astype(np.float64) - m32.mass_matrix_sqrt.astype(np.float64)).max()
+    scale = float(np.abs(m32.mass_matrix_sqrt).max())
     mt = ohmc.default_metric(cov, dense_accum="f32chain", mass_matrix_sqrt=factor_t)
     qt, at, rt = _run(mt, cov, fn, q0, idx, keys)
     flips_f = int((at != a32).sum())
     dq_f = float(np.abs(qt - q32).max())
-    print(f"NumPy vs torch factor: {n_diff} of {D * D} entries differ (max {int(ulp.max())} ulp); "
-          f"accept flips {flips_f}, max|dq| {dq_f:.3e}")
-    assert ulp.max() <= 1
+    print(f"NumPy vs torch factor: {n_diff} of {D * D} entries differ (max |diff| {err:.2e} on a scale of "
+          f"{scale:.2f}); accept flips {flips_f}, max|dq| {dq_f:.3e}")
+    assert err <= 2.0 ** -23 * scale
     assert flips_f == 0 and dq_f <= 2e-4
