@@ -89,7 +89,7 @@ class _GraphWorkspace:
     """Static device buffers + captured chunk graphs for the ``use_graph`` driver."""
 
     MAX_CHUNK = 16
-    MIN_BUCKET = 256
+    MIN_BUCKET = int(__import__("os").environ.get("BJX_NUTS_MIN_BUCKET", "256"))  # smallest recorded batch
 
     def __init__(self, N, D, max_depth, vg, imm_shape, kind, thr, device, owner=None,
                  kick_c=(0.5, 0.5), drift_c=(1.0,)):
@@ -322,7 +322,10 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             idx_doubling = ws.idx[:n_doubling].clone()
             n_cap = ws.bucket(n_doubling)
             n_leaves = 1 << depth
-            k = min(chunk_max, n_leaves)
+            # deep doublings are a handful of chains and pure launch latency (two dependent kernels per
+            # leaf): longer recorded chunks there -- fewer compaction / control-block launches and
+            # replay boundaries per leaf
+            k = min(chunk_max if depth < 7 else 4 * chunk_max, n_leaves)
             for j, s_base in enumerate(range(0, n_leaves, k)):
                 if j > 0:
                     # drop the chains whose subtree has stopped -- on the device, no host sync
@@ -722,10 +725,31 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         groups.append(_Group(rows_g, n_g, qf[s0:s0 + n_g]))
     tail_ctx = None
     ticks_left = max_ticks
+    # Lagged completion polling for the tail: the finished-chain count is copied to pinned host memory
+    # behind every batch of replays and the host reads the copy of the PREVIOUS batch, so the next
+    # batch is always queued before the host waits -- the GPU never idles on the round trip of a
+    # blocking .item() (0.5-1 us per tick of a 12 us tick).  The count only grows: a stale (smaller)
+    # value is safe for the tier choice, and the run ends at most one batch late (ticks over finished
+    # chains do nothing).
+    pinned = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    poll_ev = [torch.cuda.Event() for _ in range(2)]
+    poll = {"slot": 0, "primed": False, "last": 0}
+
+    def poll_done():
+        k = poll["slot"]
+        pinned[k].copy_(n_done, non_blocking=True)
+        poll_ev[k].record()
+        poll["slot"] = k ^ 1
+        if poll["primed"]:
+            poll_ev[k ^ 1].synchronize()
+            poll["last"] = int(pinned[k ^ 1][0])
+        poll["primed"] = True
+        return poll["last"]
+
     while ticks_left > 0:
         if tail_ctx is not None:
             ticks_left -= tail_ctx.advance()
-            n_active = N - int(n_done.item())  # one host sync per chunk
+            n_active = N - poll_done()
             if n_active == 0:
                 break
             if tail_ctx.wants_compaction(n_active):
@@ -751,6 +775,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             if can_record and n_active <= graph_max_rows:
                 tail_ctx = _Tail(n_active, sync_every, 4)
                 tail_ctx.enter(groups, n_active)
+                poll["last"] = N - n_active
                 groups = []
                 continue
             rows_all = torch.empty(n_rows, **i32)

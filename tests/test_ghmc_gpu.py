@@ -146,7 +146,10 @@ def test_meads_run_matches_oracle(dev, N, K, D, steps):
         np.testing.assert_allclose(t2n(info.state.position[t]), hist[t][0].position, rtol=1e-4, atol=1e-5)
     for name in ("step_size", "alpha", "delta", "momentum_inverse_scale"):
         np.testing.assert_allclose(t2n(par_g[name]), par_o[name], rtol=2e-5)
-    np.testing.assert_allclose(t2n(st_g.slice), st_o.slice, rtol=1e-4, atol=1e-6)
+    # the slice variable integrates every energy error of the run (slice *= exp(-dE)); since round 3 the
+    # engine forms the fold Gram matrices in fp32 (as the reference does) where the oracle uses fp64, which
+    # moves the per-fold step sizes by ~1e-6 relative and a slice close to zero by a few 1e-6 absolute
+    np.testing.assert_allclose(t2n(st_g.slice), st_o.slice, rtol=1e-4, atol=2e-5)
     assert par_g["momentum_inverse_scale"].shape == (D,) and par_g["step_size"].ndim == 0
     if K > 1:  # Algorithm 3 line 4 on the engine: fold t mod K does not move at step t
         n = N // K
