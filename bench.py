@@ -481,6 +481,8 @@ def bench_c2(args, ctx):
         roofline = {"bound": "hbm", "kernel": "k_leapfrog_diag_flat<2>" if flat else "k_leapfrog_diag<4,2>",
                     "achieved": la["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": la["achieved"] / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                    "nontemporal": bool(flat and stream_m is not None and os.environ.get("BJX_LF_NT", "") != "0"
+                                        and 12.0 * D * la["chains_per_launch"] > (256 << 20)),
                     "mode": ("hbm streaming: all chains per launch" if stream_m else
                              "Infinity-Cache blocks (no streaming measurement in this run)"),
                     **{k: la[k] for k in ("algorithmic_bytes_per_launch", "chains_per_launch",

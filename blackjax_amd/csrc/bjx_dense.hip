@@ -50,6 +50,15 @@ struct GemmArgs {
   // otherwise its momentum and position are copied through untouched.  NULL = every row advances.
   const int32_t* n_steps = nullptr;
   int32_t step_idx = 0;
+  // Staggered start (k_dense_gemm_tn8): workgroups of the second half of the grid (stagger_mode 0) or
+  // of every other group of eight (mode 1) wait this many ticks of the 100 MHz wall clock before
+  // they load anything.  When a launch is exactly one round of resident workgroups (C5: 512 tiles on
+  // 256 CUs x 2) all of them reach the drift epilogue -- 67 MB of q / q' -- at the same moment and the
+  // matrix pipes idle while HBM drains it; a late workgroup lets its CU neighbour run at the full pipe
+  // rate first, so the two finish their main loops a stagger apart and one epilogue hides under the
+  // other's MFMAs.  0 = off.  Pure scheduling: results are unchanged.
+  int32_t stagger_ticks = 0;
+  int32_t stagger_mode = 0;
 };
 
 __device__ __forceinline__ bool gemm_row_active(const GemmArgs& a, int64_t row) {
@@ -525,6 +534,13 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   const int64_t row0 = row_blk * BM, col0 = col_blk * BN, D = a.D;
   float* As0 = smem;
   float* Bs0 = smem + 2 * BM * LDK;
+  if (a.stagger_ticks > 0) {
+    const bool late = a.stagger_mode == 0 ? (blockIdx.x >= gridDim.x / 2) : (((blockIdx.x >> 3) & 1) != 0);
+    if (late) {
+      const uint64_t t0 = wall_clock64();
+      while (wall_clock64() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+  }
 
   // staging: thread -> (tile row tid/4, 4 consecutive k starting at (tid&3)*4) of A and of Bt
   const int s_row = tid >> 2, s_k = (tid & 3) * 4;
@@ -804,6 +820,15 @@ struct PcArgs {
   float kick_a = 0.5f, kick_b = 0.5f, drift = 1.0f;  // as in GemmArgs
   const int32_t* n_steps = nullptr;
   int32_t step_idx = 0;
+  // Staggered start (k_dense_gemm_tn8): workgroups of the second half of the grid (stagger_mode 0) or
+  // of every other group of eight (mode 1) wait this many ticks of the 100 MHz wall clock before
+  // they load anything.  When a launch is exactly one round of resident workgroups (C5: 512 tiles on
+  // 256 CUs x 2) all of them reach the drift epilogue -- 67 MB of q / q' -- at the same moment and the
+  // matrix pipes idle while HBM drains it; a late workgroup lets its CU neighbour run at the full pipe
+  // rate first, so the two finish their main loops a stagger apart and one epilogue hides under the
+  // other's MFMAs.  0 = off.  Pure scheduling: results are unchanged.
+  int32_t stagger_ticks = 0;
+  int32_t stagger_mode = 0;
 };
 
 template <int EPI>
@@ -914,12 +939,20 @@ int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
   return bjx_check_launch("bjx_dense_pc gemv");
 }
 
-int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga) {
+int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
+  GemmArgs ga = ga_in;
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B, ga.C, ga.Q_in, ga.Q_out);
   const bool full = (ga.M % BM == 0) && (ga.D % BN == 0);
   if (ga.b_symmetric && aligned && full) {
     static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
+    // staggered start: only when the launch is at most one round of resident workgroups (2 per CU)
+    static const double stagger_us = [] { const char* e = getenv("BJX_DENSE_STAGGER_US"); return e ? atof(e) : 0.0; }();
+    static const int stagger_mode = [] { const char* e = getenv("BJX_DENSE_STAGGER_MODE"); return e ? atoi(e) : 0; }();
+    if (stagger_us > 0.0 && grid.x <= 512u && grid.x >= 2u) {
+      ga.stagger_ticks = (int32_t)(stagger_us * 100.0);
+      ga.stagger_mode = stagger_mode;
+    }
 #define BJX_LAUNCH_TN(E, K)                                                                   \
   do {                                                                                        \
     if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga); \

@@ -19,7 +19,10 @@ KERNEL = "k_leapfrog_diag<4,2>"  # replaced by the bench line's roofline.kernel 
 
 
 def is_kernel(name):
-    return KERNEL.replace(" ", "") + "(" in name.replace(" ", "")
+    # "k_leapfrog_diag_flat<2>" also matches its nontemporal / plain instantiations <2, true> / <2, false>
+    key = KERNEL.replace(" ", "")
+    key = key[:-1] if key.endswith(">") else key
+    return key in name.replace(" ", "")
 
 
 def counter_avg(sub, counter):
@@ -36,7 +39,7 @@ def counter_avg(sub, counter):
 def main():
     global KERNEL
     tag = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+    rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
     out_dir = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(out_dir, exist_ok=True)
     bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
