@@ -59,6 +59,7 @@ SIGNATURES = {
     "bjx_mhmc_finish_masked": [c_void_p, c_int64, c_int64, c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _u8p,
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_dense_matmul": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
+    "bjx_dense_apply_imm": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
     "bjx_hmc_momentum_dense": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_leapfrog_dense": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, _f32p, _f32p,
@@ -122,7 +123,7 @@ class NutsDesc(ctypes.Structure):
         ("fs", c_void_p), ("is_", c_void_p),
         ("Mdense", c_void_p), ("Mdense_stride", c_int64), ("v0", c_void_p),
         ("Lv", c_void_p), ("Rv", c_void_p), ("ckpt_v", c_void_p),
-        ("int_kick", c_float), ("int_drift", c_float),
+        ("int_kick", c_float), ("int_drift", c_float), ("v_pre", c_void_p),
     ]
 
 
@@ -140,6 +141,8 @@ SIGNATURES.update({
     "bjx_nuts_pre": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p],
     "bjx_nuts_post": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, _f32p,
                       _f32p, _f32p, ctypes.c_int32],
+    "bjx_nuts_dense_kick": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_int64, c_void_p, c_void_p,
+                            _f32p, c_float, _f32p],
     "bjx_nuts_mid": [c_void_p, POINTER(NutsDesc), c_int64, c_void_p, c_void_p, _f32p, _f32p, c_float, c_float],
     "bjx_nuts_pre_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p],
     "bjx_nuts_post_ctl": [c_void_p, POINTER(NutsDesc), ctypes.c_int32, c_int64, c_void_p, c_void_p, _f32p,

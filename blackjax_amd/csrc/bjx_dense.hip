@@ -990,6 +990,14 @@ int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const f
   return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
 }
 
+int bjx_dense_apply_imm(void* stream, int64_t N, int64_t D, const float* P, const float* imm, float* V) {
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(N >= 0 && D > 0 && P && imm && V, "bjx_dense_apply_imm: bad arguments");
+  GemmArgs ga{N, D, P, nullptr, 0, 0.0f, nullptr, nullptr, imm, V, nullptr, nullptr};
+  ga.b_symmetric = true;  // B is an inverse mass matrix: the TN kernel reads it as stored
+  return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
+}
+
 int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                            int64_t step_fold, int64_t N, int64_t D, const float* mass_sqrt_t,
                            const float* imm, float* z_work, float* v_work, float* p_out,

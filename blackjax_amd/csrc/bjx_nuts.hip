@@ -168,13 +168,23 @@ __device__ __forceinline__ double matvec_t_lane(const float* __restrict__ M, int
 // gsrc = gradient at the current end state.
 template <int VEC, bool DENSE>
 __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, int dir, float deps,
-                                               float h, const float* gsrc, float* qo) {
+                                               float h, const float* gsrc, float* qo,
+                                               const float* vpre = nullptr) {
   const int64_t base = c * nt.D;
   float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
   float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
   if constexpr (DENSE) {
     static_assert(VEC == 1, "dense metric uses the 4-byte mapping");
     const int lane = threadIdx.x & 63;
+    if (vpre) {  // velocity of the kicked momentum from the caller's GEMM (bjx_nuts_t.v_pre)
+      for (int64_t i = lane; i < nt.D; i += 64) {
+        const float qn = fmaf(deps, vpre[i], fq[i]);
+        fq[i] = qn;
+        qo[i] = qn;
+        fp[i] = fmaf(h, gsrc[i], fp[i]);
+      }
+      return;
+    }
     const float* M = nt.Mdense + c * nt.Mdense_stride;
     for (int64_t ic = 0; ic < nt.D; ic += 64) {
       const int64_t i = ic + lane;
@@ -316,7 +326,8 @@ k_nuts_pre(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
     const float deps = (float)dir * chain_eps(nt, c);  // direction * step_size (trajectory.py:323)
     const float h = deps * int_kick(nt);               // step_size * coef (integrators.py:236)
     const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
-    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), h, fg, qf + b * nt.D);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), h, fg, qf + b * nt.D,
+                               nt.v_pre ? nt.v_pre + b * nt.D : nullptr);
   }
 }
 
@@ -334,7 +345,41 @@ k_nuts_mid(bjx_nuts_t nt, int64_t n_rows_arg, const int32_t* __restrict__ idx,
     if (!IS(BJX_NUTS_I_ACTIVE, c) || !IS(BJX_NUTS_I_SUB_ACTIVE, c)) continue;
     const int dir = IS(BJX_NUTS_I_DIR, c);
     const float deps = (float)dir * chain_eps(nt, c);
-    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * drift, deps * kick, gf + b * nt.D, qf + b * nt.D);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * drift, deps * kick, gf + b * nt.D, qf + b * nt.D,
+                               nt.v_pre ? nt.v_pre + b * nt.D : nullptr);
+  }
+}
+
+// Compact rows of kicked momenta for the GEMM that applies a shared dense inverse mass matrix
+// (bjx_nuts_t.v_pre): pc[b] = p_end + (dir eps kick) g, g = gf[b] or the end's stored gradient.
+__global__ void __launch_bounds__(kBlock)
+k_nuts_dense_kick(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
+                  const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl,
+                  const float* __restrict__ gf, float kick, float* __restrict__ pc) {
+  const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = wave_row0(); b < cx.n_rows; b += wave_row_stride()) {
+    const int64_t c = idx ? (int64_t)idx[b] : b;
+    float* out = pc + b * nt.D;
+    bool act = IS(BJX_NUTS_I_ACTIVE, c) != 0;
+    int dir = 1;
+    if (act) {
+      if (cx.s == 0 && !gf) {
+        dir = nuts_begin_doubling(nt, cx, c, cx.depth);
+      } else {
+        act = IS(BJX_NUTS_I_SUB_ACTIVE, c) != 0;
+        dir = IS(BJX_NUTS_I_DIR, c);
+      }
+    }
+    if (!act) {
+      for (int64_t j = lane; j < nt.D; j += 64) out[j] = 0.0f;
+      continue;
+    }
+    const float h = ((float)dir * chain_eps(nt, c)) * kick;
+    const int64_t base = c * nt.D;
+    const float* p = (dir > 0 ? nt.Rp : nt.Lp) + base;
+    const float* g = gf ? gf + b * nt.D : (dir > 0 ? nt.Rg : nt.Lg) + base;
+    for (int64_t j = lane; j < nt.D; j += 64) out[j] = fmaf(h, g[j], p[j]);
   }
 }
 
@@ -531,14 +576,24 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
   if constexpr (DENSE) {
     const float* M = nt.Mdense + c * nt.Mdense_stride;
     fv = (dir > 0 ? nt.Rv : nt.Lv) + base;
-    for (int64_t ic = 0; ic < nt.D; ic += 64) {
-      const int64_t i = ic + lane;
-      const double av = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gn[j], fp[j]); });
-      if (i < nt.D) {
+    if (nt.v_pre) {  // velocity of the closing-kicked momentum from the caller's GEMM
+      const float* vp = nt.v_pre + b * nt.D;
+      for (int64_t i = lane; i < nt.D; i += 64) {
         const float p = fmaf(h, gn[i], fp[i]);
-        const float v = (float)av;
+        const float v = vp[i];
         fv[i] = v;
         acc += (double)v * (double)p;
+      }
+    } else {
+      for (int64_t ic = 0; ic < nt.D; ic += 64) {
+        const int64_t i = ic + lane;
+        const double av = matvec_t_lane(M, nt.D, i, [&](int64_t j) { return fmaf(h, gn[j], fp[j]); });
+        if (i < nt.D) {
+          const float p = fmaf(h, gn[i], fp[i]);
+          const float v = (float)av;
+          fv[i] = v;
+          acc += (double)v * (double)p;
+        }
       }
     }
     for (int64_t j = lane; j < nt.D; j += 64) {
@@ -1865,6 +1920,19 @@ int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_
   BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
                   *nuts, 0, s_off, n_cap, idx, ctl, qf);
   return bjx_check_launch("bjx_nuts_pre_ctl");
+}
+
+int bjx_nuts_dense_kick(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                        const int32_t* idx, const int64_t* ctl, const float* gf, float kick, float* pc_out) {
+  if (check_nuts(nuts, "bjx_nuts_dense_kick")) return 1;
+  if (nuts->N == 0) return 0;  // an empty ensemble has no buffers to check
+  BJX_CHECK_ARG(nuts->Mdense && nuts->Mdense_stride == 0, "bjx_nuts_dense_kick: needs a shared dense metric");
+  BJX_CHECK_ARG(depth >= 0 && s >= 0 && n_rows >= 0 && n_rows <= nuts->N && pc_out && (idx || !ctl),
+                "bjx_nuts_dense_kick: bad arguments");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(k_nuts_dense_kick, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, ctl, gf, kick, pc_out);
+  return bjx_check_launch("bjx_nuts_dense_kick");
 }
 
 int bjx_nuts_mid(void* stream, const bjx_nuts_t* nuts, int64_t n_rows, const int32_t* idx,

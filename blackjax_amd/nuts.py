@@ -107,7 +107,11 @@ class _GraphWorkspace:
         self.idx = torch.arange(N, dtype=torch.int32, device=device)
         self.qf = torch.zeros((N, D), **f32)
         self.ctl = torch.zeros(8, dtype=torch.int64, device=device)
-        self.dense = _dense_fields(kind, self.imm, N, D, max_depth, device)
+        self.gemm = kind == "dense_gemm"
+        self.dense = _dense_fields("dense" if self.gemm else kind, self.imm, N, D, max_depth, device)
+        if self.gemm:
+            self.pc, self.vc = torch.empty((N, D), **f32), torch.empty((N, D), **f32)
+            self.dense["fields"]["v_pre"] = self.vc.data_ptr()
         self.desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=self.imm.data_ptr(),
             imm_stride=D if (kind == "diag" and len(imm_shape) == 2) else 0,
@@ -129,18 +133,37 @@ class _GraphWorkspace:
         stream = _lib.current_stream()
         dref = ctypes.byref(self.desc)
         qf = self.qf[:n_cap]
-        _lib.call("bjx_nuts_pre_ctl", stream, dref, 0, n_cap, self.idx.data_ptr(),
-                  self.ctl.data_ptr(), qf.data_ptr())
+        idx_p, ctl_p = self.idx.data_ptr(), self.ctl.data_ptr()
+
+        def velocities(s_off, gf_t, kick):
+            """GEMM mode (shared dense metric): vc[b] = M^{-1} (p_end + (dir eps kick) g), one GEMM over
+            the chunk's row capacity"""
+            _lib.call("bjx_nuts_dense_kick", stream, dref, 0, s_off, n_cap, idx_p, ctl_p, _lib.ptr(gf_t), kick,
+                      self.pc.data_ptr())
+            _lib.call("bjx_dense_apply_imm", stream, n_cap, self.D, self.pc.data_ptr(), self.imm.data_ptr(),
+                      self.vc.data_ptr())
+
+        if self.gemm:
+            velocities(0, None, self.kick_c[0])
+        _lib.call("bjx_nuts_pre_ctl", stream, dref, 0, n_cap, idx_p, ctl_p, qf.data_ptr())
         for i in range(k):
             logp_f, gf = eval_logdensity(self.vg, qf)
             for si in range(1, len(self.drift_c)):  # stages 2 .. K of a multi-stage integrator
-                _lib.call("bjx_nuts_mid", stream, dref, n_cap, self.idx.data_ptr(), self.ctl.data_ptr(),
+                if self.gemm:
+                    velocities(i, gf, self.kick_c[si])
+                _lib.call("bjx_nuts_mid", stream, dref, n_cap, idx_p, ctl_p,
                           qf.data_ptr(), gf.data_ptr(), self.kick_c[si], self.drift_c[si])
                 logp_f, gf = eval_logdensity(self.vg, qf)
-            # post(i) fused with pre(i+1) inside the chunk (row order is fixed within a chunk)
-            _lib.call("bjx_nuts_post_ctl", stream, dref, i, n_cap, self.idx.data_ptr(),
-                      self.ctl.data_ptr(), qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr(),
-                      1 if i < k - 1 else 0)
+            if self.gemm:
+                velocities(i, gf, self.kick_c[-1])
+            # post(i) fused with pre(i+1) inside the chunk (row order is fixed within a chunk); in GEMM
+            # mode the next leaf's opening velocity is its own product, so pre is a launch of its own
+            fuse = 0 if self.gemm else (1 if i < k - 1 else 0)
+            _lib.call("bjx_nuts_post_ctl", stream, dref, i, n_cap, idx_p, ctl_p, qf.data_ptr(),
+                      logp_f.data_ptr(), gf.data_ptr(), fuse)
+            if self.gemm and i < k - 1:
+                velocities(i + 1, None, self.kick_c[0])
+                _lib.call("bjx_nuts_pre_ctl", stream, dref, i + 1, n_cap, idx_p, ctl_p, qf.data_ptr())
         return logp_f, gf
 
     def chunk_graph(self, k, n_cap):
@@ -169,7 +192,8 @@ class _GraphWorkspace:
 
 
 def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: int = 1000, *,
-                 recompact_every: int = 16, use_graph="auto", graph_sync_every: int = 4):
+                 recompact_every: int = 16, use_graph="auto", graph_sync_every: int = 4,
+                 dense_gemm="auto"):
     """blackjax/mcmc/nuts.py:77-147.  ``use_graph``: ``True`` = the HIP-graph driver, ``False`` =
     plain launches (three per leaf from Python: host-bound once a leaf is a few microseconds of GPU
     work), ``"auto"`` (default) = the graph driver for callables DECLARED recordable
@@ -182,6 +206,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     batch); compaction itself happens on the device every chunk."""
     if use_graph not in (True, False, "auto"):
         raise ValueError("use_graph must be True, False or 'auto'")
+    if dense_gemm not in (True, False, "auto"):
+        raise ValueError("dense_gemm must be True, False or 'auto'")
     # any palindromic coefficient list [b1, a1, ..., b1] (integrators.py:62-152, nuts.py:150-158): a leaf
     # is then pre (kick b1, drift a1) -> callable -> [mid (kick b_i, drift a_i) -> callable] ... -> post
     integrators.check_supported(integrator, allow_general=True)
@@ -209,12 +235,20 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             _lib.call("bjx_hmc_momentum_diag", stream, k0, k1, int(chain_offset), fold, N, D,
                       metric.imm.data_ptr(), metric.imm_stride, p0.data_ptr(), ke0.data_ptr())
         else:
-            # dense metric (shared or per chain): fp64-accumulated matrix-vector kernels throughout,
-            # so tree decisions stay bit-compatible with the oracle
+            # dense metric.  One matrix per chain, and small shared-matrix problems: fp64-accumulated
+            # matrix-vector kernels throughout (bit-compatible with the oracle's "f64" mode).  A SHARED
+            # matrix on a batch large enough to fill GEMM tiles (dense_gemm="auto": >= 512 chains and
+            # D >= 128; True forces it): every product v = M^{-1} p of a leaf is ONE fp32 MFMA GEMM
+            # over the live rows (bjx_nuts_dense_kick -> bjx_dense_apply_imm -> kernels reading
+            # bjx_nuts_t.v_pre) instead of D^2 words per chain -- the oracle's "f32chain" mode
+            # (metrics.py:263-304 with util.py:58-61).
             from . import dense
 
+            gemm = metric.kind == "dense" and (dense_gemm is True or (dense_gemm == "auto" and N >= 512
+                                                                      and D >= 128))
             v0 = dense.momentum(stream, metric, k0, k1, int(chain_offset), fold, N, D, p0, ke0,
-                                force_pc=True)
+                                force_pc=not gemm)
+            metric = metric._replace(kind="dense_gemm") if gemm else metric
         return q0, logp0, g0, N, D, k0, k1, fold, vg, metric, eps, eps_pc, stream, p0, ke0, v0
 
     def kernel_eager(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
@@ -228,9 +262,14 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         ck_rs = torch.empty_like(ck_r)
         fs = torch.empty((_lib.NUTS_NF, N), dtype=torch.float32, device=dev)
         is_ = torch.empty((_lib.NUTS_NI, N), dtype=torch.int32, device=dev)
-        dense_f = _dense_fields(metric.kind, metric.imm, N, D, max_depth, dev)
+        gemm = metric.kind == "dense_gemm"
+        dense_f = _dense_fields("dense" if gemm else metric.kind, metric.imm, N, D, max_depth, dev)
         if v0 is not None:
             dense_f["fields"]["v0"] = v0.data_ptr()
+        pc = vc = None
+        if gemm:  # compact kicked momenta and their velocities (one GEMM per product)
+            pc, vc = torch.empty_like(q0), torch.empty_like(q0)
+            dense_f["fields"]["v_pre"] = vc.data_ptr()
         desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=metric.imm.data_ptr(),
             imm_stride=metric.imm_stride, eps_per_chain=_lib.ptr(eps_pc), eps=eps,
@@ -268,17 +307,31 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     if n_new < n_step:
                         idx_step, n_step = new_idx.contiguous(), n_new
                         qf = qf[:n_step]
+                def velocities(gf_t, kick):
+                    """GEMM mode: vc[b] = M^{-1} (p_end + (dir eps kick) g) for the live rows"""
+                    _lib.call("bjx_nuts_dense_kick", stream, dref, depth, s, n_step, _lib.ptr(idx_step), None,
+                              _lib.ptr(gf_t), kick, pc.data_ptr())
+                    _lib.call("bjx_dense_apply_imm", stream, n_step, D, pc.data_ptr(), metric.imm.data_ptr(),
+                              vc.data_ptr())
+
                 if need_pre:
+                    if gemm:
+                        velocities(None, kick_c[0])
                     _lib.call("bjx_nuts_pre", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
                               qf.data_ptr())
                 logp_f, gf = eval_logdensity(vg, qf)
                 for si in range(1, len(drift_c)):  # stages 2 .. K of a multi-stage integrator
+                    if gemm:
+                        velocities(gf, kick_c[si])
                     _lib.call("bjx_nuts_mid", stream, dref, n_step, _lib.ptr(idx_step), None, qf.data_ptr(),
                               gf.data_ptr(), kick_c[si], drift_c[si])
                     logp_f, gf = eval_logdensity(vg, qf)
+                if gemm:
+                    velocities(gf, kick_c[-1])
                 # fuse the next leaf's opening half into post unless rows are re-compacted before it
+                # (never in GEMM mode: the next leaf's opening velocity is its own product)
                 nxt = s + 1
-                fuse = nxt < n_leaves and not (recompact_every and nxt % recompact_every == 0)
+                fuse = (not gemm) and nxt < n_leaves and not (recompact_every and nxt % recompact_every == 0)
                 _lib.call("bjx_nuts_post", stream, dref, depth, s, n_step, _lib.ptr(idx_step),
                           qf.data_ptr(), logp_f.data_ptr(), gf.data_ptr(), 1 if fuse else 0)
                 need_pre = not fuse
@@ -837,7 +890,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
                      recompact_every: int = 16, use_graph="auto",
-                     graph_sync_every: int = 4, run_use_graph="auto") -> SamplingAlgorithm:
+                     graph_sync_every: int = 4, run_use_graph="auto", dense_gemm="auto") -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
     ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
@@ -845,7 +898,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     integrators.check_supported(integrator, allow_general=True)
     general = integrator is not integrators.velocity_verlet
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
-                          use_graph=use_graph, graph_sync_every=graph_sync_every)
+                          use_graph=use_graph, graph_sync_every=graph_sync_every, dense_gemm=dense_gemm)
 
     def init_fn(position, rng_key=None):
         del rng_key

@@ -221,6 +221,12 @@ int bjx_mhmc_finish_masked(void* stream, int64_t N, int64_t D, const int32_t* n_
  * C = A @ B with A (N, D), B (D, D): the building block, exported for parity tests. */
 int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C);
 
+/* V = P @ imm^T for N rows: v_i = imm p_i (linear_map(inverse_mass_matrix, p), util.py:58-61;
+ * metrics.py:263-304) on the fp32 MFMA GEMM, imm read as the reference stores it (row n = output n).
+ * Complete 128 x 128 tiles take the k-contiguous "TN" kernel.  Used by dense-metric NUTS, where the
+ * kick and the consumers of v are separate kernels (bjx_nuts.h, v_pre). */
+int bjx_dense_apply_imm(void* stream, int64_t N, int64_t D, const float* P, const float* imm, float* V);
+
 /* Momentum draw: z = normal(km, (D,)) ; p = L^{-T} z = z @ mass_sqrt_t with mass_sqrt_t = L^{-1}
  * (L = cholesky(imm, lower)) ; ke = 0.5 dot(imm @ p, p).  z_work, v_work: (N, D) scratch.
  * Replaces: blackjax/mcmc/hmc.py:299,302 ; metrics.py:260-261,263-270,711-715 ; util.py:58-61,89-91. */

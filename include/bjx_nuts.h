@@ -104,6 +104,15 @@ typedef struct {
    * Both 0: velocity Verlet (0.5, 1.0).  Lockstep entry points only (bjx_nuts_pre / post / _ctl);
    * the free-running tick kernels integrate with velocity Verlet. */
   float int_kick, int_drift;
+  /* Shared dense metric on the MFMA GEMM (Mdense != NULL, Mdense_stride == 0): v_pre != NULL is a
+   * compact (n_rows, D) array holding, for row b, the velocity M^{-1} p' of the kicked momentum the
+   * next kernel is about to form -- computed by the caller with bjx_nuts_dense_kick (p' rows) and
+   * bjx_dense_apply_imm (one GEMM for all live rows).  bjx_nuts_pre / _mid / _post (and their _ctl
+   * forms) then read their velocities from it instead of running one fp64 mat-vec per chain
+   * (D^2 words per chain and leapfrog).  The products are fp32 fmaf chains in the engine's stated k
+   * order, i.e. the oracle's "f32chain" mode.  post must then be called
+   * with fuse_next = 0 (the next leaf's opening velocity needs its own product).  NULL: as before. */
+  const float* v_pre;
 } bjx_nuts_t;
 
 /* Start of a transition: trajectory = (z0, z0, momentum_sum = p0, num_states = 0), proposal =
@@ -137,6 +146,16 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
  * ctl[2] (at most n_rows) as in bjx_nuts_pre_ctl.  Diagonal and dense metrics. */
 int bjx_nuts_mid(void* stream, const bjx_nuts_t* nuts, int64_t n_rows, const int32_t* idx,
                  const int64_t* ctl, float* qf, const float* gf, float kick, float drift);
+
+/* Shared dense metric on the GEMM: compact rows of KICKED momenta for the next product.  Row b gets
+ * p_end + (dir * eps * kick) g with p_end the momentum of the trajectory end that is integrating and
+ * g = gf[b] (the callable's latest gradient; closing kick or a stage kick) or, when gf == NULL, the
+ * end's own stored gradient (opening kick of leaf s; at s == 0 the direction of the doubling is drawn
+ * first, exactly as bjx_nuts_pre does -- that kernel re-derives the same values).  Rows whose chain
+ * is not integrating are zero-filled.  Nothing but pc_out is written.  ctl != NULL: replayable form
+ * (depth, leaf base and row count from the control block, s = ctl[1] + s_off). */
+int bjx_nuts_dense_kick(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s, int64_t n_rows,
+                        const int32_t* idx, const int64_t* ctl, const float* gf, float kick, float* pc_out);
 
 /* HIP-graph-replayable variants of bjx_nuts_pre / bjx_nuts_post.  The per-launch parameters that
  * change between replays are read from a DEVICE control block

@@ -149,11 +149,13 @@ def _one_chain(key_integrator, z0, logdensity_fn, eps, metric, max_depth, thr, c
 
 def kernel(rng_key, state: ohmc.HMCState, logdensity_fn, step_size, inverse_mass_matrix,
            max_num_doublings: int = 10, divergence_threshold: float = 1000.0,
-           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, coefficients=None):
+           chain_offset: int = 0, chain_keys_override=None, per_chain_diag=False, coefficients=None,
+           metric=None):
     """nuts.py:113-145, batched by looping over chains.  ``coefficients``: palindromic integrator
     (nuts.py:150-158 ``integrator=``; None = velocity Verlet)."""
     N, D = state.position.shape
-    metric = ohmc.default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
+    if metric is None:  # ``metric``: a prepared Metric, e.g. default_metric(..., dense_accum="f32chain")
+        metric = ohmc.default_metric(inverse_mass_matrix, n_chains=N, per_chain_diag=per_chain_diag)
     keys = (ohmc.chain_keys(rng_key, N, chain_offset) if chain_keys_override is None
             else chain_keys_override)
     kk = prng.split(keys, 2)  # nuts.py:133

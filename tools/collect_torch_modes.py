@@ -17,6 +17,21 @@ SRC = os.path.join(ROOT, "gpurun_out", "torch_modes")
 STEPS, WARMUP, L = 2, 1, 50  # the flags of pmc_torch_modes.sh; one priming + one unthrottled-issue transition on top
 
 
+def short(name):
+    """kernel name without return type / anonymous namespace / argument list, at most 90 characters"""
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth, out = 0, []
+    for ch in n:  # cut at the first "(" outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)[:90]
+
+
 def newest(pattern):
     found = glob.glob(pattern)
     return max(found, key=os.path.getmtime) if found else None
@@ -31,7 +46,7 @@ def counter_total(sub, counter):
         if r["Counter_Name"] == counter:
             v = float(r["Counter_Value"])
             tot += v
-            k = r["Kernel_Name"].split("(")[0][-70:]
+            k = short(r["Kernel_Name"])
             per[k] = per.get(k, 0.0) + v
     return tot, per
 
@@ -70,7 +85,7 @@ def summarise():
         ks = newest(os.path.join(SRC, f"kt_{mode}", "*", "*kernel_stats.csv"))
         if ks:
             rows = list(csv.DictReader(open(ks)))[:12]
-            entry["kernel_time_split"] = [{"kernel": r["Name"].split("(")[0][-90:], "calls": int(r["Calls"]),
+            entry["kernel_time_split"] = [{"kernel": short(r["Name"]), "calls": int(r["Calls"]),
                                            "avg_us": float(r["AverageNs"]) / 1e3, "percent": float(r["Percentage"])}
                                           for r in rows]
         out[mode] = entry
@@ -79,6 +94,9 @@ def summarise():
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--summarise-only":
+        if not glob.glob(os.path.join(SRC, "fetch_*", "*", "*counter_collection.csv")):
+            sys.exit("no raw counter tables under gpurun_out/torch_modes (they only exist on the GPU box, "
+                     "inside tools/pmc_torch_modes.sh): not overwriting summary.json")
         out = summarise()
         json.dump(out, open(os.path.join(SRC, "summary.json"), "w"), indent=1)
         for m, e in out.items():
