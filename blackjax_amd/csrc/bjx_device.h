@@ -117,52 +117,6 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
   return 1.41421354f * erfinv_f32(u);
 }
 
-// Four normals at once with the SAME per-element arithmetic as normal_from_bits, arranged for
-// instruction-level parallelism (round 3).  The one-at-a-time form puts a data-dependent branch
-// (the Ziv fallback of the fast log1p, the w >= 5 tail polynomial) inside every element, so the
-// compiler emits the elements of an unrolled loop strictly one after another: one dependent chain of
-// ~200 instructions per wave -- measured 2.4x off the issue bound (k_momentum_diag 392 us at
-// 65 536 x 1 024 against ~165 us of issue slots).  Here the four fast log1p evaluations and the four
-// Horner chains are straight-line code (the tail polynomial is chosen by per-coefficient selects,
-// sqrtf is evaluated for every element), and the rare slow path (2^-19 per element) is one
-// wave-level branch behind them.  Results are bit-identical to normal_from_bits.
-__device__ __forceinline__ void normal4_from_bits(const uint32_t bits[4], float z[4]) {
-  const float lo = -0.99999994f;
-  float x[4], t[4], w[4];
-  bool ok[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    x[e] = fmaxf(lo, fmaf(unit_float(bits[e]), 2.0f, lo));
-    t[e] = -(x[e] * x[e]);
-    ok[e] = bjx_neg_log1p_fast(t[e], &w[e]);
-  }
-  if (!(ok[0] && ok[1] && ok[2] && ok[3])) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (!ok[e]) w[e] = -(float)log1p((double)t[e]);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool lt = w[e] < 5.0f;
-    float sq = sqrtf(w[e]);
-    asm volatile("" : "+v"(sq));  // keep the square root unconditional: no branch between the chains
-    const float ws = lt ? w[e] - 2.5f : sq - 3.0f;
-    float p = lt ? 2.81022636e-08f : -0.000200214257f;
-    p = fmaf(p, ws, lt ? 3.43273939e-07f : 0.000100950558f);
-    p = fmaf(p, ws, lt ? -3.5233877e-06f : 0.00134934322f);
-    p = fmaf(p, ws, lt ? -4.39150654e-06f : -0.00367342844f);
-    p = fmaf(p, ws, lt ? 0.00021858087f : 0.00573950773f);
-    p = fmaf(p, ws, lt ? -0.00125372503f : -0.0076224613f);
-    p = fmaf(p, ws, lt ? -0.00417768164f : 0.00943887047f);
-    p = fmaf(p, ws, lt ? 0.246640727f : 1.00167406f);
-    p = fmaf(p, ws, lt ? 1.50140941f : 2.83297682f);
-    float xi = x[e] * __builtin_inff();
-    asm volatile("" : "+v"(xi));  // likewise: a select, not a branch
-    const float r = fabsf(x[e]) == 1.0f ? xi : p * x[e];
-    z[e] = 1.41421354f * r;
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // wave64 reductions (all lanes receive the result)
 //

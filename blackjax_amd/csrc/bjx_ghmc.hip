@@ -47,14 +47,8 @@ k_ghmc_init(Key key, int64_t off, int64_t N, int64_t D, float* __restrict__ p_ou
     const Key km = key_child(kc, 0), ks = key_child(kc, 1);
     for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
       float z[VEC];
-      if constexpr (VEC == 4) {
-        uint32_t bits[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j + e));
-        normal4_from_bits(bits, z);
-      } else {
-        z[0] = normal_from_bits(key_bits32(km, (uint64_t)j));
-      }
+      for (int e = 0; e < VEC; ++e) z[e] = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
       stv<VEC>(p_out + r * D + j, z);
     }
     // uniform(ks, (), -1, 1) = max(minval, f * (maxval - minval) + minval)
@@ -90,18 +84,9 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
       float m[VEC], pp[VEC], pn[VEC];
       ldv<VEC>(im + j, m);
       ldv<VEC>(p_prev + base + j, pp);
-      float zz[VEC];
-      if constexpr (VEC == 4) {  // four independent threefry + erf_inv chains
-        uint32_t bits[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j + e));
-        normal4_from_bits(bits, zz);
-      } else {
-        zz[0] = normal_from_bits(key_bits32(km, (uint64_t)j));
-      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float z = zz[e];
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
         const float fresh = (1.0f / sqrtf(m[e])) * z;  // metrics.py:704-709 (two roundings)
         const float t1 = pp[e] * s1, t2 = s2 * fresh;  // two products, one sum (ghmc.py:216-221)
         pn[e] = t1 + t2;

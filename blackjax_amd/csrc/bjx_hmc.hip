@@ -67,18 +67,9 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
       } else {
         m[0] = im[j];
       }
-      float zz[VEC];
-      if constexpr (VEC == 4) {  // four independent threefry + erf_inv chains (normal4_from_bits)
-        uint32_t bits[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j + e));
-        normal4_from_bits(bits, zz);
-      } else {
-        zz[0] = normal_from_bits(key_bits32(km, (uint64_t)j));
-      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float z = zz[e];
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
         const float ms = 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
         pv[e] = ms * z;
         const float v = m[e] * pv[e];
@@ -138,14 +129,10 @@ k_momentum_diag_short(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, 
       for (int64_t j = (int64_t)gl * 4; j < D; j += G * 4) {
         const F4 t = ld4(im + j);
         const float m[4] = {t.x, t.y, t.z, t.w};
-        float pv[4], zz[4];
-        uint32_t bits[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j + e));
-        normal4_from_bits(bits, zz);
+        float pv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = zz[e];
+          const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
           const float ms = 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
           pv[e] = ms * z;
           const float v = m[e] * pv[e];

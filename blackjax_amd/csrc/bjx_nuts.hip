@@ -16,12 +16,6 @@
 
 using namespace bjx;
 
-// momentum draws of the tick kernels: four interleaved threefry + erf_inv chains (normal4_from_bits, more
-// registers) or one element after the other.  A/B switch for tools/ab_variant.sh builds.
-#ifndef BJX_NUTS_NORMAL4
-#define BJX_NUTS_NORMAL4 1
-#endif
-
 namespace {
 
 constexpr int kBlock = 256;
@@ -1136,19 +1130,9 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
       BJX_ROW_SWEEP(j0) {
         const Row<VEC> m = ldr<VEC>(im + j0);
         Row<VEC> pv;
-        float zz[VEC];
-        if constexpr (VEC == 4 && BJX_NUTS_NORMAL4) {
-          uint32_t bits[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j0 + e));
-          normal4_from_bits(bits, zz);
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) zz[e] = normal_from_bits(key_bits32(km, (uint64_t)(j0 + e)));
-        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float z = zz[e];
+          const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0 + e)));
           const float ms = 1.0f / sqrtf(m.v[e]);
           pv.v[e] = ms * z;
           acc += (double)(m.v[e] * pv.v[e]) * (double)pv.v[e];
@@ -1624,19 +1608,9 @@ __device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx
   for (int k = 0; k < NI; ++k)
     if (ok[k]) {
       M[k] = ldr<VEC>(im + j0[k]);
-      float zz[4];
-      if constexpr (BJX_NUTS_NORMAL4) {
-        uint32_t bits[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j0[k] + e));
-        normal4_from_bits(bits, zz);  // four independent threefry + erf_inv chains
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) zz[e] = normal_from_bits(key_bits32(km, (uint64_t)(j0[k] + e)));
-      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float z = zz[e];
+        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j0[k] + e)));
         const float ms = 1.0f / sqrtf(M[k].v[e]);
         P[k].v[e] = ms * z;
         acc += (double)(M[k].v[e] * P[k].v[e]) * (double)P[k].v[e];
