@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "round_summary")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out_dir = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
 
@@ -37,6 +37,7 @@ for key, name in [("bench_py_C2", "bench_c2.json"), ("bench_py_C2_two_gloo_ranks
                   ("bench_py_C4_shard", "bench_c4.json"), ("nuts_C3_free_running_T20", "nuts_c3_T20.json"),
                   ("nuts_C3_free_running_T100", "nuts_c3_T100.json"), ("nuts_C3_free_running_T400", "nuts_c3_T400.json"),
                   ("nuts_C3_lockstep_step", "nuts_c3_lockstep.json"), ("dense_C5", "dense_c5.json"),
+                  ("nuts_shared_dense_metric_gemm_vs_matvec", "nuts_dense_shared.json"),
                   ("chees_C2", "chees_c2.json"), ("ghmc_C2_shape_and_meads", "ghmc_c2.json"),
                   ("nuts_C3_warmup", "nuts_warmup_c3.json"),
                   ("hmc_small_batches", "hmc_small.json")]:

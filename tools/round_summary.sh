@@ -1,7 +1,8 @@
 #!/bin/bash
 # One-box summary of a round: full GPU test suite, smoke(), every bench (C2 default, C2 at 2 gloo ranks
 # on one GPU, C4 shard through bench.py --config c4, C3 NUTS free-running T = 20 / 100 / 400 + lockstep,
-# C5 dense, ChEES at C2, GHMC + MEADS, NUTS warm-up) and the rocprofv3 kernel stats of the NUTS and dense runs.
+# C5 dense, NUTS with a shared dense metric on the GEMM, ChEES at C2, GHMC + MEADS, NUTS warm-up) and the
+# rocprofv3 kernel stats of the NUTS and dense runs.
 # Outputs land in gpurun_out/round_summary/; tools/collect_summary.py <round> turns them into
 # profiles/<round>/summary_final_<round>.json and copies the kernel-stats CSVs.
 set -u
@@ -13,10 +14,11 @@ cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 BJX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --headline-only --no-cpu-baseline > $O/bench_c2_2ranks_one_gpu.json 2> $O/bench_2r.err
-python bench.py --config c4 --steps 100 --warmup 20 > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --config c4 > $O/bench_c4.json 2> $O/bench_c4.err   # default: the 1 000-step warm-up of configs[3]
 for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --steps $T --no-tick-timing > $O/nuts_c3_T$T.json 2>> $O/nuts.err; done
 timeout 600 python tools/bench_nuts.py --use-graph --steps 5 > $O/nuts_c3_lockstep.json 2>> $O/nuts.err
 python tools/bench_dense.py > $O/dense_c5.json 2> $O/dense.err
+timeout 900 python tools/bench_nuts_dense.py --steps 5 --warmup 3 > $O/nuts_dense_shared.json 2> $O/nuts_dense.err
 python tools/bench_chees.py > $O/chees_c2.json 2> $O/chees.err
 python tools/bench_ghmc.py > $O/ghmc_c2.json 2> $O/ghmc.err
 python tools/bench_nuts_warmup.py > $O/nuts_warmup_c3.json 2> $O/nuts_warmup.err
