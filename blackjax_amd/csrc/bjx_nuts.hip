@@ -174,14 +174,22 @@ __device__ __forceinline__ void nuts_open_half(const bjx_nuts_t& nt, int64_t c, 
   float* fq = (dir > 0 ? nt.Rq : nt.Lq) + base;
   float* fp = (dir > 0 ? nt.Rp : nt.Lp) + base;
   if constexpr (DENSE) {
-    static_assert(VEC == 1, "dense metric uses the 4-byte mapping");
+    // VEC == 4 instantiations exist for the v_pre path only (the launcher picks them when v_pre is set and
+    // the buffers are 16-byte aligned): the mat-vec below uses the 4-byte lane mapping, and all sweeps of
+    // one kernel must share one mapping
     const int lane = threadIdx.x & 63;
     if (vpre) {  // velocity of the kicked momentum from the caller's GEMM (bjx_nuts_t.v_pre)
-      for (int64_t i = lane; i < nt.D; i += 64) {
-        const float qn = fmaf(deps, vpre[i], fq[i]);
-        fq[i] = qn;
-        qo[i] = qn;
-        fp[i] = fmaf(h, gsrc[i], fp[i]);
+      BJX_ROW_SWEEP(j0) {
+        const Row<VEC> g = ldr<VEC>(gsrc + j0), v = ldr<VEC>(vpre + j0);
+        Row<VEC> p = ldr<VEC>(fp + j0), q = ldr<VEC>(fq + j0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          q.v[e] = fmaf(deps, v.v[e], q.v[e]);
+          p.v[e] = fmaf(h, g.v[e], p.v[e]);
+        }
+        str<VEC>(fq + j0, q);
+        str<VEC>(qo + j0, q);
+        str<VEC>(fp + j0, p);
       }
       return;
     }
@@ -352,12 +360,12 @@ k_nuts_mid(bjx_nuts_t nt, int64_t n_rows_arg, const int32_t* __restrict__ idx,
 
 // Compact rows of kicked momenta for the GEMM that applies a shared dense inverse mass matrix
 // (bjx_nuts_t.v_pre): pc[b] = p_end + (dir eps kick) g, g = gf[b] or the end's stored gradient.
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_dense_kick(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_rows_arg,
                   const int32_t* __restrict__ idx, const int64_t* __restrict__ ctl,
                   const float* __restrict__ gf, float kick, float* __restrict__ pc) {
   const StepCtx cx = make_ctx(nt, depth_arg, s_arg, n_rows_arg, ctl);
-  const int lane = threadIdx.x & 63;
   for (int64_t b = wave_row0(); b < cx.n_rows; b += wave_row_stride()) {
     const int64_t c = idx ? (int64_t)idx[b] : b;
     float* out = pc + b * nt.D;
@@ -372,14 +380,23 @@ k_nuts_dense_kick(bjx_nuts_t nt, int32_t depth_arg, int32_t s_arg, int64_t n_row
       }
     }
     if (!act) {
-      for (int64_t j = lane; j < nt.D; j += 64) out[j] = 0.0f;
+      Row<VEC> z;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) z.v[e] = 0.0f;
+      BJX_ROW_SWEEP(j0) str<VEC>(out + j0, z);
       continue;
     }
     const float h = ((float)dir * chain_eps(nt, c)) * kick;
     const int64_t base = c * nt.D;
     const float* p = (dir > 0 ? nt.Rp : nt.Lp) + base;
     const float* g = gf ? gf + b * nt.D : (dir > 0 ? nt.Rg : nt.Lg) + base;
-    for (int64_t j = lane; j < nt.D; j += 64) out[j] = fmaf(h, g[j], p[j]);
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> gg = ldr<VEC>(g + j0);
+      Row<VEC> pp = ldr<VEC>(p + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pp.v[e] = fmaf(h, gg.v[e], pp.v[e]);
+      str<VEC>(out + j0, pp);
+    }
   }
 }
 
@@ -578,11 +595,17 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
     fv = (dir > 0 ? nt.Rv : nt.Lv) + base;
     if (nt.v_pre) {  // velocity of the closing-kicked momentum from the caller's GEMM
       const float* vp = nt.v_pre + b * nt.D;
-      for (int64_t i = lane; i < nt.D; i += 64) {
-        const float p = fmaf(h, gn[i], fp[i]);
-        const float v = vp[i];
-        fv[i] = v;
-        acc += (double)v * (double)p;
+      BJX_ROW_SWEEP(j0) {
+        const Row<VEC> g = ldr<VEC>(gn + j0), v = ldr<VEC>(vp + j0);
+        Row<VEC> p = ldr<VEC>(fp + j0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          p.v[e] = fmaf(h, g.v[e], p.v[e]);
+          acc += (double)v.v[e] * (double)p.v[e];
+        }
+        str<VEC>(fv + j0, v);
+        str<VEC>(fp + j0, p);
+        str<VEC>(fg + j0, g);
       }
     } else {
       for (int64_t ic = 0; ic < nt.D; ic += 64) {
@@ -596,10 +619,11 @@ __device__ __forceinline__ bool nuts_post_chain(const bjx_nuts_t& nt, const Step
         }
       }
     }
-    for (int64_t j = lane; j < nt.D; j += 64) {
-      fp[j] = fmaf(h, gn[j], fp[j]);
-      fg[j] = gn[j];
-    }
+    if (!nt.v_pre)
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        fp[j] = fmaf(h, gn[j], fp[j]);
+        fg[j] = gn[j];
+      }
   } else {
     BJX_ROW_SWEEP(j0) {
       const Row<VEC> g = ldr<VEC>(gn + j0), m = ldr<VEC>(im + j0);
@@ -1872,6 +1896,20 @@ int nuts_resident_ni(const bjx_nuts_t* nt, P... extra) {
   return nt->D <= 256 ? 1 : (nt->D <= 512 ? 2 : 0);
 }
 
+// 16-byte sweeps for a dense metric whose velocities come from the caller's GEMM (v_pre): every row array
+// the pre / mid / post kernels touch is aligned and D % 4 == 0
+template <typename... P>
+bool nuts_vec4_dense(const bjx_nuts_t* nt, P... extra) {
+  return nt->Mdense && nt->v_pre &&
+         bjx_vec4_ok(nt->D, nt->v_pre, nt->Lq, nt->Lp, nt->Lg, nt->Rq, nt->Rp, nt->Rg, nt->Lv, nt->Rv, nt->msum,
+                     nt->Smsum, nt->Sq, nt->Sg, nt->ckpt_r, nt->ckpt_rs, nt->ckpt_v, extra...);
+}
+#define BJX_NUTS_LAUNCH_V(KERNEL, grid, stream, vec4, dense, vec4_dense, ...)                          \
+  do {                                                                                                 \
+    if (vec4_dense) hipLaunchKernelGGL((KERNEL<4, true>), grid, dim3(kBlock), 0, stream, __VA_ARGS__); \
+    else BJX_NUTS_LAUNCH(KERNEL, grid, stream, vec4, dense, __VA_ARGS__);                              \
+  } while (0)
+
 // pick the <VEC, DENSE> instantiation of a kernel template
 #define BJX_NUTS_LAUNCH(KERNEL, grid, stream, vec4, dense, ...)                                        \
   do {                                                                                                 \
@@ -1904,7 +1942,8 @@ int bjx_nuts_pre(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s,
                 "bjx_nuts_pre: bad arguments");
   if (n_rows == 0) return 0;
   const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
-  BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+  BJX_NUTS_LAUNCH_V(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+                    nuts_vec4_dense(nuts, qf),
                   *nuts, depth, (int32_t)s, n_rows, idx, (const int64_t*)nullptr, qf);
   return bjx_check_launch("bjx_nuts_pre");
 }
@@ -1917,7 +1956,8 @@ int bjx_nuts_pre_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64_
                 "bjx_nuts_pre_ctl: bad arguments");
   if (n_cap == 0) return 0;
   const dim3 grid(bjx_row_grid(n_cap, kWavesPerBlock));
-  BJX_NUTS_LAUNCH(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+  BJX_NUTS_LAUNCH_V(k_nuts_pre, grid, (hipStream_t)stream, nuts_vec4(nuts, qf), nuts->Mdense != nullptr,
+                    nuts_vec4_dense(nuts, qf),
                   *nuts, 0, s_off, n_cap, idx, ctl, qf);
   return bjx_check_launch("bjx_nuts_pre_ctl");
 }
@@ -1930,8 +1970,13 @@ int bjx_nuts_dense_kick(void* stream, const bjx_nuts_t* nuts, int32_t depth, int
   BJX_CHECK_ARG(depth >= 0 && s >= 0 && n_rows >= 0 && n_rows <= nuts->N && pc_out && (idx || !ctl),
                 "bjx_nuts_dense_kick: bad arguments");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(k_nuts_dense_kick, dim3(bjx_row_grid(n_rows, kWavesPerBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, *nuts, depth, (int32_t)s, n_rows, idx, ctl, gf, kick, pc_out);
+  const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
+  if (bjx_vec4_ok(nuts->D, nuts->Lp, nuts->Rp, nuts->Lg, nuts->Rg, gf, pc_out))
+    hipLaunchKernelGGL(k_nuts_dense_kick<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, *nuts, depth, (int32_t)s,
+                       n_rows, idx, ctl, gf, kick, pc_out);
+  else
+    hipLaunchKernelGGL(k_nuts_dense_kick<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, *nuts, depth, (int32_t)s,
+                       n_rows, idx, ctl, gf, kick, pc_out);
   return bjx_check_launch("bjx_nuts_dense_kick");
 }
 
@@ -1942,7 +1987,8 @@ int bjx_nuts_mid(void* stream, const bjx_nuts_t* nuts, int64_t n_rows, const int
   BJX_CHECK_ARG(n_rows >= 0 && n_rows <= nuts->N && qf && gf && (idx || !ctl), "bjx_nuts_mid: bad arguments");
   if (n_rows == 0) return 0;
   const dim3 grid(bjx_row_grid(n_rows, kWavesPerBlock));
-  BJX_NUTS_LAUNCH(k_nuts_mid, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr,
+  BJX_NUTS_LAUNCH_V(k_nuts_mid, grid, (hipStream_t)stream, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr,
+                    nuts_vec4_dense(nuts, qf, gf),
                   *nuts, n_rows, idx, ctl, qf, gf, kick, drift);
   return bjx_check_launch("bjx_nuts_mid");
 }
@@ -1967,7 +2013,8 @@ int bjx_nuts_post(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t s
     hipLaunchKernelGGL(k_nuts_post_res<2>, grid, dim3(kBlock), 0, st, *nuts, depth, (int32_t)s, n_rows, idx,
                        (const int64_t*)nullptr, qf, logp_f, gf, fuse);
   else
-    BJX_NUTS_LAUNCH(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr, *nuts, depth,
+    BJX_NUTS_LAUNCH_V(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr,
+                      nuts_vec4_dense(nuts, qf, gf), *nuts, depth,
                     (int32_t)s, n_rows, idx, (const int64_t*)nullptr, qf, logp_f, gf, fuse);
   return bjx_check_launch("bjx_nuts_post");
 }
@@ -1990,7 +2037,8 @@ int bjx_nuts_post_ctl(void* stream, const bjx_nuts_t* nuts, int32_t s_off, int64
     hipLaunchKernelGGL(k_nuts_post_res<2>, grid, dim3(kBlock), 0, st, *nuts, 0, s_off, n_cap, idx, ctl, qf,
                        logp_f, gf, (int)fuse_next);
   else
-    BJX_NUTS_LAUNCH(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr, *nuts, 0, s_off,
+    BJX_NUTS_LAUNCH_V(k_nuts_post, grid, st, nuts_vec4(nuts, qf, gf), nuts->Mdense != nullptr,
+                      nuts_vec4_dense(nuts, qf, gf), *nuts, 0, s_off,
                     n_cap, idx, ctl, qf, logp_f, gf, (int)fuse_next);
   return bjx_check_launch("bjx_nuts_post_ctl");
 }
