@@ -287,7 +287,7 @@ def timed_region(ctx, step_fn, steps):
     return mx, per, t_enq
 
 
-def selftest_control_flow(args, ctx):
+def selftest_control_flow(args, ctx, emit):
     """CPU-only exercise of this file's multi-rank control flow (spawn, rendezvous, barriers,
     max-over-ranks timing, gather, one JSON line from rank 0) with a sleep in place of the GPU step.
     NOT a measurement: ``value`` is null and the metric says so."""
@@ -297,12 +297,12 @@ def selftest_control_flow(args, ctx):
     rows = ctx.gather_rows(torch.full((2, 3), float(ctx.rank)))
     seen = ctx.ranks_seen()
     if ctx.rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "control-flow self-test (no GPU work; NOT a measurement)", "value": None,
             "unit": None, "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per],
             "ranks_seen": seen, "backend": ctx.backend, "gathered_rows": list(rows.shape),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None}), flush=True)
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None})
 
 
 # ------------------------------------------------------------------------------------ C2
@@ -766,10 +766,29 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)  # does not return
+    # RCCL prints a five-line banner ("RCCL version : ... Librccl path : ...") to the C library's STDOUT,
+    # flushed when the process exits -- i.e. AFTER anything Python printed (seen on MI355X / ROCm 7.0 with a
+    # one-rank communicator).  The contract is ONE JSON line on stdout, so with a process group every rank
+    # points file descriptor 1 at stderr for the rest of its life and rank 0 writes the JSON line to a
+    # duplicate of the original stdout.
+    json_fd = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BJX_BENCH_FORCE_PG", "0") == "1":
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(obj):
+        line = json.dumps(obj) + "\n"
+        if json_fd is None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            os.write(json_fd, line.encode())
+
     ctx = Ctx(args)
     try:
         if args.selftest_control_flow:
-            selftest_control_flow(args, ctx)
+            selftest_control_flow(args, ctx, emit)
             return
         seen = ctx.ranks_seen()
         out = bench_c2(args, ctx) if args.config == "c2" else bench_c4(args, ctx)
@@ -796,7 +815,7 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(args.dim or 1024, args.leapfrogs, args.eps)
                 except Exception as e:  # the baseline is a reported extra; never fail the GPU number
                     out["cpu_baseline"] = {"value": None, "error": repr(e)}
-            print(json.dumps(out), flush=True)
+            emit(out)
     finally:
         ctx.finish()
 

@@ -87,6 +87,10 @@ def test_bench_control_flow_over_rccl_with_one_rank():
                         "--chains", "4096", "--headline-only", "--no-cpu-baseline", "--no-rng-pin"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    # RCCL prints a banner to the C library's stdout at process exit; bench.py keeps its own stdout to the
+    # ONE JSON line the driver parses (file descriptor 1 is pointed at stderr once a process group exists)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-600:]
     j = _last_json(r.stdout)
     assert j["backend"] == "nccl" and j["n_gpus"] == 1 and j["ranks"] == 1 and j["devices_distinct"] == 1
     assert j["value"] > 0 and j["final_draws_gathered"] == [256, 1024]
