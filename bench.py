@@ -414,6 +414,11 @@ def bench_c2(args, ctx):
         candidates = [(min(args.chain_block or N, N), bool(args.use_graph), max(1, args.streams))]
     elif blk_auto < N:
         candidates += [(blk_auto, True, 1), (max(blk_auto // 2, 1024), False, 2), (N, False, 1)]
+        if world > 1:
+            # no HIP-graph candidate under a process group: a capture that fails on one rank only (the
+            # RCCL watchdog thread polls events while another thread captures) would desynchronise the
+            # ranks' barriers; the graph mode has not won the autotune on any single-GPU box either
+            candidates = [c for c in candidates if not c[1]]
     tuning = {}
     if len(candidates) > 1:
         for cb, gr, ns_ in candidates:
@@ -571,11 +576,15 @@ def bench_c2(args, ctx):
         torch_mode = torch_line(m, k_t, "torch_autograd",
                                 "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad, grad_outputs=ones)", 48)
         torch_mode["frac_of_68B_roofline"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D))
-        try:
-            mg = measure(blk_auto, True, False, steps=k_t, fn=torch_logdensity, timing=False)
-            torch_graph_mode = torch_line(mg, k_t, "torch_autograd", torch_mode["logdensity"] + ", inner loop as a HIP graph", 48)
-        except Exception as e:  # a callable torch cannot record is driven with plain launches: say why
-            torch_graph_mode = {"value": None, "error": repr(e)[:300]}
+        if world > 1:
+            torch_graph_mode = {"value": None, "skipped": "single-GPU runs only (no graph capture under a process group)"}
+        else:
+            try:
+                mg = measure(blk_auto, True, False, steps=k_t, fn=torch_logdensity, timing=False)
+                torch_graph_mode = torch_line(mg, k_t, "torch_autograd",
+                                              torch_mode["logdensity"] + ", inner loop as a HIP graph", 48)
+            except Exception as e:  # a callable torch cannot record is driven with plain launches: say why
+                torch_graph_mode = {"value": None, "error": repr(e)[:300]}
         mp = measure(blk_auto, False, False, steps=k_t, fn=torch_pair, timing=False)
         # g = -(q*iv): r1 w1 (+ neg fused or r1 w1); q*g: r2 w1; sum: r1 -> ~6-8 words
         torch_pair_mode = torch_line(mp, k_t, "torch_pair",
