@@ -13,6 +13,7 @@
 #include "../../include/bjx_hip.h"
 #include "bjx_device.h"
 #include "bjx_host.h"
+#include "bjx_targets_dev.h"
 
 using namespace bjx;
 
@@ -1551,8 +1552,10 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
 
 // End of a transition (phase 3) and start of the next one (phase 0 / after phase 3): record, accept,
 // adapt, momentum draw, lazy tree start, doubling 0, opening half of its first leaf.
+// Returns true when the chain leaves with a new pending position in qf[b] (false: it has completed its
+// last transition).
 template <int NI>
-__device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+__device__ __forceinline__ bool async_end2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
                                                  int64_t c, int64_t b, int phase, int& w) {
   constexpr int VEC = 4;
   const int lane = threadIdx.x & 63;
@@ -1608,7 +1611,7 @@ __device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx
         ax.phase[c] = 2;
         atomicAdd(ax.n_done, 1);
       }
-      return;
+      return false;
     }
   } else {
 #pragma unroll
@@ -1675,6 +1678,26 @@ __device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx
     }
   rec_set_i(w, RW_LAZY, (LZ_L | LZ_R | LZ_P | LZ_M) & ~(dir > 0 ? LZ_R : LZ_L));
   if (lane == 0) ax.phase[c] = 1;
+  return true;
+}
+
+// Engine-resident log-density of the row this wave just wrote to qf[b] (bjx_nuts_async_t.target_kind):
+// the position is re-read (same wave, after a fence: L1 / L2 resident) and (logp, grad) of the stand-alone
+// target kernels written to logp_f[b] / gf[b] for the next tick.
+template <int NI>
+__device__ __forceinline__ void async_target_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax,
+                                                 const float* qf, float* logp_f, float* gf, int64_t b) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // qf[b]: written above by this wave
+  const float* qrow = qf + b * nt.D;
+  F4 x[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int64_t j = ((int64_t)lane + 64 * k) * 4;
+    if (j < nt.D) x[k] = ld4(qrow + j);
+  }
+  if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_row<NI>(nt.D, x, logp_f + b, gf + b * nt.D);
+  else diag_gaussian_row<NI>(nt.D, x, ax.target_vec, logp_f + b, gf + b * nt.D);
 }
 
 // One tick of one compact row.  MODE 0: leaf work only (phase 1), 1: transition ends / starts only
@@ -1682,7 +1705,7 @@ __device__ __forceinline__ void async_end2_chain(const bjx_nuts_t& nt, const bjx
 #ifndef BJX_LEAF2_WAVES
 #define BJX_LEAF2_WAVES 4
 #endif
-template <int NI, int MODE>
+template <int NI, int MODE, bool TGT = false>
 __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
                                                 const float* __restrict__ logp_f,
                                                 const float* __restrict__ gf, int64_t b) {
@@ -1714,23 +1737,28 @@ __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_
   }
   phase = __builtin_amdgcn_readfirstlane(phase);
   const int w_in = w;
+  bool pending = false;  // a new position for the callable was written to qf[b]
   if (MODE != 1 && phase == 1) {
     const int done = async_leaf2_chain<NI>(nt, ax, qf, lp, c, b, w, R);
+    pending = !done;
     if (MODE == 2 && done) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
+      pending = async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
     }
     // two-kernel ticks: rows whose transition ended go on the work list of the second kernel
     if (MODE == 0 && done && ax.end_list && lane == 0)
       ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
   } else if (MODE != 0 && (phase == 3 || phase == 0)) {
-    async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
+    pending = async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
   } else {
     if (MODE == 0 && phase == 0 && ax.end_list && lane == 0)  // first tick of a run: every chain starts
       ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
     return;
   }
   if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
+  if constexpr (TGT) {  // engine-resident log-density (its own instantiations: the default kernels are untouched)
+    if (pending) async_target_row<NI>(nt, ax, qf, const_cast<float*>(logp_f), const_cast<float*>(gf), b);
+  }
 }
 
 // WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168.
@@ -1738,15 +1766,14 @@ __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_
 // all its wave slots at once, so with four chains per workgroup a CU slot group lives as long as
 // the slowest of four leaves (a merge + direction change takes several times a plain leaf); these
 // kernels use neither LDS nor barriers, so nothing is lost by launching 64-thread workgroups.
-template <int NI, int MODE, int WAVES>
+template <int NI, int MODE, int WAVES, bool TGT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
-k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
-                   const float* __restrict__ gf) {
+k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* logp_f, const float* gf) {
   if (MODE == 0 && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
   const int64_t n_rows = async_n_rows(ax);
   for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
-    async_tick2_row<NI, MODE>(nt, ax, qf, logp_f, gf, b);
+    async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
 }
 
 // Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
@@ -1755,15 +1782,14 @@ k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
 // tick k appends to list k & 1 and clears the counter of the other one, whose readers (tick k - 1)
 // are done -- no completion counting (2 048 same-address atomics with a returned value cost more
 // than the transition ends themselves: 35 us per tick measured).
-template <int NI>
+template <int NI, bool TGT = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
-k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
-                      const float* __restrict__ gf) {
+k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* logp_f, const float* gf) {
   const int par = ax.tick & 1;
   const int n = __builtin_amdgcn_readfirstlane(ax.end_count[par]);
   const int32_t* list = ax.end_list + (int64_t)par * nt.N;
   for (int64_t i = wave_row0(); i < n; i += wave_row_stride())
-    async_tick2_row<NI, 1>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(list[i]));
+    async_tick2_row<NI, 1, TGT>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(list[i]));
 }
 
 // Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
@@ -2099,6 +2125,12 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                      nuts->imm_stride == nuts->D),
                 "bjx_nuts_async_tick: adaptation needs every adapt_* buffer, nuts->eps_per_chain == "
                 "adapt_step_size and nuts->imm == adapt_imm with imm_stride == D");
+  BJX_CHECK_ARG(run->target_kind == BJX_TARGET_NONE ||
+                    ((run->target_kind == BJX_TARGET_NEAL_FUNNEL ||
+                      (run->target_kind == BJX_TARGET_DIAG_GAUSSIAN && run->target_vec && nuts->D > 128)) &&
+                     !nuts->Mdense && run->rec && run->front_p),
+                "bjx_nuts_async_tick: target_kind needs the low-traffic tick kernels (diagonal metric, rec / "
+                "front_p) and a supported target (funnel; diagonal Gaussian with target_vec and D > 128)");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
   if (nuts->Mdense) {
     // dense metric: every leaf is a D x D matrix-vector product per chain (fp64 accumulated, the
@@ -2134,8 +2166,17 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     // wave is everything -- the one-launch tick needs 168 VGPRs + 18 spilled ones (scratch) when capped
     // for three waves per SIMD; uncapped (two waves, up to 256 VGPRs) it spills nothing.
     static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
-#define BJX_TICK2_L(NI_, MODE_, W_) \
-  hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf)
+    const bool tgt = run->target_kind != BJX_TARGET_NONE;
+#define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
+  do {                                                                                                            \
+    if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+    else hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, false>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);    \
+  } while (0)
+#define BJX_END_LIST(NI_)                                                                                         \
+  do {                                                                                                            \
+    if (tgt) hipLaunchKernelGGL((k_nuts_async_end_list<NI_, true>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
+    else hipLaunchKernelGGL((k_nuts_async_end_list<NI_, false>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);    \
+  } while (0)
 #define BJX_TICK2(NI_)                                                                     \
   do {                                                                                     \
     if (fused) {                                                                           \
@@ -2144,7 +2185,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     } else {                                                                               \
       if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);            \
       if (run->end_list && run->end_count)                                                 \
-        hipLaunchKernelGGL((k_nuts_async_end_list<NI_>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
+        BJX_END_LIST(NI_);                                                                 \
       else                                                                                 \
         BJX_TICK2_L(NI_, 1, 4);                                                            \
     }                                                                                      \
@@ -2152,9 +2193,13 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     if (ni2 == 1) BJX_TICK2(1);
     else BJX_TICK2(2);
 #undef BJX_TICK2_L
+#undef BJX_END_LIST
 #undef BJX_TICK2
     return bjx_check_launch("bjx_nuts_async_tick");
   }
+  BJX_CHECK_ARG(run->target_kind == BJX_TARGET_NONE,
+                "bjx_nuts_async_tick: target_kind is served by the low-traffic kernels only (D % 4 == 0, D <= 512, "
+                "16-byte aligned buffers)");
   if (fused) {
     const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
     if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {

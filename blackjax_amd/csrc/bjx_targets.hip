@@ -5,6 +5,7 @@
 #include "../../include/bjx_hip.h"
 #include "bjx_device.h"
 #include "bjx_host.h"
+#include "bjx_targets_dev.h"
 
 using namespace bjx;
 
@@ -140,39 +141,12 @@ k_neal_funnel_v4(int64_t N, int64_t D, const float* __restrict__ q, float* __res
   for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
     const int64_t base = r * D;
     F4 x[NI];
-    double S = 0.0;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int64_t j = ((int64_t)lane + 64 * k) * 4;
-      if (j < D) {
-        x[k] = ld4(q + base + j);
-        const double a = (double)x[k].x, b = (double)x[k].y, c = (double)x[k].z, d = (double)x[k].w;
-        if (j != 0) S += a * a;  // element 0 is y
-        S += b * b;
-        S += c * c;
-        S += d * d;
-      }
+      if (j < D) x[k] = ld4(q + base + j);
     }
-    S = wave_sum(S);
-    const float y32 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[0].x)));  // lane 0, k = 0
-    const double y = (double)y32;
-    const float ey32 = (float)exp((double)(-y32));
-    const double ey = (double)ey32;
-    const double dm1 = (double)(D - 1);
-    const float g0 = (float)(-y / 9.0 + 0.5 * ey * S - 0.5 * dm1);
-    if (lane == 0) {
-      const double t = y / 3.0;
-      logp[r] = (float)(-0.5 * (t * t) - 0.5 * ey * S - 0.5 * dm1 * y);
-    }
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int64_t j = ((int64_t)lane + 64 * k) * 4;
-      if (j < D) {
-        F4 o{-(ey32 * x[k].x), -(ey32 * x[k].y), -(ey32 * x[k].z), -(ey32 * x[k].w)};
-        if (j == 0) o.x = g0;
-        st4(g + base + j, o);
-      }
-    }
+    funnel_row<NI>(D, x, logp + r, g + base);  // bjx_targets_dev.h: shared with the fused NUTS tick
   }
 }
 

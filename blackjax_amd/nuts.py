@@ -452,7 +452,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
              sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
-             row_block=None):
+             row_block=None, fuse_target: bool = False):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -480,6 +480,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     host table ``tab`` (``(num_steps, NUTS_ADAPT_COLS)`` float32), ``target`` and the device buffers
     ``log_x, log_x_avg, avg_err, mu, step_size`` (N,), ``mean, m2, imm`` (N, D), all updated in place;
     ``step_size`` / ``inverse_mass_matrix`` arguments are then ignored in favour of those buffers.
+
+    ``fuse_target=True`` (off by default; only for log-densities the library itself ships,
+    ``blackjax_amd.targets.NealFunnel`` / ``DiagGaussian``, diagonal metric, ``D % 4 == 0``, ``D <= 512``):
+    the tick kernels evaluate the log-density of the position they just produced THEMSELVES, with the
+    device function the stand-alone target kernel runs, so a tick is one launch instead of two and the
+    results are bit for bit those of the default path.  This leaves the external-callable contract of
+    the engine (any PyTorch callable between two ticks) -- it shows what that contract costs: the tail of
+    a run is two dependent launches per leapfrog, ~10-14 us, against one.
 
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
@@ -586,6 +594,17 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         rec=_lib.ptr(rec), front_p=_lib.ptr(front_p), end_list=end_list.data_ptr(),
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
+    fused = False
+    if fuse_target:
+        spec = getattr(logdensity_fn, "_bjx_fused_target", None)
+        spec = spec(D) if callable(spec) else None
+        if spec is None or metric.kind != "diag" or D % 4 != 0 or D > 512 or rec is None:
+            raise NotImplementedError(
+                "fuse_target=True needs a blackjax_amd.targets log-density the tick kernels can evaluate "
+                "(NealFunnel; DiagGaussian with D > 128), a diagonal metric, D % 4 == 0 and D <= 512")
+        run.target_kind, run.target_vec = int(spec[0]), _lib.ptr(spec[1])
+        fused_keep = spec[1]  # noqa: F841  (keeps the parameter vector alive for the run)
+        fused = True
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2
@@ -623,7 +642,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 self.run.tick = i & 1  # work-list parity (include/bjx_nuts.h); chunks have an even length
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
                           logp_f.data_ptr(), gf.data_ptr())
-                logp_f, gf = eval_logdensity(vg, self.qf)
+                if not fused:  # fuse_target: the tick wrote (logp, grad) of its new positions in place
+                    logp_f, gf = eval_logdensity(vg, self.qf)
             return logp_f, gf
 
         def advance(self, n_ticks, record):
@@ -641,8 +661,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     cg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(cg):
                         lp_e, g_e = self.chunk(n_ticks, lp_s, g_s)
-                        lp_s.copy_(lp_e)
-                        g_s.copy_(g_e)
+                        if lp_e is not lp_s:
+                            lp_s.copy_(lp_e)
+                            g_s.copy_(g_e)
                     self.graph = (cg, lp_s, g_s, n_ticks)
                     self.logp_f, self.gf = lp_s, g_s
                 except Exception:
@@ -686,6 +707,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 self.run.append(r)
             self.graph = {}   # (buffer set, view rows) -> (CUDAGraph, ticks per replay)
             self.cur, self.n_cur, self.view = 0, 0, cap
+            if fused:  # in/out (logp, grad) of the pending positions, one pair per buffer set
+                self.lp = [torch.zeros(cap, **f32) for _ in range(2)]
+                self.g = [torch.zeros((cap, D), **f32) for _ in range(2)]
 
         def tier(self, n_active):
             if not self.tiered:
@@ -699,6 +723,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             self.view = self.tier(n_active)
             self.run[k].n_rows = self.view
             self.cur, self.n_cur = k, n_active
+            if fused:  # (logp, grad) of the gathered positions: one stand-alone evaluation, then in place
+                lp, g_ = eval_logdensity(vg, self.qf[k][:self.view])
+                self.lp[k][:self.view].copy_(lp)
+                self.g[k][:self.view].copy_(g_)
 
         def chunk_ticks(self):
             """Ticks per recorded sequence: the few-row tiers are pure launch latency (two dependent
@@ -735,8 +763,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             copied logp and the gradient once per sequence: 0.85 us per tick in the deep tail)."""
             qf_v = self.qf[k][:self.view]
             rref_k = ctypes.byref(self.run[k])
+            if fused:
+                lp, g_ = self.lp[k][:self.view], self.g[k][:self.view]
             for i in range(n_ticks):
-                lp, g_ = eval_logdensity(vg, qf_v)
+                if not fused:
+                    lp, g_ = eval_logdensity(vg, qf_v)
                 self.run[k].tick = i & 1
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, qf_v.data_ptr(),
                           lp.data_ptr(), g_.data_ptr())
@@ -909,7 +940,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                       max_num_doublings, chain_offset=chain_offset)
 
     def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
-               store_positions: bool = True):
+               store_positions: bool = True, fuse_target: bool = False):
         if general:
             # the free-running tick kernels integrate with velocity Verlet; with another integrator the
             # same num_steps transitions run as lockstep steps (identical draws, chain c at transition t
@@ -919,6 +950,6 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,
                         store_positions=store_positions,
-                        use_graph=True if use_graph is True else run_use_graph)
+                        use_graph=True if use_graph is True else run_use_graph, fuse_target=fuse_target)
 
     return SamplingAlgorithm(init_fn, step_fn, run_fn)

@@ -32,6 +32,14 @@ class DiagGaussian(_Target):
     def __init__(self, inv_var: torch.Tensor):
         self.inv_var = check_batch(inv_var, "inv_var")
 
+    def _bjx_fused_target(self, dim: int):
+        """(kind, parameter vector) for ``bjx_nuts_async_t.target_kind`` or None when the tick kernels
+        cannot evaluate this target themselves (rows of at most 128 floats take another reduction order
+        in the stand-alone kernel)."""
+        if dim > 128 and tuple(self.inv_var.shape) == (dim,):
+            return 2, self.inv_var
+        return None
+
     def __call__(self, q):
         q, logp, g = self._alloc(q)
         N, D = q.shape
@@ -43,6 +51,9 @@ class DiagGaussian(_Target):
 
 
 class NealFunnel(_Target):
+    def _bjx_fused_target(self, dim: int):
+        return 1, None
+
     def __call__(self, q):
         q, logp, g = self._alloc(q)
         N, D = q.shape

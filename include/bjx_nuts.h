@@ -273,7 +273,20 @@ typedef struct {
    * to.  Both NULL for a diagonal metric. */
   const float* mass_sqrt_t;
   float* v0;
+  /* Optional engine-resident log-density (round 3; low-traffic tick kernels only: diagonal metric,
+   * rec / front_p given).  target_kind != 0: every row that leaves the tick with a new pending position
+   * also gets its log-density and gradient evaluated IN the tick, by the device function the stand-alone
+   * target kernel runs (csrc/bjx_targets_dev.h: identical results), written to logp_f[b] / gf[b] -- the
+   * arrays passed to bjx_nuts_async_tick, which are then in/out -- so the caller launches NO callable
+   * between ticks: one launch per leapfrog instead of two.  This is outside the external-callable
+   * contract of the engine: it exists for the targets the library itself ships.
+   * BJX_TARGET_NEAL_FUNNEL: no parameters; BJX_TARGET_DIAG_GAUSSIAN: target_vec = inv_var (D,), D > 128. */
+  int32_t target_kind;
+  int32_t target_reserved;
+  const float* target_vec;
 } bjx_nuts_async_t;
+
+enum { BJX_TARGET_NONE = 0, BJX_TARGET_NEAL_FUNNEL = 1, BJX_TARGET_DIAG_GAUSSIAN = 2 };
 
 #define BJX_NUTS_REC_WORDS 32
 

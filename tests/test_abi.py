@@ -87,7 +87,7 @@ def test_nuts_descriptor_and_slots_match_header():
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     py = [f[0] for f in _lib.NutsAsync._fields_]
     assert names == py, (names, py)
-    assert ctypes.sizeof(_lib.NutsAsync) == 8 + 4 * 2 + 8 * 7 + 8 * 2 + 8 * 8 + 8 + 4 * 2 + 8 * 9 + 8 * 4 + 4 * 2 + 8 + 8 * 2
+    assert ctypes.sizeof(_lib.NutsAsync) == 8 + 4 * 2 + 8 * 7 + 8 * 2 + 8 * 8 + 8 + 4 * 2 + 8 * 9 + 8 * 4 + 4 * 2 + 8 + 8 * 2 + 4 * 2 + 8
     for name, i in _lib.NUTS_AT.items():
         assert enums["BJX_NUTS_AT_" + name] == i
     assert enums["BJX_NUTS_ADAPT_COLS"] == _lib.NUTS_ADAPT_COLS

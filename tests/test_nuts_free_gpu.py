@@ -225,3 +225,51 @@ def test_free_running_dense_metric_equals_lockstep_and_oracle(dev, per_chain, N,
     alg_g = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.3, dev_t(imm, dev), max_num_doublings=depth, use_graph=True)
     final_g, pos_g, info_g = alg_g.run(run_key, st0, T)
     assert torch.equal(pos_g, positions) and torch.equal(info_g.num_integration_steps, info.num_integration_steps)
+
+
+@pytest.mark.parametrize("target,N,D,T", [("funnel", 9000, 256, 4), ("funnel", 300, 320, 6), ("gauss", 700, 256, 5),
+                                          ("funnel", 40, 64, 8)])
+def test_fused_target_ticks_equal_the_external_callable_path(dev, target, N, D, T):
+    """``run(..., fuse_target=True)``: the tick kernels evaluate the library's own target themselves (one
+    launch per tick, bjx_nuts_async_t.target_kind) with the device function the stand-alone target kernel
+    runs -- every record, position and the final state are bit for bit those of the default path (two
+    launches per tick).  9 000 rows: the two-kernel ticks + work list; the small cases: one-launch ticks and
+    the recorded tail."""
+    import blackjax_amd as bjx
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    if target == "funnel":
+        fn = bjx.targets.NealFunnel()
+        q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
+        eps = 0.15
+    else:
+        iv = (0.5 + torch.rand(D, device=dev, generator=g)).contiguous()
+        fn = bjx.targets.DiagGaussian(iv)
+        q0 = torch.randn(N, D, device=dev, generator=g)
+        eps = 0.3
+    alg = bjx.nuts(fn, eps, torch.ones(D, device=dev), max_num_doublings=6)
+    st0 = alg.init(q0)
+    key = bjx.random.key(11)
+    st_a, pos_a, info_a = alg.run(key, st0, T)
+    st_b, pos_b, info_b = alg.run(key, st0, T, fuse_target=True)
+    assert torch.equal(pos_a, pos_b)
+    for a, b in zip(st_a, st_b):
+        assert torch.equal(a, b)
+    for name in ("logdensity", "acceptance_rate", "energy", "num_integration_steps", "num_trajectory_expansions",
+                 "is_divergent", "is_turning"):
+        assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
+    assert int(info_a.num_integration_steps.max()) > int(info_a.num_integration_steps.min())
+
+
+def test_fused_target_is_refused_where_it_does_not_apply(dev):
+    import blackjax_amd as bjx
+
+    fn = lambda q: -0.5 * (q * q).sum(-1)  # noqa: E731  (not a library target)
+    alg = bjx.nuts(fn, 0.2, torch.ones(8, device=dev), max_num_doublings=3)
+    st = alg.init(torch.zeros(4, 8, device=dev))
+    with pytest.raises(NotImplementedError):
+        alg.run(bjx.random.key(0), st, 2, fuse_target=True)
+    small = bjx.nuts(bjx.targets.DiagGaussian(torch.ones(64, device=dev)), 0.2, torch.ones(64, device=dev))
+    with pytest.raises(NotImplementedError):  # D <= 128: the stand-alone kernel reduces in another order
+        small.run(bjx.random.key(0), small.init(torch.zeros(4, 64, device=dev)), 2, fuse_target=True)

@@ -27,6 +27,9 @@ ap.add_argument("--free-running", action="store_true",
                 help="drive the timed transitions with alg.run (asynchronous chains) instead of step")
 ap.add_argument("--no-tick-timing", action="store_true",
                 help="free-running: do not bracket ticks with HIP events (the brackets drain the queue)")
+ap.add_argument("--fuse-target", action="store_true",
+                help="free-running: the tick kernels evaluate the built-in funnel themselves (one launch per tick; "
+                     "OUTSIDE the external-callable contract -- a second, separately labelled figure)")
 ap.add_argument("--run-graph", default="auto", choices=["auto", "off", "on"],
                 help="free-running: HIP-graph replay of tick chunks (auto = in the tail of the run)")
 args = ap.parse_args()
@@ -44,14 +47,14 @@ for t in range(args.warmup):
     state, info = alg.step(keys[t], state)
 torch.cuda.synchronize()
 if args.free_running:
-    alg.run(bjx.random.key(5), state, 2, store_positions=False)  # first use of the tick kernel
+    alg.run(bjx.random.key(5), state, 2, store_positions=False, fuse_target=args.fuse_target)  # first use of the tick kernel
     tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=8, capacity=4096)
     # events cannot be recorded while a graph is being captured: ticks are only timed without graphs
     if args.run_graph == "off" and not args.use_graph and not args.no_tick_timing:
         _lib.set_timer(tick_timer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    state, positions, rinfo = alg.run(bjx.random.key(1), state, args.steps)
+    state, positions, rinfo = alg.run(bjx.random.key(1), state, args.steps, fuse_target=args.fuse_target)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
@@ -76,7 +79,9 @@ if args.free_running:
         "frac_of_52B_roofline": tot / dt / (8e12 / (52.0 * D)),
         "utilisation_per_100_transitions": util_windows,
         "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
-                   "driver": "free-running chains (alg.run)",
+                   "driver": "free-running chains (alg.run)" + (
+                       ", log-density evaluated INSIDE the tick kernels (fuse_target=True: engine-resident target, "
+                       "not the external-callable contract)" if args.fuse_target else ""),
                    "hip_graph": "on" if args.use_graph else args.run_graph},
         "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
         "mean_leapfrogs_per_chain_transition": tot / (N * args.steps),
