@@ -174,7 +174,7 @@ class NutsAsync(ctypes.Structure):
         ("rec", c_void_p), ("front_p", c_void_p), ("end_list", c_void_p), ("end_count", c_void_p),
         ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("n_rows_dev", c_void_p),
         ("mass_sqrt_t", c_void_p), ("v0", c_void_p),
-        ("target_kind", ctypes.c_int32), ("target_reserved", ctypes.c_int32), ("target_vec", c_void_p),
+        ("target_kind", ctypes.c_int32), ("ticks_per_launch", ctypes.c_int32), ("target_vec", c_void_p),
     ]
 
 

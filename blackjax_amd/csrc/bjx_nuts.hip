@@ -1705,8 +1705,9 @@ __device__ __forceinline__ void async_target_row(const bjx_nuts_t& nt, const bjx
 #ifndef BJX_LEAF2_WAVES
 #define BJX_LEAF2_WAVES 4
 #endif
+// Returns false when the row's chain has completed all its transitions (nothing left to do for it).
 template <int NI, int MODE, bool TGT = false>
-__device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+__device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
                                                 const float* __restrict__ logp_f,
                                                 const float* __restrict__ gf, int64_t b) {
   constexpr int VEC = 4;
@@ -1753,12 +1754,13 @@ __device__ __forceinline__ void async_tick2_row(const bjx_nuts_t& nt, const bjx_
   } else {
     if (MODE == 0 && phase == 0 && ax.end_list && lane == 0)  // first tick of a run: every chain starts
       ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
-    return;
+    return phase != 2;
   }
   if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
   if constexpr (TGT) {  // engine-resident log-density (its own instantiations: the default kernels are untouched)
     if (pending) async_target_row<NI>(nt, ax, qf, const_cast<float*>(logp_f), const_cast<float*>(gf), b);
   }
+  return pending || MODE == 0;
 }
 
 // WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168.
@@ -1772,8 +1774,20 @@ k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* l
   if (MODE == 0 && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
   const int64_t n_rows = async_n_rows(ax);
-  for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
-    async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
+  for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x) {
+    if constexpr (TGT && MODE == 2) {
+      // several ticks of this wave's chain in one launch: everything a tick reads was written by this
+      // same wave one iteration earlier (record, rows, the in-place log-density) -- a workgroup-scope
+      // fence orders the wave's own stores before its next loads; no other wave touches the chain
+      const int k_ticks = ax.ticks_per_launch > 1 ? ax.ticks_per_launch : 1;
+      for (int it = 0; it < k_ticks; ++it) {
+        if (!async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b)) break;
+        if (it + 1 < k_ticks) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    } else {
+      async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
+    }
+  }
 }
 
 // Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
@@ -2131,6 +2145,13 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                      !nuts->Mdense && run->rec && run->front_p),
                 "bjx_nuts_async_tick: target_kind needs the low-traffic tick kernels (diagonal metric, rec / "
                 "front_p) and a supported target (funnel; diagonal Gaussian with target_vec and D > 128)");
+  static const int64_t fused_rows_limit = [] {
+    const char* e = getenv("BJX_NUTS_FUSED_ROWS");
+    return e ? atoll(e) : (int64_t)8192;
+  }();
+  BJX_CHECK_ARG(run->ticks_per_launch <= 1 || (run->target_kind != BJX_TARGET_NONE && run->n_rows <= fused_rows_limit),
+                "bjx_nuts_async_tick: ticks_per_launch > 1 needs target_kind and one-launch ticks (n_rows <= the "
+                "fused-row limit, 8 192)");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
   if (nuts->Mdense) {
     // dense metric: every leaf is a D x D matrix-vector product per chain (fp64 accumulated, the

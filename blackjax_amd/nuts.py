@@ -419,6 +419,12 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
     return kernel_graph if use_graph else kernel_eager
 
 
+def _os_environ():
+    import os
+
+    return os.environ
+
+
 def auto_row_block(n_rows: int, dim: int) -> int:
     """Rows per group of the free-running schedule.  Default: ALL rows in one group.  Ticking the
     ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; set
@@ -595,6 +601,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
     fused = False
+    # rows up to which a tick is one launch (csrc: BJX_NUTS_FUSED_ROWS) and, with an engine-resident target,
+    # a whole chunk of ticks is (0 disables the multi-tick launches)
+    multi_tick_rows = int(_os_environ().get("BJX_NUTS_MULTI_TICK_ROWS", _os_environ().get("BJX_NUTS_FUSED_ROWS", "8192")))
     if fuse_target:
         spec = getattr(logdensity_fn, "_bjx_fused_target", None)
         spec = spec(D) if callable(spec) else None
@@ -638,6 +647,13 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 
         def chunk(self, n_ticks, logp_f, gf):
             """``n_ticks`` ticks, each followed by the callable on the group's batch."""
+            if fused and self.n_rows <= multi_tick_rows:
+                # engine-resident target + one-launch ticks: the whole chunk is ONE launch, every wave
+                # advancing its chain n_ticks times (bjx_nuts_async_t.ticks_per_launch)
+                self.run.tick, self.run.ticks_per_launch = 0, n_ticks
+                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
+                          logp_f.data_ptr(), gf.data_ptr())
+                return logp_f, gf
             for i in range(n_ticks):
                 self.run.tick = i & 1  # work-list parity (include/bjx_nuts.h); chunks have an even length
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
@@ -765,6 +781,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             rref_k = ctypes.byref(self.run[k])
             if fused:
                 lp, g_ = self.lp[k][:self.view], self.g[k][:self.view]
+                if self.view <= multi_tick_rows:  # the whole sequence as one launch
+                    self.run[k].tick, self.run[k].ticks_per_launch = 0, n_ticks
+                    _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, qf_v.data_ptr(),
+                              lp.data_ptr(), g_.data_ptr())
+                    return
             for i in range(n_ticks):
                 if not fused:
                     lp, g_ = eval_logdensity(vg, qf_v)

@@ -259,7 +259,8 @@ def test_fused_target_ticks_equal_the_external_callable_path(dev, target, N, D, 
     for name in ("logdensity", "acceptance_rate", "energy", "num_integration_steps", "num_trajectory_expansions",
                  "is_divergent", "is_turning"):
         assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
-    assert int(info_a.num_integration_steps.max()) > int(info_a.num_integration_steps.min())
+    if target == "funnel":
+        assert int(info_a.num_integration_steps.max()) > int(info_a.num_integration_steps.min())
 
 
 def test_fused_target_is_refused_where_it_does_not_apply(dev):
