@@ -2145,13 +2145,8 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                      !nuts->Mdense && run->rec && run->front_p),
                 "bjx_nuts_async_tick: target_kind needs the low-traffic tick kernels (diagonal metric, rec / "
                 "front_p) and a supported target (funnel; diagonal Gaussian with target_vec and D > 128)");
-  static const int64_t fused_rows_limit = [] {
-    const char* e = getenv("BJX_NUTS_FUSED_ROWS");
-    return e ? atoll(e) : (int64_t)8192;
-  }();
-  BJX_CHECK_ARG(run->ticks_per_launch <= 1 || (run->target_kind != BJX_TARGET_NONE && run->n_rows <= fused_rows_limit),
-                "bjx_nuts_async_tick: ticks_per_launch > 1 needs target_kind and one-launch ticks (n_rows <= the "
-                "fused-row limit, 8 192)");
+  BJX_CHECK_ARG(run->ticks_per_launch <= 1 || run->target_kind != BJX_TARGET_NONE,
+                "bjx_nuts_async_tick: ticks_per_launch > 1 needs an engine-resident target (target_kind)");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
   if (nuts->Mdense) {
     // dense metric: every leaf is a D x D matrix-vector product per chain (fp64 accumulated, the
@@ -2170,7 +2165,8 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   // One launch per tick (leaf, fence, boundary in the same wave) unless nearly all chains of a large
   // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
   // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
-  const bool fused = run->n_rows <= fused_rows;
+  // one launch per tick for small batches -- and always when the launch carries several ticks per chain
+  const bool fused = run->n_rows <= fused_rows || run->ticks_per_launch > 1;
   static const bool use_v2 = [] {
     const char* e = getenv("BJX_NUTS_V2");
     return e ? atoi(e) != 0 : true;

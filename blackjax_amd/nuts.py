@@ -601,9 +601,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
     fused = False
-    # rows up to which a tick is one launch (csrc: BJX_NUTS_FUSED_ROWS) and, with an engine-resident target,
-    # a whole chunk of ticks is (0 disables the multi-tick launches)
-    multi_tick_rows = int(_os_environ().get("BJX_NUTS_MULTI_TICK_ROWS", _os_environ().get("BJX_NUTS_FUSED_ROWS", "8192")))
+    # with an engine-resident target a whole chunk of ticks is ONE launch for batches of at most this many
+    # rows (default: always; 0 = one launch per tick).  Measured at C3: every chunk as
+    # one launch 322 / 340 / 220 M/s at T = 20 / 100 / 400, only below 8 192 rows 239 / 254 / 181, one launch
+    # per tick 190 / 212 / 112, the external-callable path 172 / 200 / 99
+    multi_tick_rows = int(_os_environ().get("BJX_NUTS_MULTI_TICK_ROWS", str(N)))
     if fuse_target:
         spec = getattr(logdensity_fn, "_bjx_fused_target", None)
         spec = spec(D) if callable(spec) else None
@@ -617,6 +619,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2
+    sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
     sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even: the work lists alternate per tick
     import os as _os
 

@@ -282,10 +282,10 @@ typedef struct {
    * contract of the engine: it exists for the targets the library itself ships.
    * BJX_TARGET_NEAL_FUNNEL: no parameters; BJX_TARGET_DIAG_GAUSSIAN: target_vec = inv_var (D,), D > 128. */
   int32_t target_kind;
-  int32_t ticks_per_launch;   /* target_kind != 0 and one-launch ticks (n_rows <= the fused-row limit): every
-                                 wave advances ITS chain by this many ticks inside one launch (chains are
-                                 independent and the log-density is evaluated in place, so nothing separates
-                                 two leapfrogs of a chain but the wave's own stores); 0 or 1: one tick */
+  int32_t ticks_per_launch;   /* target_kind != 0: every wave advances ITS chain by this many ticks inside one
+                                 launch of the one-kernel tick (chains are independent and the log-density is
+                                 evaluated in place, so nothing separates two leapfrogs of a chain but the
+                                 wave's own stores); 0 or 1: one tick per launch */
   const float* target_vec;
 } bjx_nuts_async_t;
 
