@@ -457,7 +457,7 @@ class NUTSRunInfo(NamedTuple):
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every: int = 16, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
+             sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
              row_block=None, fuse_target: bool = False):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
@@ -471,7 +471,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     ``run_inference_algorithm``; ``"chain_major"``: ``split(split(rng_key, N)[c], num_steps)[t]``),
     so the draws are identical to ``num_steps`` calls of ``step``.
 
-    The host syncs once per ``sync_every`` ticks (to stop, and to drop finished chains from the
+    ``key_layout="step"`` (``num_steps`` must be 1): chain ``c`` uses ``split(rng_key, N)[c]`` -- the one
+    transition ``step(rng_key, state)`` makes.
+
+    The host syncs once per ``sync_every`` ticks (default 16; 128 with ``fuse_target``, where a whole chunk
+    of ticks is one launch) (to stop, and to drop finished chains from the
     callable's batch once fewer than half of its rows are still running).  In the tail of a run,
     where a few deep trees are all that is left, a tick is a few microseconds of GPU work and the
     loop is bound by the host's launch rate; there (``use_graph="auto"``: once at most
@@ -510,8 +514,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     max_depth = int(max_num_doublings)
     if max_depth < 1:
         raise ValueError("free-running chains need max_num_doublings >= 1")
-    if key_layout not in ("step_major", "chain_major"):
-        raise ValueError("key_layout must be 'step_major' or 'chain_major'")
+    if key_layout not in ("step_major", "chain_major", "step"):
+        raise ValueError("key_layout must be 'step_major', 'chain_major' or 'step'")
+    if key_layout == "step" and T != 1:
+        raise ValueError("key_layout='step' is the single transition of step(): num_steps must be 1")
     vg = value_and_grad(logdensity_fn)
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -554,10 +560,19 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if T == 0 or N == 0:
         return HMCState(q, logp, g), positions, info
 
+    t_first = 0
     if key_layout == "step_major":
         keys = bjx_random.split(rng_key, T)
         step_keys = torch.as_tensor(keys.view(np.int32), device=dev).contiguous()
         k0 = k1 = 0
+    elif key_layout == "step":
+        k0, k1, fold = bjx_random.key_spec(rng_key)
+        step_keys = None
+        if fold < 0:  # a plain key: the transition's own key; a ChainMajorKey: (run key, transition index)
+            step_keys = torch.as_tensor(np.array([[k0, k1]], dtype=np.uint32).view(np.int32), device=dev)
+            k0 = k1 = 0
+        else:
+            t_first = int(fold)
     else:
         step_keys = None
         k0, k1 = bjx_random.key_words(rng_key)
@@ -589,7 +604,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         p0=p.data_ptr(), ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(),
         is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"])
     run = _lib.NutsAsync(
-        step_keys=_lib.ptr(step_keys), t_first=0, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
+        step_keys=_lib.ptr(step_keys), t_first=t_first, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
         logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
         n_done=n_done.data_ptr(), rows=None, n_rows=N, out_position=_lib.ptr(positions),
         out_logdensity=info.logdensity.data_ptr(), out_acceptance_rate=info.acceptance_rate.data_ptr(),
@@ -619,6 +634,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
     max_ticks = T * ((1 << max_depth) - 1) + 2
+    if sync_every is None:
+        sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
     sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even: the work lists alternate per tick
     import os as _os
@@ -945,13 +962,23 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      max_num_doublings: int = 10, divergence_threshold: int = 1000,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
                      recompact_every: int = 16, use_graph="auto",
-                     graph_sync_every: int = 4, run_use_graph="auto", dense_gemm="auto") -> SamplingAlgorithm:
+                     graph_sync_every: int = 4, run_use_graph="auto", dense_gemm="auto",
+                     fuse_target: bool = False) -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
     ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
-    should be driven on this engine."""
+    should be driven on this engine.
+
+    ``fuse_target=True`` (``run_free``: engine-resident targets only, outside the external-callable
+    contract): ``run`` evaluates the log-density inside the tick kernels, and ``step`` is ONE free-running
+    transition of every chain instead of the lockstep tree -- same keys, same draws, same state and scalar
+    info fields bit for bit; the ``momentum`` and ``trajectory_*_state`` fields of ``NUTSInfo`` are ``None``
+    (the free-running kernels keep a trajectory's ends only while its tree grows)."""
     integrators.check_supported(integrator, allow_general=True)
     general = integrator is not integrators.velocity_verlet
+    if fuse_target and general:
+        raise NotImplementedError("fuse_target=True: the free-running tick kernels integrate with velocity Verlet")
+    fuse_default = bool(fuse_target)
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
                           use_graph=use_graph, graph_sync_every=graph_sync_every, dense_gemm=dense_gemm)
 
@@ -960,11 +987,19 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
         return init(position, logdensity_fn)
 
     def step_fn(rng_key, state):
+        if fuse_default:
+            new_state, _, ri = run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, 1,
+                                        max_num_doublings, divergence_threshold=divergence_threshold,
+                                        chain_offset=chain_offset, key_layout="step", store_positions=False,
+                                        use_graph=True if use_graph is True else run_use_graph, fuse_target=True)
+            return new_state, NUTSInfo(None, ri.is_divergent[0], ri.is_turning[0], ri.energy[0], None, None,
+                                       ri.num_trajectory_expansions[0], ri.num_integration_steps[0],
+                                       ri.acceptance_rate[0])
         return kernel(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                       max_num_doublings, chain_offset=chain_offset)
 
     def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
-               store_positions: bool = True, fuse_target: bool = False):
+               store_positions: bool = True, fuse_target: bool = fuse_default):
         if general:
             # the free-running tick kernels integrate with velocity Verlet; with another integrator the
             # same num_steps transitions run as lockstep steps (identical draws, chain c at transition t

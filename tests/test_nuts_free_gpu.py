@@ -274,3 +274,30 @@ def test_fused_target_is_refused_where_it_does_not_apply(dev):
     small = bjx.nuts(bjx.targets.DiagGaussian(torch.ones(64, device=dev)), 0.2, torch.ones(64, device=dev))
     with pytest.raises(NotImplementedError):  # D <= 128: the stand-alone kernel reduces in another order
         small.run(bjx.random.key(0), small.init(torch.zeros(4, 64, device=dev)), 2, fuse_target=True)
+
+
+@pytest.mark.parametrize("N,D,depth", [(600, 256, 7), (9000, 128, 5)])
+def test_step_through_the_free_running_engine_equals_the_lockstep_step(dev, N, D, depth):
+    """``nuts(..., fuse_target=True).step``: one free-running transition per chain (key_layout="step") instead
+    of the lockstep tree.  State and every scalar info field are bit for bit those of the default ``step``,
+    for a plain key and for a ChainMajorKey; the trajectory ends and the momentum are not reported."""
+    import blackjax_amd as bjx
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    fn = bjx.targets.NealFunnel()
+    q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
+    imm = torch.ones(D, device=dev)
+    ref = bjx.nuts(fn, 0.15, imm, max_num_doublings=depth)
+    fused = bjx.nuts(fn, 0.15, imm, max_num_doublings=depth, fuse_target=True)
+    sa = sb = ref.init(q0)
+    for t, key in enumerate([bjx.random.key(3), bjx.random.key(4), bjx.random.ChainMajorKey(bjx.random.key(9), 2)]):
+        sa, ia = ref.step(key, sa)
+        sb, ib = fused.step(key, sb)
+        for a, b in zip(sa, sb):
+            assert torch.equal(a, b), t
+        for name in ("is_divergent", "is_turning", "energy", "num_trajectory_expansions", "num_integration_steps",
+                     "acceptance_rate"):
+            assert torch.equal(getattr(ia, name), getattr(ib, name)), (t, name)
+        assert ib.momentum is None and ib.trajectory_leftmost_state is None
+    assert int(ia.num_integration_steps.max()) > int(ia.num_integration_steps.min())

@@ -38,7 +38,8 @@ N, D = args.chains, args.dim
 alg = bjx.nuts(bjx.targets.NealFunnel(), args.eps, torch.ones(D, device=dev),
                max_num_doublings=args.max_depth, recompact_every=args.recompact,
                use_graph=args.use_graph,
-               run_use_graph={"auto": "auto", "off": False, "on": True}[args.run_graph])
+               run_use_graph={"auto": "auto", "off": False, "on": True}[args.run_graph],
+               fuse_target=args.fuse_target)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=g))
@@ -114,9 +115,13 @@ pre = timer.durations_ms("bjx_nuts_pre")
 post = timer.durations_ms("bjx_nuts_post")
 print(json.dumps({
     "metric": "NUTS useful chain-leapfrog-steps/s", "value": tot_steps / dt, "unit": "chain-leapfrog-steps/s",
-    "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}",
+    "config": {"workload": f"NUTS max_depth={args.max_depth}, Neal funnel D={D}, {N} chains, eps={args.eps}"
+               + (", step() = one free-running transition per chain with the log-density evaluated inside "
+                  "the tick kernels (fuse_target=True: engine-resident target, not the external-callable "
+                  "contract)" if args.fuse_target else ""),
                "recompact_every": args.recompact},
     "steps": args.steps, "ms_per_transition": dt / args.steps * 1e3,
+    "frac_of_52B_roofline": tot_steps / dt / (8e12 / (52.0 * D)),
     "mean_leapfrogs_per_chain_transition": tot_steps / (N * args.steps),
     "leapfrog_launches_per_transition": launches / args.steps if launches else None,
     "lockstep_utilisation_vs_uncompacted": tot_steps / (N * launches) if launches else None,
