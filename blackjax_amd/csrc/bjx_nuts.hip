@@ -1258,13 +1258,24 @@ template <int NI>
 struct LeafRows {  // requested before the chain's phase and record are known (direction independent)
   Row<4> G[NI], M[NI], P[NI], S[NI], X[NI];
 };
+// Several ticks of one chain in one launch (engine-resident target, async_multi_tick_row): while a subtree
+// keeps integrating, everything leaf s + 1 reads is what leaf s just computed -- the rows stay in registers
+// (`hot`) and so does the checkpoint an even leaf stores for the odd leaf after it (PK).  A hot leaf has no
+// top-of-tick fence, so the loads it still makes (deeper checkpoint levels, merge rows: stored by this same
+// wave, earlier in the launch) are preceded by a workgroup-scope fence of their own.
+template <int NI>
+struct HotState {
+  bool hot, pk_valid;
+  Row<4> PK[NI];
+};
 
 // One leaf of chain c (phase 1), record register `w` and rows already requested.  Returns 0 = a
 // leaf is in flight again (phase stays 1), 1 = the transition is complete (phase 3 written;
 // async_end2_chain finishes it).
-template <int NI>
+template <int NI, bool LOOP = false>
 __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
-                                                 float lp, int64_t c, int64_t b, int& w, LeafRows<NI>& R) {
+                                                 float lp, int64_t c, int64_t b, int& w, LeafRows<NI>& R,
+                                                 HotState<NI>* hs = nullptr) {
   constexpr int VEC = 4;
   const int lane = threadIdx.x & 63;
   const int32_t depth = rec_i(w, RW_DEPTH);
@@ -1302,16 +1313,23 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   // (Smsum after leaf s - 1), so it is neither loaded here nor -- when no later leaf reads it, s - 1
   // not a multiple of 4 -- stored by leaf s - 1.
   Row<VEC> C0[NI], C1[NI], MS[NI], OP[NI];
+  bool hot = false;
+  if constexpr (LOOP) hot = hs->hot;
   if (nsub > 0) {
+    bool from_regs = false;
+    if constexpr (LOOP) from_regs = hs->pk_valid;  // leaf s - 1 ran in this launch: its checkpoint is in registers
     const float* r_ck = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+    if (LOOP && hot && !from_regs) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (not reached)
 #pragma unroll
     for (int k = 0; k < NI; ++k)
       if (ok[k]) {
-        C0[k] = ldr<VEC>(r_ck + j0[k]);
+        if constexpr (LOOP) C0[k] = from_regs ? hs->PK[k] : ldr<VEC>(r_ck + j0[k]);
+        else C0[k] = ldr<VEC>(r_ck + j0[k]);
         C1[k] = R.S[k];
       }
   }
   if (last) {
+    if (LOOP && hot) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
     for (int k = 0; k < NI; ++k)
       if (ok[k]) {
@@ -1366,6 +1384,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
       // checkpoints are read by later leaves of the same subtree only: none follow the last leaf
       // or a divergence (even leaves run no U-turn check, so `sdiv` is all that can stop them)
       if (even && !last && !sdiv) {
+        if constexpr (LOOP) hs->PK[k] = R.P[k];
         str<VEC>(nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.P[k]);
         // read from memory only as a SECOND or deeper level, i.e. by leaves s + 3, s + 7, ...: s % 4 == 0
         if ((us & 3u) == 0u) str<VEC>(nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.S[k]);
@@ -1376,12 +1395,14 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
       }
     }
 
+  if constexpr (LOOP) hs->pk_valid = even && !last && !sdiv;
   // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104); the
   // rows of level i - 1 are requested before the reduction of level i
   bool turning = false;
   for (int i = idx_max; i >= idx_min && !turning; --i) {
     Row<VEC> N0[NI], N1[NI];
     if (i > idx_min) {
+      if (LOOP && hot && i == idx_max) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i - 1) * nt.D;
       const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i - 1) * nt.D;
 #pragma unroll
@@ -1441,6 +1462,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
 
   // ---- the subtree is complete: merge it (trajectory.py:680-727, proposal.py:146-176)
   if (!last) {  // stopped early: the merge rows were not requested above
+    if (LOOP && hot) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
     for (int k = 0; k < NI; ++k)
       if (ok[k]) {
@@ -1543,6 +1565,10 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
         }
         str<VEC>(fpp + j0[k], p2);
         str<VEC>(qn + j0[k], q2);
+        if constexpr (LOOP) {  // the rows of the next leaf, as it would load them
+          R.P[k] = p2;
+          R.X[k] = q2;
+        }
       }
     lazy &= ~other_bit;
   }
@@ -1763,6 +1789,85 @@ __device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_
   return pending || MODE == 0;
 }
 
+// `k_ticks` ticks of one compact row in one launch (engine-resident target).  Only this wave touches the
+// chain during the launch.  A tick whose inputs are not in registers (the first one, the one after a
+// transition end) starts with a workgroup-scope fence and loads everything, exactly like async_tick2_row;
+// after a leaf that leaves a new leaf in flight, the next tick's rows are the registers this one holds and
+// its gradient / log-density come straight from the target's registers (the same values are still stored:
+// memory is what the next launch, or the host, sees).
+template <int NI>
+__device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
+                                                     float* logp_f, float* gf, int64_t b, int k_ticks) {
+  constexpr int VEC = 4;
+  const int lane = threadIdx.x & 63;
+  const int chain = ax.rows ? ax.rows[b] : (int)b;
+  const int64_t c = (int64_t)__builtin_amdgcn_readfirstlane(chain);
+  const int64_t base = c * nt.D;
+  int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
+  const float* im = nt.imm + c * nt.imm_stride;
+  HotState<NI> hs;
+  hs.hot = false;
+  hs.pk_valid = false;
+  LeafRows<NI> R;
+  int w = 0, phase = 0;
+  float lp = 0.0f;
+  for (int it = 0; it < k_ticks; ++it) {
+    if (!hs.hot) {
+      if (it) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      phase = ax.phase[c];
+      w = recp[lane & (BJX_NUTS_REC_WORDS - 1)];
+      lp = logp_f[b];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const uint32_t j = ((uint32_t)lane + 64u * k) * VEC;
+        if (j < (uint32_t)nt.D) {
+          R.G[k] = ldr<VEC>(gf + b * nt.D + j);
+          R.M[k] = ldr<VEC>(im + j);
+          R.P[k] = ldr<VEC>(ax.front_p + base + j);
+          R.X[k] = ldr<VEC>(qf + b * nt.D + j);
+          R.S[k] = ldr<VEC>(nt.Smsum + base + j);
+        }
+      }
+      phase = __builtin_amdgcn_readfirstlane(phase);
+      hs.pk_valid = false;
+    }
+    const int w_in = w;
+    bool pending, in_regs = false;
+    if (phase == 1) {
+      const int done = async_leaf2_chain<NI, true>(nt, ax, qf, lp, c, b, w, R, &hs);
+      if (done) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        pending = async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
+      } else {
+        pending = in_regs = true;
+      }
+    } else if (phase == 3 || phase == 0) {
+      pending = async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
+    } else {
+      return;  // the chain has completed all its transitions
+    }
+    if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
+    if (!pending) return;
+    if (in_regs) {  // the position this tick wrote to qf[b] is R.X
+      F4 x[NI], g[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) x[k] = F4{R.X[k].v[0], R.X[k].v[1], R.X[k].v[2], R.X[k].v[3]};
+      if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_eval<NI>(nt.D, x, g, lp);
+      else diag_gaussian_eval<NI>(nt.D, x, ax.target_vec, g, lp);
+      target_store<NI>(nt.D, g, lp, logp_f + b, gf + b * nt.D);
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        R.G[k].v[0] = g[k].x; R.G[k].v[1] = g[k].y; R.G[k].v[2] = g[k].z; R.G[k].v[3] = g[k].w;
+      }
+      hs.hot = true;
+      phase = 1;
+    } else {
+      async_target_row<NI>(nt, ax, qf, logp_f, gf, b);
+      hs.hot = false;
+    }
+  }
+}
+
 // WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168.
 // ONE WAVE PER WORKGROUP: the waves of a workgroup are placed together and a new workgroup needs
 // all its wave slots at once, so with four chains per workgroup a CU slot group lives as long as
@@ -1775,19 +1880,17 @@ k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* l
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
   const int64_t n_rows = async_n_rows(ax);
   for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x) {
-    if constexpr (TGT && MODE == 2) {
-      // several ticks of this wave's chain in one launch: everything a tick reads was written by this
-      // same wave one iteration earlier (record, rows, the in-place log-density) -- a workgroup-scope
-      // fence orders the wave's own stores before its next loads; no other wave touches the chain
-      const int k_ticks = ax.ticks_per_launch > 1 ? ax.ticks_per_launch : 1;
-      for (int it = 0; it < k_ticks; ++it) {
-        if (!async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b)) break;
-        if (it + 1 < k_ticks) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      }
-    } else {
-      async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
-    }
+    async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
   }
+}
+
+// Engine-resident target, bjx_nuts_async_t.ticks_per_launch > 1: one wave per row, that many ticks each.
+template <int NI, int WAVES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
+k_nuts_async_multi(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, float* logp_f, float* gf) {
+  const int64_t n_rows = async_n_rows(ax);
+  for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
+    async_multi_tick_row<NI>(nt, ax, qf, logp_f, gf, b, ax.ticks_per_launch);
 }
 
 // Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
@@ -2184,6 +2287,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     // for three waves per SIMD; uncapped (two waves, up to 256 VGPRs) it spills nothing.
     static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
     const bool tgt = run->target_kind != BJX_TARGET_NONE;
+    static const int multi_waves = [] { const char* e = getenv("BJX_MULTI_WAVES"); return e ? atoi(e) : 2; }();
 #define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
   do {                                                                                                            \
     if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
@@ -2194,9 +2298,15 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     if (tgt) hipLaunchKernelGGL((k_nuts_async_end_list<NI_, true>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
     else hipLaunchKernelGGL((k_nuts_async_end_list<NI_, false>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);    \
   } while (0)
+#define BJX_MULTI(NI_, W_)                                                                                        \
+  hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_>), wgrid, dim3(64), 0, s, *nuts, *run, qf,                       \
+                     const_cast<float*>(logp_f), const_cast<float*>(gf))
 #define BJX_TICK2(NI_)                                                                     \
   do {                                                                                     \
-    if (fused) {                                                                           \
+    if (tgt && run->ticks_per_launch > 1) {                                                \
+      if (run->n_rows <= lowlat_rows || multi_waves <= 2) BJX_MULTI(NI_, 2);               \
+      else if (multi_waves >= 4) BJX_MULTI(NI_, 4); else BJX_MULTI(NI_, 3);                \
+    } else if (fused) {                                                                           \
       if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
       else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
@@ -2211,6 +2321,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     else BJX_TICK2(2);
 #undef BJX_TICK2_L
 #undef BJX_END_LIST
+#undef BJX_MULTI
 #undef BJX_TICK2
     return bjx_check_launch("bjx_nuts_async_tick");
   }

@@ -10,10 +10,9 @@
 namespace bjx {
 
 // Neal's funnel (tests/fixtures.py:81-98 of the reference), y = q[0], v = q[1:].
-// x: the row (already loaded), out: gradient row, *logp: written by lane 0.
+// x: the row (already loaded) -> g: the gradient row, lp: the log-density (the same value in every lane).
 template <int NI>
-__device__ __forceinline__ void funnel_row(int64_t D, const F4 (&x)[NI], float* __restrict__ logp,
-                                           float* __restrict__ g_row) {
+__device__ __forceinline__ void funnel_eval(int64_t D, const F4 (&x)[NI], F4 (&g)[NI], float& lp) {
   const int lane = threadIdx.x & 63;
   double S = 0.0;
 #pragma unroll
@@ -34,17 +33,14 @@ __device__ __forceinline__ void funnel_row(int64_t D, const F4 (&x)[NI], float* 
   const double ey = (double)ey32;
   const double dm1 = (double)(D - 1);
   const float g0 = (float)(-y / 9.0 + 0.5 * ey * S - 0.5 * dm1);
-  if (lane == 0) {
-    const double t = y / 3.0;
-    *logp = (float)(-0.5 * (t * t) - 0.5 * ey * S - 0.5 * dm1 * y);
-  }
+  const double t = y / 3.0;
+  lp = (float)(-0.5 * (t * t) - 0.5 * ey * S - 0.5 * dm1 * y);
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
     if (j < D) {
-      F4 o{-(ey32 * x[k].x), -(ey32 * x[k].y), -(ey32 * x[k].z), -(ey32 * x[k].w)};
-      if (j == 0) o.x = g0;
-      st4(g_row + j, o);
+      g[k] = F4{-(ey32 * x[k].x), -(ey32 * x[k].y), -(ey32 * x[k].z), -(ey32 * x[k].w)};
+      if (j == 0) g[k].x = g0;
     }
   }
 }
@@ -52,8 +48,8 @@ __device__ __forceinline__ void funnel_row(int64_t D, const F4 (&x)[NI], float* 
 // Diagonal Gaussian: g = -(q * inv_var), logp = 0.5 * sum q * g (fp64 accumulate, pieces in ascending order
 // per lane, then the DPP wave sum -- the order of k_diag_gaussian<4> for rows of at most 1 024 floats).
 template <int NI>
-__device__ __forceinline__ void diag_gaussian_row(int64_t D, const F4 (&x)[NI], const float* __restrict__ iv,
-                                                  float* __restrict__ logp, float* __restrict__ g_row) {
+__device__ __forceinline__ void diag_gaussian_eval(int64_t D, const F4 (&x)[NI], const float* __restrict__ iv,
+                                                   F4 (&g)[NI], float& lp) {
   const int lane = threadIdx.x & 63;
   double acc = 0.0;
 #pragma unroll
@@ -61,16 +57,46 @@ __device__ __forceinline__ void diag_gaussian_row(int64_t D, const F4 (&x)[NI], 
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
     if (j < D) {
       const F4 vv = ld4(iv + j);
-      const F4 gg{-(x[k].x * vv.x), -(x[k].y * vv.y), -(x[k].z * vv.z), -(x[k].w * vv.w)};
-      acc += (double)x[k].x * (double)gg.x;
-      acc += (double)x[k].y * (double)gg.y;
-      acc += (double)x[k].z * (double)gg.z;
-      acc += (double)x[k].w * (double)gg.w;
-      st4(g_row + j, gg);
+      g[k] = F4{-(x[k].x * vv.x), -(x[k].y * vv.y), -(x[k].z * vv.z), -(x[k].w * vv.w)};
+      acc += (double)x[k].x * (double)g[k].x;
+      acc += (double)x[k].y * (double)g[k].y;
+      acc += (double)x[k].z * (double)g[k].z;
+      acc += (double)x[k].w * (double)g[k].w;
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0) *logp = (float)(0.5 * acc);
+  lp = (float)(0.5 * acc);
+}
+
+// gradient row + log-density (lane 0) to memory
+template <int NI>
+__device__ __forceinline__ void target_store(int64_t D, const F4 (&g)[NI], float lp, float* __restrict__ logp,
+                                             float* __restrict__ g_row) {
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) *logp = lp;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int64_t j = ((int64_t)lane + 64 * k) * 4;
+    if (j < D) st4(g_row + j, g[k]);
+  }
+}
+
+template <int NI>
+__device__ __forceinline__ void funnel_row(int64_t D, const F4 (&x)[NI], float* __restrict__ logp,
+                                           float* __restrict__ g_row) {
+  F4 g[NI];
+  float lp;
+  funnel_eval<NI>(D, x, g, lp);
+  target_store<NI>(D, g, lp, logp, g_row);
+}
+
+template <int NI>
+__device__ __forceinline__ void diag_gaussian_row(int64_t D, const F4 (&x)[NI], const float* __restrict__ iv,
+                                                  float* __restrict__ logp, float* __restrict__ g_row) {
+  F4 g[NI];
+  float lp;
+  diag_gaussian_eval<NI>(D, x, iv, g, lp);
+  target_store<NI>(D, g, lp, logp, g_row);
 }
 
 }  // namespace bjx

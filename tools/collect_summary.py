@@ -36,7 +36,12 @@ summary = {
 for key, name in [("bench_py_C2", "bench_c2.json"), ("bench_py_C2_two_gloo_ranks_on_one_gpu", "bench_c2_2ranks_one_gpu.json"),
                   ("bench_py_C4_shard", "bench_c4.json"), ("nuts_C3_free_running_T20", "nuts_c3_T20.json"),
                   ("nuts_C3_free_running_T100", "nuts_c3_T100.json"), ("nuts_C3_free_running_T400", "nuts_c3_T400.json"),
-                  ("nuts_C3_lockstep_step", "nuts_c3_lockstep.json"), ("dense_C5", "dense_c5.json"),
+                  ("nuts_C3_lockstep_step", "nuts_c3_lockstep.json"),
+                  ("nuts_C3_engine_resident_target_free_running_T20", "nuts_c3_fused_T20.json"),
+                  ("nuts_C3_engine_resident_target_free_running_T100", "nuts_c3_fused_T100.json"),
+                  ("nuts_C3_engine_resident_target_free_running_T400", "nuts_c3_fused_T400.json"),
+                  ("nuts_C3_engine_resident_target_step", "nuts_c3_fused_step.json"),
+                  ("dense_C5", "dense_c5.json"),
                   ("nuts_shared_dense_metric_gemm_vs_matvec", "nuts_dense_shared.json"),
                   ("chees_C2", "chees_c2.json"), ("ghmc_C2_shape_and_meads", "ghmc_c2.json"),
                   ("nuts_C3_warmup", "nuts_warmup_c3.json"),
@@ -46,11 +51,10 @@ for key, name in [("bench_py_C2", "bench_c2.json"), ("bench_py_C2_two_gloo_ranks
         j.pop("gpu_ms_of_each_step", None)
         summary[key] = j
 json.dump(summary, open(os.path.join(out_dir, f"summary_final_{rnd}.json"), "w"), indent=1)
-for tag in ("nuts", "dense"):
+for tag, name in (("nuts", "nuts_c3"), ("nuts_fused", "nuts_c3_engine_resident_target"), ("dense", "dense_c5")):
     found = glob.glob(os.path.join(SRC, f"kt_{tag}", "*", "*kernel_stats.csv"))
     if found:  # gpurun MERGES into the local directory: take the newest run
-        shutil.copy(max(found, key=os.path.getmtime),
-                    os.path.join(out_dir, f"{'nuts_c3' if tag == 'nuts' else 'dense_c5'}_kernel_stats_final.csv"))
+        shutil.copy(max(found, key=os.path.getmtime), os.path.join(out_dir, f"{name}_kernel_stats_final.csv"))
 tl = os.path.join(SRC, "nuts_c3_timeline.txt")
 if os.path.exists(tl):
     shutil.copy(tl, os.path.join(out_dir, "nuts_c3_timeline_final.txt"))

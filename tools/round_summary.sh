@@ -17,6 +17,10 @@ BJX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --headline-only --no-
 python bench.py --config c4 > $O/bench_c4.json 2> $O/bench_c4.err   # default: the 1 000-step warm-up of configs[3]
 for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --steps $T --no-tick-timing > $O/nuts_c3_T$T.json 2>> $O/nuts.err; done
 timeout 600 python tools/bench_nuts.py --use-graph --steps 5 > $O/nuts_c3_lockstep.json 2>> $O/nuts.err
+# the same C3 runs with the funnel evaluated INSIDE the tick kernels (fuse_target=True: engine-resident target,
+# outside the external-callable contract -- separately labelled figures)
+for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --steps $T --no-tick-timing --fuse-target > $O/nuts_c3_fused_T$T.json 2>> $O/nuts.err; done
+timeout 600 python tools/bench_nuts.py --steps 8 --warmup 3 --fuse-target > $O/nuts_c3_fused_step.json 2>> $O/nuts.err
 python tools/bench_dense.py > $O/dense_c5.json 2> $O/dense.err
 timeout 900 python tools/bench_nuts_dense.py --steps 5 --warmup 3 > $O/nuts_dense_shared.json 2> $O/nuts_dense.err
 python tools/bench_chees.py > $O/chees_c2.json 2> $O/chees.err
@@ -25,8 +29,9 @@ python tools/bench_nuts_warmup.py > $O/nuts_warmup_c3.json 2> $O/nuts_warmup.err
 python tools/bench_small.py > $O/hmc_small.json 2> $O/small.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_nuts -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing > $O/kt_nuts.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_nuts_fused -- python $R/tools/bench_nuts.py --free-running --steps 100 --no-tick-timing --fuse-target > $O/kt_nuts_fused.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dense -- python $R/tools/bench_dense.py > $O/kt_dense.log 2>&1
 cd $R
 python tools/nuts_trace_phases.py $(ls $O/kt_nuts/*/*kernel_trace.csv | head -1) 100 > $O/nuts_c3_timeline.txt 2>&1
-rm -f $O/kt_nuts/*/*kernel_trace.csv $O/kt_dense/*/*kernel_trace.csv
+rm -f $O/kt_nuts/*/*kernel_trace.csv $O/kt_nuts_fused/*/*kernel_trace.csv $O/kt_dense/*/*kernel_trace.csv
 tail -3 $O/gpu_tests.log
