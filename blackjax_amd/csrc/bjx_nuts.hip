@@ -1263,16 +1263,33 @@ struct LeafRows {  // requested before the chain's phase and record are known (d
 // (`hot`) and so does the checkpoint an even leaf stores for the odd leaf after it (PK).  A hot leaf has no
 // top-of-tick fence, so the loads it still makes (deeper checkpoint levels, merge rows: stored by this same
 // wave, earlier in the launch) are preceded by a workgroup-scope fence of their own.
+#ifdef BJX_TICK_PROBE
+// Build-time instrumentation (make PROBE=1; never in the product build): s_memtime stamps between the
+// stages of a multi-tick leaf, summed by the wave of compact row 0 into bjx_tick_probe[] (100 MHz ticks).
+__device__ unsigned long long bjx_tick_probe[16];
+#define BJX_PROBE(hs_, k_)                                            \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_readcyclecounter();       \
+    (hs_)->acc[k_] += t_ - (hs_)->last;                               \
+    (hs_)->last = t_;                                                 \
+  } while (0)
+#else
+#define BJX_PROBE(hs_, k_) do { } while (0)
+#endif
 template <int NI>
 struct HotState {
+#ifdef BJX_TICK_PROBE
+  unsigned long long acc[12], last;
+#endif
   bool hot, pk_valid;
+  bool merged;  // the last leaf completed a subtree and opened the next doubling
   Row<4> PK[NI];
 };
 
 // One leaf of chain c (phase 1), record register `w` and rows already requested.  Returns 0 = a
 // leaf is in flight again (phase stays 1), 1 = the transition is complete (phase 3 written;
 // async_end2_chain finishes it).
-template <int NI, bool LOOP = false>
+template <int NI, bool LOOP = false, bool FULL = false>
 __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
                                                  float lp, int64_t c, int64_t b, int& w, LeafRows<NI>& R,
                                                  HotState<NI>* hs = nullptr) {
@@ -1322,7 +1339,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     if (LOOP && hot && !from_regs) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (not reached)
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
         if constexpr (LOOP) C0[k] = from_regs ? hs->PK[k] : ldr<VEC>(r_ck + j0[k]);
         else C0[k] = ldr<VEC>(r_ck + j0[k]);
         C1[k] = R.S[k];
@@ -1332,17 +1349,27 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     if (LOOP && hot) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
         MS[k] = ldr<VEC>(ms_src + j0[k]);
         OP[k] = ldr<VEC>(op + j0[k]);
       }
   }
 
+  // the uniform of the progressive sampling step below needs the record only (fold_in(kt, s): two
+  // threefry blocks, ~250 dependent instructions): drawn here, it runs under the row loads of this leaf
+  // instead of after its energy reduction
+  float u = 0.0f;
+  if (LOOP || s != 0) {  // LOOP: drawn unconditionally (unused when s == 0) -- one basic block with what follows
+    const Key kt{(uint32_t)rec_i(w, RW_KT), (uint32_t)rec_i(w, RW_KTB)};
+    u = key_uniform(key_child(kt, (uint64_t)(uint32_t)s));
+  }
+  if constexpr (LOOP) BJX_PROBE(hs, 0);  // uniform draw
+
   // pass 1: closing half kick, kinetic energy
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < NI; ++k)
-    if (ok[k]) {
+    if (FULL || ok[k]) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
@@ -1351,6 +1378,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     }
   acc = wave_sum(acc);
   const float ke = 0.5f * (float)acc;
+  if constexpr (LOOP) BJX_PROBE(hs, 1);  // pass 1
   const float e_new = -lp + ke;  // hmc_energy (trajectory.py:745-748)
   float wgt = H0 - e_new;        // proposal.py:91-95
   if (wgt != wgt) wgt = -__builtin_inff();
@@ -1363,18 +1391,17 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     Wn = wgt;
     Sn = slpa_new;
   } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
-    const Key kt{(uint32_t)rec_i(w, RW_KT), (uint32_t)rec_i(w, RW_KTB)};
-    const float u = key_uniform(key_child(kt, (uint64_t)(uint32_t)s));  // fold_in(kt, s)
     const Scalars3 sc = scalars3(-(double)(wgt - sw), sw, wgt, sslpa, slpa_new);
     take = u < sc.r0;
     Wn = sc.lae1;
     Sn = sc.lae2;
   }
 
+  if constexpr (LOOP) BJX_PROBE(hs, 2);  // scalars3
   // pass 2: momentum-sum append, checkpoint store, subtree-proposal state copy
 #pragma unroll
   for (int k = 0; k < NI; ++k)
-    if (ok[k]) {
+    if (FULL || ok[k]) {
       if (s != 0) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) R.S[k].v[e] = R.S[k].v[e] + R.P[k].v[e];
@@ -1396,6 +1423,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     }
 
   if constexpr (LOOP) hs->pk_valid = even && !last && !sdiv;
+  if constexpr (LOOP) BJX_PROBE(hs, 3);  // pass 2
   // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104); the
   // rows of level i - 1 are requested before the reduction of level i
   bool turning = false;
@@ -1407,7 +1435,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
       const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i - 1) * nt.D;
 #pragma unroll
       for (int k = 0; k < NI; ++k)
-        if (ok[k]) {
+        if (FULL || ok[k]) {
           N0[k] = ldr<VEC>(r_ck + j0[k]);
           N1[k] = ldr<VEC>(rs_ck + j0[k]);
         }
@@ -1415,7 +1443,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     double a_left = 0.0, a_right = 0.0;
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float rl = C0[k].v[e];
@@ -1437,6 +1465,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     }
   }
   const bool stop = sdiv || turning;
+  if constexpr (LOOP) BJX_PROBE(hs, 4);  // pass 3
   if (!(stop || last)) {  // the subtree keeps integrating: opening half of leaf s + 1
     rec_set_f(w, RW_SW, Wn);
     rec_set_f(w, RW_SSLPA, Sn);
@@ -1447,7 +1476,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     rec_set_i(w, RW_SUBN, s + 1);
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
@@ -1457,6 +1486,10 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
         str<VEC>(qn + j0[k], R.X[k]);
         str<VEC>(sm + j0[k], R.S[k]);  // the subtree's momentum sum is only stored while it keeps growing
       }
+    if constexpr (LOOP) {
+      hs->merged = false;
+      BJX_PROBE(hs, 5);
+    }
     return 0;
   }
 
@@ -1465,7 +1498,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     if (LOOP && hot) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
         MS[k] = ldr<VEC>(ms_src + j0[k]);
         OP[k] = ldr<VEC>(op + j0[k]);
       }
@@ -1484,7 +1517,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   double a_left = 0.0, a_right = 0.0;
 #pragma unroll
   for (int k = 0; k < NI; ++k)
-    if (ok[k]) {
+    if (FULL || ok[k]) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float pl = dir > 0 ? OP[k].v[e] : R.P[k].v[e];
@@ -1533,7 +1566,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   if (dir2 == dir) {  // the end just reached keeps moving: its state is in registers
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           R.P[k].v[e] = fmaf(h2, R.G[k].v[e], R.P[k].v[e]);
@@ -1551,7 +1584,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     const float* og = (z0 ? nt.g0 : (dir2 > 0 ? nt.Rg : nt.Lg)) + base;
 #pragma unroll
     for (int k = 0; k < NI; ++k)
-      if (ok[k]) {
+      if (FULL || ok[k]) {
         str<VEC>(eq + j0[k], R.X[k]);
         str<VEC>(eg + j0[k], R.G[k]);
         str<VEC>(ep + j0[k], R.P[k]);
@@ -1573,6 +1606,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
     lazy &= ~other_bit;
   }
   rec_set_i(w, RW_LAZY, lazy);
+  if constexpr (LOOP) hs->merged = true;
   return 0;
 }
 
@@ -1795,7 +1829,7 @@ __device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_
 // after a leaf that leaves a new leaf in flight, the next tick's rows are the registers this one holds and
 // its gradient / log-density come straight from the target's registers (the same values are still stored:
 // memory is what the next launch, or the host, sees).
-template <int NI>
+template <int NI, bool FULL>
 __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
                                                      float* logp_f, float* gf, int64_t b, int k_ticks) {
   constexpr int VEC = 4;
@@ -1808,6 +1842,11 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
   HotState<NI> hs;
   hs.hot = false;
   hs.pk_valid = false;
+  hs.merged = false;
+#ifdef BJX_TICK_PROBE
+  for (int k = 0; k < 12; ++k) hs.acc[k] = 0;
+  hs.last = __builtin_readcyclecounter();
+#endif
   LeafRows<NI> R;
   int w = 0, phase = 0;
   float lp = 0.0f;
@@ -1833,27 +1872,30 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
     }
     const int w_in = w;
     bool pending, in_regs = false;
+    BJX_PROBE(&hs, 6);  // loop top (cold: fence + loads)
     if (phase == 1) {
-      const int done = async_leaf2_chain<NI, true>(nt, ax, qf, lp, c, b, w, R, &hs);
+      const int done = async_leaf2_chain<NI, true, FULL>(nt, ax, qf, lp, c, b, w, R, &hs);
       if (done) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         pending = async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
+        BJX_PROBE(&hs, 7);  // merge path + transition end
       } else {
         pending = in_regs = true;
+        if (hs.merged) BJX_PROBE(&hs, 8);  // merge path + next doubling
       }
     } else if (phase == 3 || phase == 0) {
       pending = async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
     } else {
-      return;  // the chain has completed all its transitions
+      break;  // the chain has completed all its transitions
     }
     if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
-    if (!pending) return;
+    if (!pending) break;
     if (in_regs) {  // the position this tick wrote to qf[b] is R.X
       F4 x[NI], g[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) x[k] = F4{R.X[k].v[0], R.X[k].v[1], R.X[k].v[2], R.X[k].v[3]};
-      if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_eval<NI>(nt.D, x, g, lp);
-      else diag_gaussian_eval<NI>(nt.D, x, ax.target_vec, g, lp);
+      if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_eval<NI, FULL>(nt.D, x, g, lp);
+      else diag_gaussian_eval<NI, FULL>(nt.D, x, ax.target_vec, g, lp);
       target_store<NI>(nt.D, g, lp, logp_f + b, gf + b * nt.D);
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
@@ -1865,7 +1907,15 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
       async_target_row<NI>(nt, ax, qf, logp_f, gf, b);
       hs.hot = false;
     }
+    BJX_PROBE(&hs, 9);  // record + target stores
+#ifdef BJX_TICK_PROBE
+    hs.acc[10] += 1;
+#endif
   }
+#ifdef BJX_TICK_PROBE
+  if (b == 0 && lane == 0)
+    for (int k = 0; k < 12; ++k) atomicAdd(&bjx_tick_probe[k], hs.acc[k]);
+#endif
 }
 
 // WAVES = occupancy hint (waves per SIMD): 4 caps the kernel at 128 VGPRs, 3 at 168.
@@ -1885,12 +1935,13 @@ k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* l
 }
 
 // Engine-resident target, bjx_nuts_async_t.ticks_per_launch > 1: one wave per row, that many ticks each.
-template <int NI, int WAVES>
+// FULL: D == 256 NI, every lane holds a piece of every row (no per-piece guards: straight-line code).
+template <int NI, int WAVES, bool FULL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_nuts_async_multi(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, float* logp_f, float* gf) {
   const int64_t n_rows = async_n_rows(ax);
   for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
-    async_multi_tick_row<NI>(nt, ax, qf, logp_f, gf, b, ax.ticks_per_launch);
+    async_multi_tick_row<NI, FULL>(nt, ax, qf, logp_f, gf, b, ax.ticks_per_launch);
 }
 
 // Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
@@ -2299,8 +2350,14 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     else hipLaunchKernelGGL((k_nuts_async_end_list<NI_, false>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);    \
   } while (0)
 #define BJX_MULTI(NI_, W_)                                                                                        \
-  hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_>), wgrid, dim3(64), 0, s, *nuts, *run, qf,                       \
-                     const_cast<float*>(logp_f), const_cast<float*>(gf))
+  do {                                                                                                            \
+    if (nuts->D == 256 * NI_)                                                                                     \
+      hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf,             \
+                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                     \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_, false>), wgrid, dim3(64), 0, s, *nuts, *run, qf,            \
+                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                     \
+  } while (0)
 #define BJX_TICK2(NI_)                                                                     \
   do {                                                                                     \
     if (tgt && run->ticks_per_launch > 1) {                                                \
@@ -2388,3 +2445,14 @@ int bjx_nuts_async_compact(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_
 }
 
 }  // extern "C"
+
+#ifdef BJX_TICK_PROBE
+extern "C" int bjx_debug_tick_probe(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(bjx_tick_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bjx_tick_probe), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

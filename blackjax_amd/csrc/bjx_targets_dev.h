@@ -11,14 +11,15 @@ namespace bjx {
 
 // Neal's funnel (tests/fixtures.py:81-98 of the reference), y = q[0], v = q[1:].
 // x: the row (already loaded) -> g: the gradient row, lp: the log-density (the same value in every lane).
-template <int NI>
+// FULL: D == 256 NI, every lane holds a piece of every row.
+template <int NI, bool FULL = false>
 __device__ __forceinline__ void funnel_eval(int64_t D, const F4 (&x)[NI], F4 (&g)[NI], float& lp) {
   const int lane = threadIdx.x & 63;
   double S = 0.0;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
-    if (j < D) {
+    if (FULL || j < D) {
       const double a = (double)x[k].x, b = (double)x[k].y, c = (double)x[k].z, d = (double)x[k].w;
       if (j != 0) S += a * a;  // element 0 is y
       S += b * b;
@@ -38,7 +39,7 @@ __device__ __forceinline__ void funnel_eval(int64_t D, const F4 (&x)[NI], F4 (&g
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
-    if (j < D) {
+    if (FULL || j < D) {
       g[k] = F4{-(ey32 * x[k].x), -(ey32 * x[k].y), -(ey32 * x[k].z), -(ey32 * x[k].w)};
       if (j == 0) g[k].x = g0;
     }
@@ -47,7 +48,7 @@ __device__ __forceinline__ void funnel_eval(int64_t D, const F4 (&x)[NI], F4 (&g
 
 // Diagonal Gaussian: g = -(q * inv_var), logp = 0.5 * sum q * g (fp64 accumulate, pieces in ascending order
 // per lane, then the DPP wave sum -- the order of k_diag_gaussian<4> for rows of at most 1 024 floats).
-template <int NI>
+template <int NI, bool FULL = false>
 __device__ __forceinline__ void diag_gaussian_eval(int64_t D, const F4 (&x)[NI], const float* __restrict__ iv,
                                                    F4 (&g)[NI], float& lp) {
   const int lane = threadIdx.x & 63;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void diag_gaussian_eval(int64_t D, const F4 (&x)[NI],
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
-    if (j < D) {
+    if (FULL || j < D) {
       const F4 vv = ld4(iv + j);
       g[k] = F4{-(x[k].x * vv.x), -(x[k].y * vv.y), -(x[k].z * vv.z), -(x[k].w * vv.w)};
       acc += (double)x[k].x * (double)g[k].x;
