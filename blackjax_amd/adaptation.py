@@ -257,13 +257,14 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
     mcmc_kernel = algorithm.build_kernel(integrator)  # the sampler validates the integrator
 
-    def _run_free_running(rng_key, state, imm, ss, eps0, num_steps, chain_offset):
+    def _run_free_running(rng_key, state, imm, ss, eps0, num_steps, chain_offset, fuse_target=False):
         """The same warm-up with free-running chains (nuts.run_free, include/bjx_nuts.h adapt_*): every
         chain carries its own dual-averaging / Welford state through its own sequence of trees and
         adapts when IT finishes a transition, so a warm-up no longer lasts as long as the deepest tree
         of every step.  Chains are independent in the reference's vmapped warm-up, hence the results
         are those of ``run`` bit for bit.  NUTS with a diagonal metric; the per-step record is the
-        ``NUTSRunInfo`` of the run (with ``step_size``), not ``adaptation_info_fn``'s."""
+        ``NUTSRunInfo`` of the run (with ``step_size``), not ``adaptation_info_fn``'s.
+        ``fuse_target``: ``nuts.run_free``'s switch (engine-resident log-densities only)."""
         from .nuts import build_kernel as _nuts_build_kernel, run_free as _nuts_run_free
 
         if getattr(algorithm, "build_kernel", None) is not _nuts_build_kernel:
@@ -293,7 +294,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         state, _, run_info = _nuts_run_free(
             rng_key, state, logdensity_fn, ad["step_size"], imm_pc, num_steps, max_depth,
             divergence_threshold=div_thr, chain_offset=chain_offset, key_layout="chain_major",
-            store_positions=False, adaptation=ad)
+            store_positions=False, adaptation=ad, fuse_target=fuse_target)
         step_size = torch.empty_like(ad["log_x_avg"])
         _lib.call("bjx_exp", _lib.current_stream(), n, ad["log_x_avg"].data_ptr(), step_size.data_ptr())
         parameters = {"step_size": step_size,
@@ -301,9 +302,13 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         return AdaptationResults(state, parameters), run_info
 
     def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0,
-            free_running: bool = False):
+            free_running: bool = False, fuse_target: bool = False):
         """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains).
-        ``free_running=True`` (NUTS, diagonal metric): see ``_run_free_running``."""
+        ``free_running=True`` (NUTS, diagonal metric): see ``_run_free_running``; with it,
+        ``fuse_target=True`` evaluates a ``blackjax_amd.targets`` log-density inside the tick kernels
+        (``nuts.run_free``: same results, outside the external-callable contract)."""
+        if fuse_target and not free_running:
+            raise ValueError("fuse_target=True needs free_running=True")
         position = check_batch(position, "position")
         n, d = position.shape
         run_key = key_words(rng_key)
@@ -320,7 +325,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         eps0 = torch.full((n,), float(initial_step_size), dtype=torch.float32, device=position.device)
         ss, _ = _da_init(eps0, from_log_avg=False)
         if free_running:
-            return _run_free_running(rng_key, state, imm, ss, eps0, int(num_steps), chain_offset)
+            return _run_free_running(rng_key, state, imm, ss, eps0, int(num_steps), chain_offset, fuse_target)
         zeros = torch.zeros_like(position)
         # Welford second moments: (N, D) diagonal, or (N, D, D) dense -- one matrix PER CHAIN, the
         # semantics of a vmapped dense warmup (N * D^2 words: meant for moderate N * D^2)

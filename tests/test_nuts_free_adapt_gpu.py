@@ -65,3 +65,27 @@ def test_free_running_warmup_funnel_per_chain_depths(dev):
     assert torch.equal(par_f["step_size"], par_l["step_size"])
     assert torch.equal(par_f["inverse_mass_matrix"], par_l["inverse_mass_matrix"])
     assert int(info.num_trajectory_expansions.max()) >= 4
+
+
+@pytest.mark.parametrize("N,D,T", [(96, 64, 60), (4500, 256, 12)])
+def test_free_running_warmup_with_an_engine_resident_target(dev, N, D, T):
+    """``run(..., free_running=True, fuse_target=True)``: the tick kernels evaluate the funnel themselves, many
+    ticks per launch, with the per-chain dual-averaging / Welford updates at each chain's own transition ends --
+    final state, step sizes, metrics and every record equal those of the external-callable run bit for bit."""
+    fn = bjx.targets.NealFunnel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    q0 = 0.5 * torch.randn(N, D, device=dev, generator=g)
+    warm = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=None, initial_step_size=0.3,
+                                 max_num_doublings=6)
+    (st_a, par_a), info_a = warm.run(prng.key(2), q0, T, free_running=True)
+    (st_b, par_b), info_b = warm.run(prng.key(2), q0, T, free_running=True, fuse_target=True)
+    for a, b in zip(st_a, st_b):
+        assert torch.equal(a, b)
+    assert torch.equal(par_a["step_size"], par_b["step_size"])
+    assert torch.equal(par_a["inverse_mass_matrix"], par_b["inverse_mass_matrix"])
+    for name in ("logdensity", "acceptance_rate", "energy", "num_integration_steps", "num_trajectory_expansions",
+                 "is_divergent", "is_turning", "step_size"):
+        assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
+    with pytest.raises(ValueError):
+        warm.run(prng.key(2), q0, T, fuse_target=True)

@@ -45,6 +45,16 @@ out["free_running"] = {"seconds": dt_f, "value": tot / dt_f, "total_leapfrogs": 
                        "mean_leapfrogs_per_chain_transition": tot / (N * T),
                        "max_chain_total_leapfrogs": int(info.num_integration_steps.sum(0).max()),
                        "final_step_size_median": float(par_f["step_size"].median())}
+t0 = time.perf_counter()
+(st_e, par_e), info_e = warm.run(key, q0, T, free_running=True, fuse_target=True)
+torch.cuda.synchronize()
+dt_e = time.perf_counter() - t0
+out["free_running_engine_resident_target"] = {
+    "seconds": dt_e, "value": tot / dt_e,
+    "note": "fuse_target=True: the funnel evaluated inside the tick kernels (outside the external-callable contract)",
+    "identical_to_free_running": bool(torch.equal(st_e.position, st_f.position)
+                                      and torch.equal(par_e["step_size"], par_f["step_size"])
+                                      and torch.equal(par_e["inverse_mass_matrix"], par_f["inverse_mass_matrix"]))}
 if not args.skip_lockstep:
     t0 = time.perf_counter()
     (st_l, par_l), _ = warm.run(key, q0, T)
