@@ -749,9 +749,10 @@ k_mhmc_step_dense(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, int6
                   const float* __restrict__ logp_new, float* __restrict__ W, float* __restrict__ S,
                   uint8_t* __restrict__ any_div, uint8_t* __restrict__ ever, float* __restrict__ Rq,
                   float* __restrict__ Rp, float* __restrict__ Rg, float* __restrict__ Rlogp,
-                  float* __restrict__ Renergy) {
+                  float* __restrict__ Renergy, const int32_t* __restrict__ n_steps) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
+    if (n_steps && step >= (int64_t)n_steps[r]) continue;  // this chain's trajectory is complete (dmhmc)
     const int64_t base = r * D;
     double acc = 0.0;
     for (int64_t j = lane; j < D; j += 64) acc += (double)v1[base + j] * (double)p1[base + j];
@@ -1221,6 +1222,44 @@ int bjx_hmc_finish_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_
   return bjx_check_launch("bjx_hmc_finish_dense_coef");
 }
 
+static int mhmc_step_dense(const char* who, void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                           int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
+                           const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                           float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                           const float* p, const float* g, const float* logp_new, float* p1_work,
+                           float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                           uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                           float* prop_logp, float* prop_energy, const int32_t* n_steps) {
+  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
+  if (!(N >= 0 && D > 0 && step >= 0 && step < ((int64_t)1 << 31) && imm && logp0 && ke0 && q && p && g &&
+        logp_new && p1_work && v_work && weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q &&
+        prop_p && prop_g && prop_logp && prop_energy && p1_work != p &&
+        (matrix_stride < 0 || matrix_stride == 0 || matrix_stride == D * D))) {
+    bjx_set_error("%s: bad arguments", who);
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // closing half kick p1 = p + (eps/2) g ; v1 = imm p1.  With n_steps, rows whose trajectory is complete
+  // keep their momentum (the prologue copies it through) and are skipped by the reservoir step below.
+  if (matrix_stride < 0) {
+    GemmArgs ga{N, D, p, g, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+    ga.b_symmetric = true;
+    ga.n_steps = n_steps;
+    ga.step_idx = (int32_t)step;
+    if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
+  } else {
+    PcArgs pa{N, D, imm, matrix_stride, p, g, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+    pa.n_steps = n_steps;
+    pa.step_idx = (int32_t)step;
+    if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;
+  }
+  hipLaunchKernelGGL(k_mhmc_step_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
+                     Key{key0, key1}, chain_offset, step_fold, N, D, step, divergence_threshold, logp0,
+                     ke0, q, p1_work, v_work, g, logp_new, weight, sum_log_p_accept, any_divergent,
+                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy, n_steps);
+  return bjx_check_launch(who);
+}
+
 int bjx_mhmc_step_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                         int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
                         const float* eps_per_chain, const float* imm, int64_t matrix_stride,
@@ -1229,26 +1268,25 @@ int bjx_mhmc_step_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                         float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
                         uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
                         float* prop_logp, float* prop_energy) {
-  if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
-  BJX_CHECK_ARG(N >= 0 && D > 0 && step >= 0 && imm && logp0 && ke0 && q && p && g && logp_new &&
-                    p1_work && v_work && weight && sum_log_p_accept && any_divergent && ever_accepted &&
-                    prop_q && prop_p && prop_g && prop_logp && prop_energy && p1_work != p &&
-                    (matrix_stride < 0 || matrix_stride == 0 || matrix_stride == D * D),
-                "bjx_mhmc_step_dense: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  if (matrix_stride < 0) {  // closing half kick p1 = p + (eps/2) g ; v1 = imm p1
-    GemmArgs ga{N, D, p, g, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
-    ga.b_symmetric = true;
-    if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
-  } else {
-    PcArgs pa{N, D, imm, matrix_stride, p, g, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
-    if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;
-  }
-  hipLaunchKernelGGL(k_mhmc_step_dense, dim3(bjx_row_grid(N, kWavesPerBlock)), dim3(kBlock), 0, s,
-                     Key{key0, key1}, chain_offset, step_fold, N, D, step, divergence_threshold, logp0,
-                     ke0, q, p1_work, v_work, g, logp_new, weight, sum_log_p_accept, any_divergent,
-                     ever_accepted, prop_q, prop_p, prop_g, prop_logp, prop_energy);
-  return bjx_check_launch("bjx_mhmc_step_dense");
+  return mhmc_step_dense("bjx_mhmc_step_dense", stream, key0, key1, chain_offset, step_fold, N, D, step, eps,
+                         eps_per_chain, imm, matrix_stride, divergence_threshold, logp0, ke0, q, p, g, logp_new,
+                         p1_work, v_work, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q, prop_p,
+                         prop_g, prop_logp, prop_energy, nullptr);
+}
+
+int bjx_mhmc_step_dense_masked(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                               int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
+                               const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                               float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                               const float* p, const float* g, const float* logp_new, float* p1_work,
+                               float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                               uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                               float* prop_logp, float* prop_energy, const int32_t* n_steps) {
+  BJX_CHECK_ARG(N == 0 || n_steps, "bjx_mhmc_step_dense_masked: n_steps is NULL");
+  return mhmc_step_dense("bjx_mhmc_step_dense_masked", stream, key0, key1, chain_offset, step_fold, N, D, step,
+                         eps, eps_per_chain, imm, matrix_stride, divergence_threshold, logp0, ke0, q, p, g,
+                         logp_new, p1_work, v_work, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q,
+                         prop_p, prop_g, prop_logp, prop_energy, n_steps);
 }
 
 }  // extern "C"

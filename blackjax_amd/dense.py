@@ -90,13 +90,18 @@ def finish_coef(stream, metric, k0, k1, off, fold, n, d, kick_coef, eps, eps_pc,
 
 
 def mhmc_step(stream, metric, k0, k1, off, fold, n, d, step, eps, eps_pc, thr, logp0, ke0, q, p, g, logp,
-              weight, slpa, any_div, ever, pq, pp, pg, plogp, penergy):
-    """Closing half kick + reservoir step of multinomial HMC; returns the fully kicked momentum."""
+              weight, slpa, any_div, ever, pq, pp, pg, plogp, penergy, n_steps=None):
+    """Closing half kick + reservoir step of multinomial HMC; returns the fully kicked momentum.
+    ``n_steps``: per-chain trajectory lengths (dmhmc) -- chains with ``step >= n_steps`` are left alone."""
     p1 = torch.empty_like(p)
     v = torch.empty_like(p)
-    _lib.call("bjx_mhmc_step_dense", stream, k0, k1, off, fold, n, d, step, eps, _lib.ptr(eps_pc),
-              metric.imm.data_ptr(), matrix_stride(metric, d), thr, logp0.data_ptr(), ke0.data_ptr(),
-              q.data_ptr(), p.data_ptr(), g.data_ptr(), logp.data_ptr(), p1.data_ptr(), v.data_ptr(),
-              weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(),
-              pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr())
+    args = (stream, k0, k1, off, fold, n, d, step, eps, _lib.ptr(eps_pc),
+            metric.imm.data_ptr(), matrix_stride(metric, d), thr, logp0.data_ptr(), ke0.data_ptr(),
+            q.data_ptr(), p.data_ptr(), g.data_ptr(), logp.data_ptr(), p1.data_ptr(), v.data_ptr(),
+            weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(),
+            pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr())
+    if n_steps is None:
+        _lib.call("bjx_mhmc_step_dense", *args)
+    else:
+        _lib.call("bjx_mhmc_step_dense_masked", *args, n_steps.data_ptr())
     return p1

@@ -278,6 +278,19 @@ int bjx_mhmc_step_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chai
                         uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
                         float* prop_logp, float* prop_energy);
 
+/* bjx_mhmc_step_dense with per-chain trajectory lengths (blackjax.dmhmc with a dense metric: blackjax/__init__.py
+ * 155-163 over mcmc/dynamic_hmc.py:85-118): chain r takes part in step `step` only while step < n_steps[r];
+ * otherwise its momentum is copied to p1_work unchanged and its reservoir is left alone.  Continue with
+ * bjx_leapfrog_dense_coef(..., n_steps, step + 1). */
+int bjx_mhmc_step_dense_masked(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                               int64_t step_fold, int64_t N, int64_t D, int64_t step, float eps,
+                               const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                               float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                               const float* p, const float* g, const float* logp_new, float* p1_work,
+                               float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                               uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                               float* prop_logp, float* prop_energy, const int32_t* n_steps);
+
 /* Closing half kick + energies + Metropolis accept + select with a dense metric (same contract as
  * bjx_hmc_finish_diag).  p1_work, v_work: (N, D) scratch (p1_work must not alias p). */
 int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

@@ -123,7 +123,8 @@ def test_dmhmc_statistics_and_validation(dev):
     for k in bjx.random.split(bjx.random.key(5), 40):
         state, info = alg.step(k, state)
     np.testing.assert_allclose(t2n(state.position.var(0)), sig * sig, rtol=0.2)
-    with pytest.raises(NotImplementedError):
-        bjx.dmhmc(fn, 0.5, torch.eye(8, device=dev)).step(bjx.random.key(1), state)  # dense metric
+    with pytest.raises(NotImplementedError):  # dense metric x multi-stage integrator
+        bjx.dmhmc(fn, 0.5, torch.eye(8, device=dev), integrator=bjx.integrators.mclachlan).step(
+            bjx.random.key(1), state)
     with pytest.raises(NotImplementedError):
         bjx.dynamic_hmc.build_kernel(build_proposal=lambda *a: None)

@@ -91,6 +91,36 @@ def test_dynamic_hmc_dense_parity(dev, N, D, per_chain):
     assert len(lengths) >= 4
 
 
+@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (45, 20, False), (18, 16, True)])
+def test_dmhmc_dense_parity(dev, N, D, per_chain):
+    """blackjax.dmhmc with a dense metric (blackjax/__init__.py:155-163; VERDICT r2 "missing" #4): per-chain
+    random trajectory lengths AND progressive sampling of one state per trajectory -- the masked dense
+    leapfrog + bjx_mhmc_step_dense_masked.  Lengths, reservoir picks (exact positions and momenta) and
+    divergence flags follow the oracle."""
+    fn_o, tgt, imm, metric, q0 = _setup(dev, N, D, per_chain, seed=7)
+    st = ohmc.init(q0, fn_o)
+    st_o = ohmc.DynamicHMCState(st.position, st.logdensity, st.logdensity_grad, prng.split(prng.key(77), N))
+    alg = bjx.dmhmc(tgt, 0.3, dev_t(imm, dev))
+    st_g = alg.init(dev_t(q0, dev), prng.key(77))
+    lengths = set()
+    moved = 0
+    for kk in prng.split(prng.key(0), 4):
+        st_n, info_o = ohmc.dynamic_hmc_kernel(kk, st_o, fn_o, f32(0.3), imm, metric=metric, multinomial=True)
+        st_g, info_g = alg.step(kk, st_g)
+        assert np.array_equal(t2n(info_g.num_integration_steps), info_o.num_integration_steps)
+        assert bool(info_g.is_accepted.all())
+        assert np.array_equal(t2n(info_g.is_divergent), info_o.is_divergent)
+        assert np.array_equal(t2n(st_g.position), st_n.position)  # same reservoir picks, same bits
+        assert np.array_equal(t2n(info_g.proposal.momentum), info_o.proposal.momentum)
+        np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(t2n(info_g.energy), info_o.energy, rtol=1e-6, atol=1e-5)
+        assert np.array_equal(t2n(st_g.random_generator_arg).view(np.uint32), st_n.random_generator_arg)
+        lengths |= set(info_o.num_integration_steps.tolist())
+        moved += int((st_n.position != st_o.position).any(1).sum())
+        st_o = st_n
+    assert len(lengths) >= 4 and moved > 0
+
+
 @pytest.mark.parametrize("name", ["mclachlan", "yoshida", "omelyan"])
 @pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (33, 18, False), (12, 16, True)])
 def test_palindromic_integrators_dense_parity(dev, name, N, D, per_chain):
