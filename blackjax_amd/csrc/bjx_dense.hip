@@ -959,7 +959,19 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
     if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga); \
     else hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga);         \
   } while (0)
-    const int kicks = ga.G ? ga.n_kicks : 0;
+    int kicks = ga.G ? ga.n_kicks : 0;
+    // BJX_DENSE_ABLATE (measurement aid, RESULTS INVALID): where do the microseconds of the fused launch go?
+    // bit 0: no store of the kicked momentum; bit 1: store-only epilogue (no read of q, no drift);
+    // bit 2: no kick prologue (no gradient loads).  DESIGN.md section 8, round 3.
+    static const int ablate = [] { const char* e = getenv("BJX_DENSE_ABLATE"); return e ? atoi(e) : 0; }();
+    if (ablate) {
+      if (ablate & 1) ga.A_out = nullptr;
+      if ((ablate & 2) && epi == EPI_DRIFT) {
+        epi = EPI_STORE;
+        ga.C = ga.Q_out;
+      }
+      if (ablate & 4) kicks = 0;
+    }
     if (epi == EPI_STORE) {
       if (kicks == 0) BJX_LAUNCH_TN(EPI_STORE, 0); else if (kicks == 1) BJX_LAUNCH_TN(EPI_STORE, 1); else BJX_LAUNCH_TN(EPI_STORE, 2);
     } else {
