@@ -590,6 +590,37 @@ def bench_c2(args, ctx):
         torch_pair_mode = torch_line(mp, k_t, "torch_pair",
                                      "g = -(q * inv_var); lp = 0.5 * (q * g).sum(-1); return lp, g  (no autograd)", 32)
 
+    # ---- what the external-callable contract costs: the same C2 transition with the built-in Gaussian evaluated
+    # INSIDE one launch per transition (hmc(..., fuse_target="lean"): engine-resident target, results bit for bit
+    # those of the headline path, tests/test_hmc_traj_gpu.py).  NOT the contract, NOT `value`: a labelled line.
+    resident_mode = None
+    if extras and not args.no_torch_callable:
+        try:
+            alg_r = bjx.hmc(target, args.eps, imm, L, chain_offset=rank * N, fuse_target="lean")
+            st_r = alg_r.init(q_init)
+            for t in range(2):
+                st_r, inf_r = alg_r.step(keys[t], st_r)
+            k_r = max(4, args.steps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            acc_r = torch.zeros((), device=dev)
+            for t in range(k_r):
+                st_r, inf_r = alg_r.step(keys[(args.warmup + t) % len(keys)], st_r)
+                acc_r += inf_r.acceptance_rate.mean()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_r = e0.elapsed_time(e1) / k_r
+            resident_mode = {
+                "value": world * N * L / (ms_r * 1e-3), "unit": "chain-leapfrog-steps/s", "ms_per_step": ms_r,
+                "steps": k_r, "mean_acceptance": float(acc_r) / k_r,
+                "note": "engine-resident target: momentum draw, all L leapfrogs with the Gaussian's (logp, grad) in "
+                        "registers, energies and accept in ONE launch per transition (bjx_hmc_trajectory_diag); a "
+                        "leapfrog moves no bytes, the launch is bound by the momentum draw's arithmetic.  OUTSIDE "
+                        "the external-callable contract -- shown to price that contract, never the headline"}
+        except Exception as e:
+            resident_mode = {"value": None, "error": repr(e)[:300]}
+
     # ---- ESS/sec (second half of BASELINE.json's metric)
     def ess_of(draws, dt):
         if len(draws) < 4:
@@ -647,6 +678,7 @@ def bench_c2(args, ctx):
         "torch_callable_mode": torch_mode,
         "torch_callable_graph_mode": torch_graph_mode,
         "torch_pair_mode": torch_pair_mode,
+        "engine_resident_target_mode": resident_mode,
         "roofline": roofline,
     }
     return out

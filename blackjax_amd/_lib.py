@@ -78,6 +78,10 @@ SIGNATURES = {
                             c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p,
                             _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p,
                             _f32p],
+    "bjx_hmc_trajectory_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                c_float, _f32p, _f32p, c_int64, c_float, ctypes.c_int32, _f32p,
+                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                _f32p, _u8p, _u8p, _f32p],
     "bjx_mhmc_step_dense_masked": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
                                    c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p,
                                    _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p,

@@ -574,15 +574,68 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: f
     return kernel
 
 
+def build_fused_target_kernel(divergence_threshold: float = 1000, *, with_info_arrays: bool = True):
+    """A whole transition per launch for log-densities the ENGINE evaluates itself (``bjx_hmc_trajectory_diag``):
+    ``blackjax_amd.targets.NealFunnel`` / ``DiagGaussian``, diagonal metric, velocity Verlet, 128 < D <= 1 024,
+    D % 4 == 0.  OUTSIDE the external-callable contract (the reference calls ``logdensity_fn`` between two
+    leapfrogs) -- opt-in through ``hmc(..., fuse_target=True)``; state and info are bit for bit those of
+    ``build_kernel()``'s kernel.  ``with_info_arrays=False``: ``HMCInfo.momentum`` and ``.proposal`` are ``None``
+    and their five arrays are not written."""
+    thr = float(divergence_threshold)
+
+    def kernel(rng_key, state: HMCState, logdensity_fn: Callable, step_size,
+               inverse_mass_matrix, num_integration_steps: int, *, chain_offset: int = 0):
+        q0 = check_batch(state.position, "state.position")
+        logp0 = check_batch(state.logdensity, "state.logdensity")
+        g0 = check_batch(state.logdensity_grad, "state.logdensity_grad")
+        N, D = q0.shape
+        dev = q0.device
+        L = int(num_integration_steps)
+        metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+        spec = getattr(logdensity_fn, "_bjx_fused_target", None)
+        spec = spec(D) if callable(spec) else None
+        if spec is None or metric.kind != "diag" or D % 4 != 0 or not 128 < D <= 1024 or L < 1:
+            raise NotImplementedError(
+                "fuse_target=True needs a blackjax_amd.targets log-density the engine can evaluate in place "
+                "(NealFunnel; DiagGaussian), a diagonal metric, 128 < D <= 1024 with D % 4 == 0 and at least "
+                "one integration step")
+        k0, k1, fold = key_spec(rng_key)
+        eps, eps_pc = step_size_args(step_size, N, dev)
+        q_new, g_new, logp_new = torch.empty_like(q0), torch.empty_like(g0), torch.empty_like(logp0)
+        acc_rate, energy = torch.empty_like(logp0), torch.empty_like(logp0)
+        is_acc = torch.empty(N, dtype=torch.bool, device=dev)
+        is_div = torch.empty(N, dtype=torch.bool, device=dev)
+        p0 = q1 = p_end = logp1 = g1 = None
+        if with_info_arrays:
+            p0, q1, p_end, g1 = (torch.empty_like(q0) for _ in range(4))
+            logp1 = torch.empty_like(logp0)
+        _lib.call("bjx_hmc_trajectory_diag", _lib.current_stream(), k0, k1, int(chain_offset), fold, N, D, L, eps,
+                  _lib.ptr(eps_pc), metric.imm.data_ptr(), metric.imm_stride, thr, int(spec[0]), _lib.ptr(spec[1]),
+                  q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), _lib.ptr(p0), _lib.ptr(q1), _lib.ptr(p_end),
+                  _lib.ptr(logp1), _lib.ptr(g1), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
+                  acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        proposal = IntegratorState(q1, p_end, logp1, g1) if with_info_arrays else None
+        return HMCState(q_new, logp_new, g_new), HMCInfo(p0, acc_rate, is_acc, is_div, energy, proposal, L)
+
+    return kernel
+
+
 def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix,
                      num_integration_steps: int, *, divergence_threshold: float = 1000,
                      integrator=integrators.velocity_verlet, build_proposal=None,
                      chain_offset: int = 0, chain_block=None,
-                     use_graph="auto", streams="auto") -> SamplingAlgorithm:
+                     use_graph="auto", streams="auto", fuse_target=False) -> SamplingAlgorithm:
     """blackjax/mcmc/hmc.py:317-414.  ``chain_offset`` is this process' first global chain
-    index when the chains of one run are sharded over several GPUs."""
-    kernel = build_kernel(integrator, divergence_threshold, build_proposal,
-                          chain_block=chain_block, use_graph=use_graph, streams=streams)
+    index when the chains of one run are sharded over several GPUs.  ``fuse_target=True`` (or ``"lean"``: without
+    the momentum / proposal arrays of ``HMCInfo``): ``build_fused_target_kernel`` -- one launch per transition for
+    the library's own log-densities, outside the external-callable contract, identical results."""
+    if fuse_target:
+        if integrator is not integrators.velocity_verlet or build_proposal not in (None, hmc_proposal):
+            raise NotImplementedError("fuse_target=True: velocity Verlet with the endpoint proposal")
+        kernel = build_fused_target_kernel(divergence_threshold, with_info_arrays=fuse_target != "lean")
+    else:
+        kernel = build_kernel(integrator, divergence_threshold, build_proposal,
+                              chain_block=chain_block, use_graph=use_graph, streams=streams)
 
     def init_fn(position, rng_key=None):
         del rng_key

@@ -265,6 +265,22 @@ int bjx_hmc_finish_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_
                               float* acceptance_rate_out, uint8_t* is_accepted_out,
                               uint8_t* is_divergent_out, float* energy_out);
 
+/* A WHOLE HMC transition in one launch for a log-density the engine evaluates itself (target_kind /
+ * target_vec: the BJX_TARGET_* values of bjx_nuts.h) -- momentum draw, num_integration_steps velocity-Verlet
+ * leapfrogs with (logp, grad) computed in registers, energies, Metropolis accept, select.  NOT the reference's
+ * contract (blackjax.hmc calls logdensity_fn between two leapfrogs, hmc.py:279-312): an opt-in path that shows
+ * what the contract costs; bit for bit the results of bjx_hmc_momentum_kick_diag + the target kernel +
+ * bjx_leapfrog_diag + bjx_hmc_finish_diag.  Diagonal metric, 128 < D <= 1024, D % 4 == 0.
+ * p0_out (HMCInfo.momentum) and q1_out / p_end_out / logp1_out / g1_out (HMCInfo.proposal) may each be NULL. */
+int bjx_hmc_trajectory_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                            int64_t step_fold, int64_t N, int64_t D, int64_t num_integration_steps,
+                            float eps, const float* eps_per_chain, const float* imm, int64_t imm_stride,
+                            float divergence_threshold, int32_t target_kind, const float* target_vec,
+                            const float* q0, const float* logp0, const float* g0, float* p0_out,
+                            float* q1_out, float* p_end_out, float* logp1_out, float* g1_out, float* q_out,
+                            float* logp_out, float* g_out, float* acceptance_rate_out,
+                            uint8_t* is_accepted_out, uint8_t* is_divergent_out, float* energy_out);
+
 /* One step of multinomial HMC after the callable, dense metric: closing half kick p1 = p + (eps/2) g
  * [-> p1_work], v1 = imm p1 [-> v_work], then energy, weight, divergence flag, progressive uniform
  * sampling with key fold_in(integrator_key, step) and the reservoir copy of (q, p1, g).  The caller
