@@ -13,7 +13,7 @@ from . import dynamic_hmc as _dynamic_hmc
 from . import ghmc as _ghmc
 from . import hmc as _hmc
 from . import nuts as _nuts
-from . import adaptation, chees, diagnostics, distributed, integrators, meads, metrics, optim, random, targets, util
+from . import adaptation, chees, diagnostics, distributed, integrators, meads, metrics, optim, random, rtc, targets, util
 from .adaptation import staged_adaptation, window_adaptation
 from .chees import chees_adaptation
 from .meads import meads_adaptation
@@ -63,4 +63,4 @@ hmc_family = [hmc, nuts, mhmc]  # blackjax/__init__.py:188
 # Generalized HMC (blackjax/mcmc/ghmc.py), the sampler the MEADS warm-up tunes
 ghmc = GenerateSamplingAPI(_ghmc.as_top_level_api, _ghmc.init, _ghmc.build_kernel)
 
-__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "dmhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable", "returns_pair"]
+__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "dmhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "rtc", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable", "returns_pair"]

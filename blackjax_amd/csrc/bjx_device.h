@@ -5,8 +5,10 @@
 // transcendentals are evaluated in fp64 and rounded once to fp32.
 #pragma once
 
+#ifndef __HIPCC_RTC__  // hiprtc (blackjax_amd/rtc.py) pre-includes the HIP device runtime and has no system headers
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "bjx_log1p.h"
 

@@ -18,9 +18,21 @@
 // Compiles for the device (hipcc) and for the host (gcc, BJX_LOG1P_HOST) from the same source.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#else  // hiprtc: no system headers; the fixed-width names live in __hip_internal there
+#ifndef BJX_RTC_STDINT
+#define BJX_RTC_STDINT
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef signed long long int64_t;
+typedef unsigned long long uint64_t;
+#endif
+#endif
 
 #ifdef BJX_LOG1P_HOST
 #define BJX_L1P_FN static inline

@@ -609,11 +609,27 @@ def build_fused_target_kernel(divergence_threshold: float = 1000, *, with_info_a
         if with_info_arrays:
             p0, q1, p_end, g1 = (torch.empty_like(q0) for _ in range(4))
             logp1 = torch.empty_like(logp0)
-        _lib.call("bjx_hmc_trajectory_diag", _lib.current_stream(), k0, k1, int(chain_offset), fold, N, D, L, eps,
-                  _lib.ptr(eps_pc), metric.imm.data_ptr(), metric.imm_stride, thr, int(spec[0]), _lib.ptr(spec[1]),
-                  q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), _lib.ptr(p0), _lib.ptr(q1), _lib.ptr(p_end),
-                  _lib.ptr(logp1), _lib.ptr(g1), q_new.data_ptr(), logp_new.data_ptr(), g_new.data_ptr(),
-                  acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(), energy.data_ptr())
+        if spec[0] == "rtc":
+            # a user-written device target (targets.DeviceTarget): the same trajectory code, compiled around it
+            # by hiprtc (csrc/bjx_traj_dev.h, blackjax_amd/rtc.py)
+            from . import rtc
+
+            tgt = spec[1]
+            ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+            args = rtc.TrajArgs(k0, k1, int(chain_offset), fold, N, D, L, eps, ptr(eps_pc), metric.imm.data_ptr(),
+                                metric.imm_stride, thr, tgt._params_ptr(dev), q0.data_ptr(), logp0.data_ptr(),
+                                g0.data_ptr(), ptr(p0), ptr(q1), ptr(p_end), ptr(logp1), ptr(g1), q_new.data_ptr(),
+                                logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(), energy.data_ptr(),
+                                is_acc.data_ptr(), is_div.data_ptr())
+            tgt.module().launch(f"bjx_rtc_traj_{rtc.ni_for(D)}", min((N + 3) // 4, 65536), 256,
+                                _lib.current_stream(), args)
+        else:
+            _lib.call("bjx_hmc_trajectory_diag", _lib.current_stream(), k0, k1, int(chain_offset), fold, N, D, L,
+                      eps, _lib.ptr(eps_pc), metric.imm.data_ptr(), metric.imm_stride, thr, int(spec[0]),
+                      _lib.ptr(spec[1]), q0.data_ptr(), logp0.data_ptr(), g0.data_ptr(), _lib.ptr(p0),
+                      _lib.ptr(q1), _lib.ptr(p_end), _lib.ptr(logp1), _lib.ptr(g1), q_new.data_ptr(),
+                      logp_new.data_ptr(), g_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(),
+                      is_div.data_ptr(), energy.data_ptr())
         proposal = IntegratorState(q1, p_end, logp1, g1) if with_info_arrays else None
         return HMCState(q_new, logp_new, g_new), HMCInfo(p0, acc_rate, is_acc, is_div, energy, proposal, L)
 

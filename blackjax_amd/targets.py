@@ -82,3 +82,82 @@ class AR1Gaussian(_Target):
         _lib.call("bjx_target_ar1_gaussian", _lib.current_stream(), N, D, self.d_edge, self.d_mid,
                   self.off, q.data_ptr(), logp.data_ptr(), g.data_ptr())
         return logp, g
+
+
+class DeviceTarget(_Target):
+    """A log-density written by the USER as HIP device code, compiled at run time (``blackjax_amd.rtc``: hiprtc)
+    into (a) a stand-alone ``(logp, grad)`` kernel -- so the object is an ordinary recordable callable under the
+    external-callable contract -- and (b) the engine's whole-transition kernel (``hmc(..., fuse_target=True)``),
+    where it is evaluated in registers between two leapfrogs.  Both call the same ``eval``, so the two paths give
+    the same bits.
+
+    ``source`` defines a struct (default name ``Target``) with the interface of ``csrc/bjx_traj_dev.h``::
+
+        struct Target {
+          template <int NI> struct Ctx { ... };          // per-chain constants in registers; may be empty
+          template <int NI> static __device__ void init(Ctx<NI>& c, int64_t D, const float* params);
+          template <int NI> static __device__ void eval(const Ctx<NI>& c, int64_t D, const float* params,
+                                                        const F4 (&x)[NI], bool need_logp, F4 (&g)[NI], float& lp);
+        };
+
+    ``x`` / ``g`` hold the chain's row in NI 16-byte pieces per lane (piece k of lane l = columns
+    4 (l + 64 k) .. + 3; guard with ``j < D``); the 64 lanes of a wave call ``eval`` together and ``lp`` must be
+    the same in every lane (``bjx::wave_sum``).  ``params``: a float32 device tensor handed to both functions
+    (data, hyper-parameters), or ``None``.  Rows of at most 1 024 floats, ``D % 4 == 0``.
+
+    The numerics of user code are the user's: compiled with ``-ffp-contract=off`` like the library, nothing is
+    checked against an oracle -- ``tests/test_device_target_gpu.py`` checks the machinery on a target whose
+    gradient autograd reproduces."""
+
+    def __init__(self, source: str, params: torch.Tensor | None = None, struct: str = "Target"):
+        self.source, self.struct = str(source), str(struct)
+        if params is not None:
+            if not (isinstance(params, torch.Tensor) and params.dtype == torch.float32 and params.is_contiguous()):
+                raise ValueError("params must be a contiguous float32 tensor")
+        self.params = params
+        self._code = None
+        self._module = None
+
+    def code_object(self) -> bytes:
+        """The compiled gfx950 code object (hiprtc cross-compiles: no GPU needed)."""
+        if self._code is None:
+            from . import rtc
+
+            self._code = rtc.compile(rtc.TARGET_TU % {"source": self.source, "struct": self.struct},
+                                     f"bjx_device_target_{self.struct}.hip")
+        return self._code
+
+    def module(self):
+        if self._module is None:
+            from . import rtc
+
+            self._module = rtc.Module(self.code_object())
+        return self._module
+
+    def _params_ptr(self, device):
+        if self.params is None:
+            return 0
+        if self.params.device != device:
+            raise ValueError(f"params live on {self.params.device}, the chains on {device}")
+        return self.params.data_ptr()
+
+    def _bjx_fused_target(self, dim: int):
+        return ("rtc", self) if dim % 4 == 0 and dim <= 1024 else None
+
+    def __call__(self, q):
+        import ctypes
+
+        from . import rtc
+
+        q, logp, g = self._alloc(q)
+        N, D = q.shape
+        if D % 4 != 0 or D > 1024:
+            raise ValueError("DeviceTarget: rows of at most 1 024 floats, a multiple of 4")
+        if N == 0:
+            return logp, g
+        grid = min((N + 3) // 4, 1 << 20)
+        self.module().launch(f"bjx_rtc_eval_{rtc.ni_for(D)}", grid, 256, _lib.current_stream(),
+                             ctypes.c_longlong(N), ctypes.c_longlong(D), ctypes.c_void_p(self._params_ptr(q.device)),
+                             ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(logp.data_ptr()),
+                             ctypes.c_void_p(g.data_ptr()))
+        return logp, g
