@@ -191,6 +191,7 @@ NUTS_AT = {"FLAGS": 0, "DA_REG": 1, "DA_INV_REG": 2, "DA_ETA": 3, "DA_COEF": 4, 
            "FIN_NM1": 6, "FIN_BETA_DATA": 7, "FIN_BETA_PREV": 8, "FIN_REG": 9}
 NUTS_ADAPT_COLS = 12
 NUTS_REC_WORDS = 32  # BJX_NUTS_REC_WORDS: packed per-chain record of the low-traffic tick kernels
+NUTS_TARGET_USER = 3  # BJX_TARGET_USER (include/bjx_nuts.h): kernels compiled at run time around a user target
 
 
 SIGNATURES.update({

@@ -10,9 +10,14 @@
 // mapping, so a lane only ever re-reads elements it wrote itself within a kernel.
 // Numerics contract as in bjx_device.h: explicit fmaf, fp64-accumulated reductions, fp64 scalar
 // transcendentals rounded once.
+#ifndef __HIPCC_RTC__
 #include "../../include/bjx_hip.h"
 #include "bjx_device.h"
 #include "bjx_host.h"
+#else  // compiled at run time around a user-written target (blackjax_amd/rtc.py): device code only
+#include "bjx_device.h"
+#include "../../include/bjx_nuts.h"
+#endif
 #include "bjx_targets_dev.h"
 
 using namespace bjx;
@@ -1756,6 +1761,17 @@ __device__ __forceinline__ void async_target_row(const bjx_nuts_t& nt, const bjx
     const int64_t j = ((int64_t)lane + 64 * k) * 4;
     if (j < nt.D) x[k] = ld4(qrow + j);
   }
+#ifdef BJX_RTC_USER_TARGET
+  if (ax.target_kind == BJX_TARGET_USER) {  // user-written device target (csrc/bjx_traj_dev.h interface)
+    typename BJX_RTC_USER_TARGET::template Ctx<NI> ctx;
+    BJX_RTC_USER_TARGET::template init<NI>(ctx, nt.D, ax.target_vec);
+    F4 g[NI];
+    float lp = 0.0f;
+    BJX_RTC_USER_TARGET::template eval<NI>(ctx, nt.D, ax.target_vec, x, true, g, lp);
+    target_store<NI>(nt.D, g, lp, logp_f + b, gf + b * nt.D);
+    return;
+  }
+#endif
   if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_row<NI>(nt.D, x, logp_f + b, gf + b * nt.D);
   else diag_gaussian_row<NI>(nt.D, x, ax.target_vec, logp_f + b, gf + b * nt.D);
 }
@@ -1843,6 +1859,10 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
   hs.hot = false;
   hs.pk_valid = false;
   hs.merged = false;
+#ifdef BJX_RTC_USER_TARGET
+  typename BJX_RTC_USER_TARGET::template Ctx<NI> user_ctx;
+  if (ax.target_kind == BJX_TARGET_USER) BJX_RTC_USER_TARGET::template init<NI>(user_ctx, nt.D, ax.target_vec);
+#endif
 #ifdef BJX_TICK_PROBE
   for (int k = 0; k < 12; ++k) hs.acc[k] = 0;
   hs.last = __builtin_readcyclecounter();
@@ -1894,6 +1914,11 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
       F4 x[NI], g[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) x[k] = F4{R.X[k].v[0], R.X[k].v[1], R.X[k].v[2], R.X[k].v[3]};
+#ifdef BJX_RTC_USER_TARGET
+      if (ax.target_kind == BJX_TARGET_USER)
+        BJX_RTC_USER_TARGET::template eval<NI>(user_ctx, nt.D, ax.target_vec, x, true, g, lp);
+      else
+#endif
       if (ax.target_kind == BJX_TARGET_NEAL_FUNNEL) funnel_eval<NI, FULL>(nt.D, x, g, lp);
       else diag_gaussian_eval<NI, FULL>(nt.D, x, ax.target_vec, g, lp);
       target_store<NI>(nt.D, g, lp, logp_f + b, gf + b * nt.D);
@@ -2058,6 +2083,7 @@ k_nuts_compact(bjx_nuts_t nt, int flag_slot, int64_t n_in_arg, const int32_t* id
   if (tid == 0) ctl[2] = base;
 }
 
+#ifndef __HIPCC_RTC__  // ---- host side from here on
 int check_nuts(const bjx_nuts_t* nt, const char* what) {
   if (!nt) { bjx_set_error("%s: null descriptor", what); return 1; }
   if (nt->N == 0 && nt->D > 0 && nt->max_depth >= 0 && nt->max_depth <= 30) return 0;  // callers return next
@@ -2112,8 +2138,10 @@ bool nuts_vec4_dense(const bjx_nuts_t* nt, P... extra) {
     else hipLaunchKernelGGL((KERNEL<1, false>), grid, dim3(kBlock), 0, stream, __VA_ARGS__);           \
   } while (0)
 
+#endif  // !__HIPCC_RTC__
 }  // namespace
 
+#ifndef __HIPCC_RTC__
 extern "C" {
 
 int bjx_nuts_init(void* stream, const bjx_nuts_t* nuts, const float* logp0, const float* ke0) {
@@ -2456,3 +2484,4 @@ extern "C" int bjx_debug_tick_probe(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+#endif  // !__HIPCC_RTC__

@@ -616,6 +616,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
     fused = False
+    rtc_module = None
     # with an engine-resident target a whole chunk of ticks is ONE launch for batches of at most this many
     # rows (default: always; 0 = one launch per tick).  Measured at C3: every chunk as
     # one launch 322 / 340 / 220 M/s at T = 20 / 100 / 400, only below 8 192 rows 239 / 254 / 181, one launch
@@ -628,8 +629,17 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             raise NotImplementedError(
                 "fuse_target=True needs a blackjax_amd.targets log-density the tick kernels can evaluate "
                 "(NealFunnel; DiagGaussian with D > 128), a diagonal metric, D % 4 == 0 and D <= 512")
-        run.target_kind, run.target_vec = int(spec[0]), _lib.ptr(spec[1])
-        fused_keep = spec[1]  # noqa: F841  (keeps the parameter vector alive for the run)
+        if spec[0] == "rtc":
+            # a user-written device target (targets.DeviceTarget): the multi-tick kernel of csrc/bjx_nuts.hip is
+            # compiled around it by hiprtc (blackjax_amd/rtc.py) and launched through the module API; every
+            # chunk of ticks is one launch (the library's one-tick kernels do not know the target)
+            rtc_target = spec[1]
+            rtc_module = rtc_target.nuts_module()
+            run.target_kind, run.target_vec = _lib.NUTS_TARGET_USER, rtc_target._params_ptr(dev) or None
+            multi_tick_rows = N
+        else:
+            run.target_kind, run.target_vec = int(spec[0]), _lib.ptr(spec[1])
+        fused_keep = spec[1]  # noqa: F841  (keeps the parameter vector / the compiled module alive for the run)
         fused = True
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
@@ -646,6 +656,18 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     can_record = use_graph is True or (use_graph == "auto" and is_capturable(logdensity_fn))
     if use_graph == "auto" and not can_record:
         warn_eager_driver(logdensity_fn, "nuts.run")
+
+    def multi_tick(run_k, qf_t, lp_t, g_t):
+        """One launch = ``run_k.ticks_per_launch`` ticks of every row of ``run_k`` (engine-resident target)."""
+        if rtc_module is None:
+            _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, ctypes.byref(run_k), qf_t.data_ptr(),
+                      lp_t.data_ptr(), g_t.data_ptr())
+        elif run_k.n_rows > 0:
+            from . import rtc
+
+            rtc_module.launch(rtc.nuts_kernel_name(D), min(int(run_k.n_rows), 1 << 20), 64, _lib.current_stream(),
+                              desc, run_k, ctypes.c_void_p(qf_t.data_ptr()), ctypes.c_void_p(lp_t.data_ptr()),
+                              ctypes.c_void_p(g_t.data_ptr()))
 
     def make_run(rows, n_rows):
         r = _lib.NutsAsync()
@@ -671,8 +693,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 # engine-resident target + one-launch ticks: the whole chunk is ONE launch, every wave
                 # advancing its chain n_ticks times (bjx_nuts_async_t.ticks_per_launch)
                 self.run.tick, self.run.ticks_per_launch = 0, n_ticks
-                _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
-                          logp_f.data_ptr(), gf.data_ptr())
+                multi_tick(self.run, self.qf, logp_f, gf)
                 return logp_f, gf
             for i in range(n_ticks):
                 self.run.tick = i & 1  # work-list parity (include/bjx_nuts.h); chunks have an even length
@@ -803,8 +824,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 lp, g_ = self.lp[k][:self.view], self.g[k][:self.view]
                 if self.view <= multi_tick_rows:  # the whole sequence as one launch
                     self.run[k].tick, self.run[k].ticks_per_launch = 0, n_ticks
-                    _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, qf_v.data_ptr(),
-                              lp.data_ptr(), g_.data_ptr())
+                    multi_tick(self.run[k], qf_v, lp, g_)
                     return
             for i in range(n_ticks):
                 if not fused:

@@ -137,3 +137,32 @@ BJX_RTC_KERNELS(4)
 
 def ni_for(dim: int) -> int:
     return 1 if dim <= 256 else (2 if dim <= 512 else 4)
+
+
+# The free-running NUTS multi-tick kernel (csrc/bjx_nuts.hip: async_multi_tick_row) around a user target:
+# hiprtc compiles the SAME source file the library is built from, device code only, with the user's struct as
+# BJX_RTC_USER_TARGET.  One wave per workgroup and row, two waves per SIMD, as k_nuts_async_multi.
+NUTS_TU = """#include "bjx_traj_dev.h"
+using namespace bjx;
+// ---- user source
+%(source)s
+// ---- the engine's NUTS device code around it
+#define BJX_RTC_USER_TARGET %(struct)s
+#include "bjx_nuts.hip"
+#define BJX_RTC_NUTS(NI_, FULL_, NAME_)                                                                      \\
+  extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))                   \\
+  NAME_(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, float* logp_f, float* gf) {                           \\
+    const int64_t n_rows = async_n_rows(ax);                                                                 \\
+    for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)                                                 \\
+      async_multi_tick_row<NI_, FULL_>(nt, ax, qf, logp_f, gf, b, ax.ticks_per_launch);                      \\
+  }
+BJX_RTC_NUTS(1, false, bjx_rtc_nuts_multi_1)
+BJX_RTC_NUTS(1, true, bjx_rtc_nuts_multi_1_full)
+BJX_RTC_NUTS(2, false, bjx_rtc_nuts_multi_2)
+BJX_RTC_NUTS(2, true, bjx_rtc_nuts_multi_2_full)
+"""
+
+
+def nuts_kernel_name(dim: int) -> str:
+    ni = 1 if dim <= 256 else 2
+    return f"bjx_rtc_nuts_multi_{ni}" + ("_full" if dim == 256 * ni else "")

@@ -134,6 +134,16 @@ class DeviceTarget(_Target):
             self._module = rtc.Module(self.code_object())
         return self._module
 
+    def nuts_module(self):
+        """The free-running NUTS multi-tick kernel compiled around this target (``run(..., fuse_target=True)``;
+        a separate, larger code object: ~10 s on first use)."""
+        if getattr(self, "_nuts_module", None) is None:
+            from . import rtc
+
+            self._nuts_module = rtc.Module(rtc.compile(rtc.NUTS_TU % {"source": self.source, "struct": self.struct},
+                                                       f"bjx_device_target_nuts_{self.struct}.hip"))
+        return self._nuts_module
+
     def _params_ptr(self, device):
         if self.params is None:
             return 0

@@ -20,7 +20,9 @@
 #ifndef BJX_NUTS_H
 #define BJX_NUTS_H
 
+#ifndef __HIPCC_RTC__ /* hiprtc has no system headers; blackjax_amd/rtc.py supplies the fixed-width names */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -289,7 +291,13 @@ typedef struct {
   const float* target_vec;
 } bjx_nuts_async_t;
 
-enum { BJX_TARGET_NONE = 0, BJX_TARGET_NEAL_FUNNEL = 1, BJX_TARGET_DIAG_GAUSSIAN = 2 };
+enum {
+  BJX_TARGET_NONE = 0,
+  BJX_TARGET_NEAL_FUNNEL = 1,
+  BJX_TARGET_DIAG_GAUSSIAN = 2,
+  BJX_TARGET_USER = 3 /* only in kernels compiled at run time around a user-written device target
+                         (blackjax_amd/rtc.py; target_vec = the user's parameter pointer); libbjxhip refuses it */
+};
 
 #define BJX_NUTS_REC_WORDS 32
 

@@ -121,3 +121,27 @@ def test_device_target_samples_its_density(dev):
         state, info = alg.step(key, state)
     np.testing.assert_allclose(state.position.var(0).cpu().numpy(), (1.0 / a).cpu().numpy(), rtol=0.15)
     assert float(info.acceptance_rate.mean()) > 0.7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,T", [(700, 256, 4), (90, 320, 5), (9000, 128, 3)])
+def test_device_target_inside_the_nuts_tick_kernel_equals_the_external_callable_path(dev, N, D, T):
+    """Free-running NUTS with the user's eval compiled into the multi-tick kernel of csrc/bjx_nuts.hip (hiprtc
+    compiles the library's own source file around it): positions, records and the final state are bit for bit
+    those of the run where the same object is an external callable between two ticks."""
+    tgt, _, a = _quartic(dev, D, c=0.6)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    alg = bjx.nuts(tgt, 0.35, (1.0 / a).contiguous(), max_num_doublings=6)
+    st0 = alg.init(q0)
+    key = bjx.random.key(13)
+    st_a, pos_a, info_a = alg.run(key, st0, T)
+    st_b, pos_b, info_b = alg.run(key, st0, T, fuse_target=True)
+    assert torch.equal(pos_a, pos_b)
+    for x, y in zip(st_a, st_b):
+        assert torch.equal(x, y)
+    for name in ("logdensity", "acceptance_rate", "energy", "num_integration_steps", "num_trajectory_expansions",
+                 "is_divergent", "is_turning"):
+        assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
+    assert int(info_a.num_integration_steps.max()) > int(info_a.num_integration_steps.min())
