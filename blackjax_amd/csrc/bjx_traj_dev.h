@@ -34,6 +34,8 @@ struct TrajArgs {
   uint8_t *is_acc_out, *is_div_out;
 };
 
+static_assert(sizeof(TrajArgs) == 216, "blackjax_amd/rtc.py mirrors this struct field for field (TrajArgs)");
+
 struct FunnelTarget {  // Neal's funnel (bjx_targets_dev.h)
   template <int NI> struct Ctx {};
   template <int NI> static __device__ __forceinline__ void init(Ctx<NI>&, int64_t, const float*) {}

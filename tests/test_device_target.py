@@ -56,6 +56,14 @@ def test_device_target_source_compiles_for_gfx950_without_a_gpu():
     assert "error" in str(e.value)
 
 
+def test_trajargs_mirror_has_the_size_the_header_asserts():
+    import ctypes
+    import re
+
+    hdr = open(bjx.rtc.CSRC + "/bjx_traj_dev.h").read()
+    assert int(re.search(r"sizeof\(TrajArgs\) == (\d+)", hdr).group(1)) == ctypes.sizeof(bjx.rtc.TrajArgs)
+
+
 def _quartic(dev, D, c=0.3):
     g = torch.Generator(device=dev)
     g.manual_seed(D)
@@ -145,3 +153,25 @@ def test_device_target_inside_the_nuts_tick_kernel_equals_the_external_callable_
                  "is_divergent", "is_turning"):
         assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
     assert int(info_a.num_integration_steps.max()) > int(info_a.num_integration_steps.min())
+
+
+@pytest.mark.gpu
+def test_device_target_through_the_free_running_warmup_and_step(dev):
+    """window_adaptation(nuts).run(free_running=True, fuse_target=True) and nuts(..., fuse_target=True).step with a
+    user target: the per-chain adaptation code of csrc/bjx_nuts.hip is part of the run-time kernel too."""
+    N, D, T = 300, 256, 40
+    tgt, _, a = _quartic(dev, D, c=0.6)
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    warm = bjx.window_adaptation(bjx.nuts, tgt, adaptation_info_fn=None, initial_step_size=0.3, max_num_doublings=6)
+    (st_a, par_a), _ = warm.run(bjx.random.key(2), q0, T, free_running=True)
+    (st_b, par_b), _ = warm.run(bjx.random.key(2), q0, T, free_running=True, fuse_target=True)
+    assert torch.equal(st_a.position, st_b.position)
+    assert torch.equal(par_a["step_size"], par_b["step_size"])
+    assert torch.equal(par_a["inverse_mass_matrix"], par_b["inverse_mass_matrix"])
+    imm = torch.ones(D, device=dev)
+    ref, fused = bjx.nuts(tgt, 0.3, imm, max_num_doublings=6), bjx.nuts(tgt, 0.3, imm, max_num_doublings=6, fuse_target=True)
+    sa, ia = ref.step(bjx.random.key(3), st_a)
+    sb, ib = fused.step(bjx.random.key(3), st_a)
+    assert torch.equal(sa.position, sb.position) and torch.equal(ia.num_integration_steps, ib.num_integration_steps)
