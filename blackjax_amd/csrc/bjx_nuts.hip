@@ -1839,17 +1839,6 @@ __device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_
   return pending || MODE == 0;
 }
 
-// The transition end as a REAL call (BJX_MULTI_END_CALL, a build-time experiment): inlined, its momentum draw and
-// adaptation code set the register count of the whole multi-tick kernel (256 VGPRs, two waves per SIMD).
-template <int NI>
-__device__ __attribute__((noinline)) int async_end2_chain_call(const bjx_nuts_t* nt, const bjx_nuts_async_t* ax,
-                                                               float* qf, int64_t c, int64_t b, int phase, int w_in,
-                                                               int* pending_out) {
-  int w = w_in;
-  *pending_out = async_end2_chain<NI>(*nt, *ax, qf, c, b, phase, w) ? 1 : 0;
-  return w;
-}
-
 // `k_ticks` ticks of one compact row in one launch (engine-resident target).  Only this wave touches the
 // chain during the launch.  A tick whose inputs are not in registers (the first one, the one after a
 // transition end) starts with a workgroup-scope fence and loads everything, exactly like async_tick2_row;
@@ -1908,26 +1897,14 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
       const int done = async_leaf2_chain<NI, true, FULL>(nt, ax, qf, lp, c, b, w, R, &hs);
       if (done) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#ifdef BJX_MULTI_END_CALL
-        int pend_i;
-        w = async_end2_chain_call<NI>(&nt, &ax, qf, c, b, 3, w, &pend_i);
-        pending = pend_i != 0;
-#else
         pending = async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
-#endif
         BJX_PROBE(&hs, 7);  // merge path + transition end
       } else {
         pending = in_regs = true;
         if (hs.merged) BJX_PROBE(&hs, 8);  // merge path + next doubling
       }
     } else if (phase == 3 || phase == 0) {
-#ifdef BJX_MULTI_END_CALL
-      int pend_i;
-      w = async_end2_chain_call<NI>(&nt, &ax, qf, c, b, phase, w, &pend_i);
-      pending = pend_i != 0;
-#else
       pending = async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
-#endif
     } else {
       break;  // the chain has completed all its transitions
     }
