@@ -42,8 +42,20 @@ class CompileError(RuntimeError):
     pass
 
 
+_CODE_CACHE: dict = {}  # source text -> code object (a process-wide cache: the NUTS unit takes seconds)
+
+
 def compile(source: str, name: str = "bjx_user.hip") -> bytes:  # noqa: A001  (mirrors hiprtcCompileProgram)
     """HIP source -> gfx950 code object.  The engine's device headers are on the include path."""
+    hit = _CODE_CACHE.get(source)
+    if hit is not None:
+        return hit
+    code = _compile(source, name)
+    _CODE_CACHE[source] = code
+    return code
+
+
+def _compile(source: str, name: str) -> bytes:
     rtc = _librtc()
     prog = ctypes.c_void_p()
     rc = rtc.hiprtcCreateProgram(ctypes.byref(prog), source.encode(), name.encode(), 0, None, None)
