@@ -73,3 +73,25 @@ def test_fused_trajectory_is_refused_where_it_does_not_apply(dev):
     dense = bjx.hmc(bjx.targets.NealFunnel(), 0.1, torch.eye(256, device=dev), 3, fuse_target=True)
     with pytest.raises(NotImplementedError):
         dense.step(bjx.random.key(0), dense.init(torch.zeros(4, 256, device=dev)))
+
+
+def test_fused_trajectory_random_shapes(dev):
+    """Row lengths that leave lanes / pieces partly empty (D = 132 ... 1 020, not multiples of 256), single
+    chains, long trajectories: still the bits of the default path."""
+    rng = np.random.default_rng(7)
+    for _ in range(8):
+        D = int(rng.integers(33, 256)) * 4 + 4
+        N = int(rng.choice([1, 2, 5, 63, 130]))
+        L = int(rng.integers(1, 12))
+        target = "gauss" if rng.random() < 0.5 else "funnel"
+        fn, q0, imm, eps = _case(dev, target, N, D, bool(rng.random() < 0.5))
+        ref = bjx.hmc(fn, eps, imm, L, chain_offset=11)
+        fused = bjx.hmc(fn, eps, imm, L, chain_offset=11, fuse_target=True)
+        st = ref.init(q0)
+        key = bjx.random.key(int(rng.integers(1, 1000)))
+        sa, ia = ref.step(key, st)
+        sb, ib = fused.step(key, st)
+        for a, b in zip(sa, sb):
+            assert torch.equal(a, b), (target, N, D, L)
+        assert torch.equal(ia.acceptance_rate, ib.acceptance_rate) and torch.equal(ia.energy, ib.energy)
+        assert torch.equal(ia.proposal.momentum, ib.proposal.momentum)

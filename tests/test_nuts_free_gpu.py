@@ -301,3 +301,28 @@ def test_step_through_the_free_running_engine_equals_the_lockstep_step(dev, N, D
             assert torch.equal(getattr(ia, name), getattr(ib, name)), (t, name)
         assert ib.momentum is None and ib.trajectory_leftmost_state is None
     assert int(ia.num_integration_steps.max()) > int(ia.num_integration_steps.min())
+
+
+def test_fused_target_random_shapes(dev):
+    """Engine-resident NUTS targets on row lengths that are not multiples of 256, tiny ensembles and shallow
+    trees: positions and tree sizes equal the external-callable run."""
+    import blackjax_amd as bjx
+
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        D = int(rng.integers(3, 128)) * 4
+        N = int(rng.choice([1, 3, 70, 300]))
+        depth = int(rng.integers(1, 7))
+        T = int(rng.integers(1, 6))
+        g = torch.Generator(device=dev)
+        g.manual_seed(D)
+        fn = bjx.targets.NealFunnel()
+        q0 = 0.2 * torch.randn(N, D, device=dev, generator=g)
+        alg = bjx.nuts(fn, 0.12, torch.ones(D, device=dev), max_num_doublings=depth)
+        st0 = alg.init(q0)
+        key = bjx.random.key(int(rng.integers(1, 1000)))
+        _, pos_a, info_a = alg.run(key, st0, T)
+        _, pos_b, info_b = alg.run(key, st0, T, fuse_target=True)
+        assert torch.equal(pos_a, pos_b), (N, D, depth, T)
+        assert torch.equal(info_a.num_integration_steps, info_b.num_integration_steps)
+        assert torch.equal(info_a.acceptance_rate, info_b.acceptance_rate)
