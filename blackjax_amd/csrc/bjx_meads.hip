@@ -28,7 +28,7 @@ using namespace bjx;
 
 namespace {
 
-constexpr int kSplits = 16;  // row splits of a fold per column block
+constexpr int kSplits = 64;  // row splits of a fold per column block (16 left one wave per SIMD: 0.9 TB/s)
 
 // partial[(k * kSplits + r) * 2 + s][c]: s = 0 sum, s = 1 sum of squares of (v - v_first) over the
 // rows of split r of fold k, v = x (WHITEN = false) or x / sd_k (WHITEN = true)
@@ -114,7 +114,7 @@ k_meads_build(int64_t N, int64_t n, int64_t D, const float* __restrict__ x, cons
 }
 
 // sum of squares of M floats per matrix, fp64: kFrobBlocks partials per matrix, combined in order
-constexpr int kFrobBlocks = 64;
+constexpr int kFrobBlocks = 256;
 __global__ void __launch_bounds__(256)
 k_meads_frob_partial(int64_t M, const float* __restrict__ G, double* __restrict__ partial) {
   __shared__ double sm[4];
@@ -122,11 +122,22 @@ k_meads_frob_partial(int64_t M, const float* __restrict__ G, double* __restrict_
   const float* gm = G + (int64_t)mtx * M;
   double s = 0.0;
   // a block sums a contiguous range so that the result does not depend on the launch geometry
-  const int64_t per = (M + kFrobBlocks - 1) / kFrobBlocks;
+  const int64_t per = (((M + kFrobBlocks - 1) / kFrobBlocks) + 3) & ~(int64_t)3;  // 16-byte pieces
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const double v = (double)gm[i];
-    s += v * v;
+  const bool vec = ((M & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
+  if (vec) {
+    for (int64_t i = lo + (int64_t)threadIdx.x * 4; i < hi; i += 1024) {  // hi - lo is a multiple of 4
+      const F4 v = ld4(gm + i);
+      s += (double)v.x * (double)v.x;
+      s += (double)v.y * (double)v.y;
+      s += (double)v.z * (double)v.z;
+      s += (double)v.w * (double)v.w;
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      const double v = (double)gm[i];
+      s += v * v;
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
@@ -134,50 +145,58 @@ k_meads_frob_partial(int64_t M, const float* __restrict__ G, double* __restrict_
   if (threadIdx.x == 0) partial[(int64_t)mtx * kFrobBlocks + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// One workgroup: per fold lambda_max of the two matrices, then the parameter table and its per-chain
-// broadcast.  frob_partial: (2, K, kFrobBlocks) [matrix mtx * K + k: mtx 0 = A, 1 = B of fold k].
+// maximum_eigenvalue of one (matrix, fold) pair per workgroup (meads_adaptation.py:790-817): lam_out[mtx * K + k].
+// frob_partial: (2, K, kFrobBlocks) [matrix mtx * K + k: mtx 0 = A, 1 = B of fold k].
+__global__ void __launch_bounds__(256)
+k_meads_lambda(int K, int64_t n, const double* __restrict__ frob_partial, const double* __restrict__ rowsq,
+               float* __restrict__ lam_out) {
+  __shared__ double red[3][4];
+  const int k = blockIdx.x, mtx = blockIdx.y;
+  const int64_t N = (int64_t)K * n;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // sum diag(S) and sum diag(S)^2 over the fold's rows, and the Frobenius partials (fixed order: thread
+  // strided, wave tree, 4 waves)
+  double d1 = 0.0, d2 = 0.0, fr = 0.0;
+  const double* rs = rowsq + (int64_t)mtx * N + (int64_t)k * n;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double v = rs[i];
+    d1 += v;
+    d2 += v * v;
+  }
+  const double* fp = frob_partial + ((int64_t)mtx * K + k) * kFrobBlocks;
+  for (int b = threadIdx.x; b < kFrobBlocks; b += 256) fr += fp[b];
+  d1 = wave_sum(d1);
+  d2 = wave_sum(d2);
+  fr = wave_sum(fr);
+  if (lane == 0) {
+    red[0][wv] = d1;
+    red[1][wv] = d2;
+    red[2][wv] = fr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sd1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double sd2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double frs = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    // lamda = sum diag / n ; lamda_sq = (sum S^2 - sum diag^2) / (n (n - 1))
+    const double lam = sd1 / (double)n;
+    const double lam_sq = (frs - sd2) / ((double)n * (double)(n - 1));
+    lam_out[mtx * K + k] = (float)(lam_sq / lam);
+  }
+}
+
+// One workgroup: the parameter table from the per-fold eigenvalue estimates and its per-chain broadcast.
 __global__ void __launch_bounds__(256)
 k_meads_params(int K, int64_t n, int64_t D, int64_t t, float multiplier, float slowdown,
-               const double* __restrict__ frob_partial, const double* __restrict__ rowsq,
-               const float* __restrict__ sd, float* __restrict__ eps_fold, float* __restrict__ alpha_fold,
-               float* __restrict__ delta_fold, float* __restrict__ sigma_fold, float* __restrict__ eps_pc,
-               float* __restrict__ alpha_pc, float* __restrict__ delta_pc, float* __restrict__ scale_pc) {
-  __shared__ double red[2][4];
+               const float* __restrict__ lam_in, const float* __restrict__ sd, float* __restrict__ eps_fold,
+               float* __restrict__ alpha_fold, float* __restrict__ delta_fold, float* __restrict__ sigma_fold,
+               float* __restrict__ eps_pc, float* __restrict__ alpha_pc, float* __restrict__ delta_pc,
+               float* __restrict__ scale_pc) {
   __shared__ float lam_max[2][64];  // [matrix][fold]
   __shared__ float eps_own[64], eps_r[64], al[64];
   const int64_t N = (int64_t)K * n;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = 0; k < K; ++k)
-    for (int mtx = 0; mtx < 2; ++mtx) {
-      // sum diag(S) and sum diag(S)^2 over the fold's rows (fixed order: thread strided, wave tree, 4 waves)
-      double d1 = 0.0, d2 = 0.0;
-      const double* rs = rowsq + (int64_t)mtx * N + (int64_t)k * n;
-      for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const double v = rs[i];
-        d1 += v;
-        d2 += v * v;
-      }
-      d1 = wave_sum(d1);
-      d2 = wave_sum(d2);
-      __syncthreads();
-      if (lane == 0) {
-        red[0][wv] = d1;
-        red[1][wv] = d2;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const double sd1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const double sd2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        double fr = 0.0;
-        const double* fp = frob_partial + ((int64_t)mtx * K + k) * kFrobBlocks;
-        for (int b = 0; b < kFrobBlocks; ++b) fr += fp[b];
-        // meads_adaptation.py:812-817: lamda = sum diag / n ; lamda_sq = (sum S^2 - sum diag^2) / (n (n - 1))
-        const double lam = sd1 / (double)n;
-        const double lam_sq = (fr - sd2) / ((double)n * (double)(n - 1));
-        lam_max[mtx][k] = (float)(lam_sq / lam);
-      }
-      __syncthreads();
-    }
+  if (threadIdx.x < 2 * K) lam_max[threadIdx.x / K][threadIdx.x % K] = lam_in[threadIdx.x];
+  __syncthreads();
   if (threadIdx.x < K) {
     const int k = threadIdx.x;
     const float e = multiplier / sqrtf(lam_max[0][k]);  // 583-588
@@ -204,23 +223,29 @@ k_meads_params(int K, int64_t n, int64_t D, int64_t t, float multiplier, float s
     const int64_t k = i / D, j = i - k * D;
     sigma_fold[i] = sd[((k + K - 1) % K) * D + j];
   }
-  for (int64_t i = threadIdx.x; i < N; i += 256) {
-    const int k = (int)(i / n);
-    eps_pc[i] = eps_r[k];
-    alpha_pc[i] = al[k];
-    delta_pc[i] = al[k] / 2.0f;
-  }
+  // the per-chain broadcasts of (eps, alpha, delta) ride along in k_meads_scale_rows (one wave per chain)
+  (void)N;
+  (void)eps_pc;
+  (void)alpha_pc;
+  (void)delta_pc;
   (void)scale_pc;
 }
 
 // scale_pc[row] = sd[(fold(row) - 1) mod K]: the per-chain inverse scale GHMC squares (one wave per row)
 __global__ void __launch_bounds__(256)
 k_meads_scale_rows(int64_t N, int64_t n, int64_t D, int K, const float* __restrict__ sd,
-                   float* __restrict__ scale_pc, float* __restrict__ imm_pc) {
+                   float* __restrict__ scale_pc, float* __restrict__ imm_pc, const float* __restrict__ eps_fold,
+                   const float* __restrict__ alpha_fold, const float* __restrict__ delta_fold,
+                   float* __restrict__ eps_pc, float* __restrict__ alpha_pc, float* __restrict__ delta_pc) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   const int64_t k = row / n;
+  if (lane == 0) {  // jnp.repeat of the fold table (meads_adaptation.py:636-640)
+    eps_pc[row] = eps_fold[k];
+    alpha_pc[row] = alpha_fold[k];
+    delta_pc[row] = delta_fold[k];
+  }
   const float* s = sd + ((k + K - 1) % K) * D;
   for (int64_t j = lane; j < D; j += 64) {
     const float v = s[j];
@@ -236,7 +261,7 @@ extern "C" {
 size_t bjx_meads_workspace_bytes(int64_t K, int64_t D) {
   const size_t moments = (size_t)K * kSplits * 2 * (size_t)D * sizeof(double);
   const size_t frob = (size_t)2 * K * kFrobBlocks * sizeof(double);
-  return moments + frob + 256;
+  return moments + frob + 2 * (size_t)K * sizeof(float) + 256;
 }
 
 int bjx_meads_fold_moments(void* stream, int64_t K, int64_t n, int64_t D, const float* x, void* workspace,
@@ -278,12 +303,15 @@ int bjx_meads_fold_params(void* stream, int64_t K, int64_t n, int64_t D, int64_t
   double* frob = (double*)((char*)workspace + (size_t)K * kSplits * 2 * (size_t)D * sizeof(double));
   hipLaunchKernelGGL(k_meads_frob_partial, dim3(kFrobBlocks, (unsigned)(2 * K)), dim3(256), 0, s, gram_elems, gram,
                      frob);
+  float* lam = (float*)(frob + (size_t)2 * K * kFrobBlocks);
+  hipLaunchKernelGGL(k_meads_lambda, dim3((unsigned)K, 2), dim3(256), 0, s, (int)K, n, (const double*)frob, rowsq, lam);
   hipLaunchKernelGGL(k_meads_params, dim3(1), dim3(256), 0, s, (int)K, n, D, t, step_size_multiplier,
-                     damping_slowdown, (const double*)frob, rowsq, sd, eps_fold, alpha_fold, delta_fold, sigma_fold,
+                     damping_slowdown, (const float*)lam, sd, eps_fold, alpha_fold, delta_fold, sigma_fold,
                      eps_pc, alpha_pc, delta_pc, (float*)nullptr);
   const int64_t N = K * n;
   hipLaunchKernelGGL(k_meads_scale_rows, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, N, n, D, (int)K, sd,
-                     (float*)nullptr, imm_pc);
+                     (float*)nullptr, imm_pc, (const float*)eps_fold, (const float*)alpha_fold,
+                     (const float*)delta_fold, eps_pc, alpha_pc, delta_pc);
   return bjx_check_launch("bjx_meads_fold_params");
 }
 

@@ -155,8 +155,8 @@ def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
         q_new, p_new, g_new = torch.empty_like(q0), torch.empty_like(q0), torch.empty_like(q0)
         logp_new, sl_new = torch.empty_like(logp0), torch.empty_like(sl_prev)
         acc_rate, energy = torch.empty_like(logp0), torch.empty_like(logp0)
-        is_acc = torch.empty(N, dtype=torch.uint8, device=dev)
-        is_div = torch.empty(N, dtype=torch.uint8, device=dev)
+        is_acc = torch.empty(N, dtype=torch.bool, device=dev)  # one byte per flag, 0 / 1: written as uint8
+        is_div = torch.empty(N, dtype=torch.bool, device=dev)
         p_end = torch.empty_like(q0)
         s_lo, s_hi = (0, 0) if skip_chains is None else (int(skip_chains[0]), int(skip_chains[1]))
         _lib.call("bjx_ghmc_finish", _lib.current_stream(), N, D, eps, _lib.ptr(eps_pc), imm.data_ptr(), imm_stride,
@@ -165,7 +165,7 @@ def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
                   g1.data_ptr(), s_lo, s_hi, q_new.data_ptr(), p_new.data_ptr(), logp_new.data_ptr(),
                   g_new.data_ptr(), sl_new.data_ptr(), acc_rate.data_ptr(), is_acc.data_ptr(), is_div.data_ptr(),
                   energy.data_ptr(), p_end.data_ptr())
-        info = HMCInfo(p, acc_rate, is_acc.bool(), is_div.bool(), energy,
+        info = HMCInfo(p, acc_rate, is_acc, is_div, energy,
                        IntegratorState(q1, p_end, logp1, g1), 1)
         return GHMCState(q_new, p_new, logp_new, g_new, sl_new), info
 
