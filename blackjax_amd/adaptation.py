@@ -228,7 +228,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                       initial_step_size: float = 1.0, target_acceptance_rate: float = 0.80,
                       adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
                       integrator=integrators.velocity_verlet, _schedule_fn: Optional[Callable] = None,
-                      **extra_parameters) -> AdaptationAlgorithm:
+                      fuse_target: bool = False, **extra_parameters) -> AdaptationAlgorithm:
     """blackjax/adaptation/window_adaptation.py:296-444.  ``algorithm`` is ``blackjax_amd.hmc`` or
     ``blackjax_amd.nuts``; ``extra_parameters`` are forwarded to its kernel (e.g.
     ``num_integration_steps=...``).  ``adaptation_info_fn=None`` records nothing.
@@ -240,7 +240,12 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
     ``adaptation_info_fn`` or integrator raises rather than silently ignoring them.
     ``parameters["inverse_mass_matrix"]`` is a ``metrics.PerChainDiagTensor`` (an ``(N, D)`` tensor
     tagged as per-chain diagonals) so that ``algorithm(logdensity_fn, **parameters)`` is
-    unambiguous even when ``N == D``."""
+    unambiguous even when ``N == D``.
+
+    ``fuse_target=True`` with ``blackjax_amd.hmc`` (engine-resident or ``targets.DeviceTarget`` log-densities,
+    diagonal mass matrix, velocity Verlet; OUTSIDE the external-callable contract): every warm-up transition is
+    one launch (``hmc.build_fused_target_kernel``); results equal the default warm-up's bit for bit.  For NUTS
+    the switch belongs to ``run(..., free_running=True, fuse_target=True)``."""
     if initial_inverse_mass_matrix is not None:
         imm0 = torch.as_tensor(initial_inverse_mass_matrix)
         if is_mass_matrix_diagonal:
@@ -256,6 +261,18 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         raise ValueError(
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
     mcmc_kernel = algorithm.build_kernel(integrator)  # the sampler validates the integrator
+    if fuse_target:
+        from .hmc import build_fused_target_kernel as _fused, build_kernel as _hmc_build_kernel
+
+        if getattr(algorithm, "build_kernel", None) is not _hmc_build_kernel:
+            raise NotImplementedError("window_adaptation(fuse_target=True) is the hmc switch; NUTS takes "
+                                      "run(..., free_running=True, fuse_target=True)")
+        if integrator is not integrators.velocity_verlet or not is_mass_matrix_diagonal:
+            raise NotImplementedError("fuse_target=True: velocity Verlet and a diagonal mass matrix")
+        fused_kwargs = {}
+        if "divergence_threshold" in extra_parameters:
+            fused_kwargs["divergence_threshold"] = extra_parameters["divergence_threshold"]
+        mcmc_kernel = _fused(**fused_kwargs)
 
     def _run_free_running(rng_key, state, imm, ss, eps0, num_steps, chain_offset, fuse_target=False):
         """The same warm-up with free-running chains (nuts.run_free, include/bjx_nuts.h adapt_*): every

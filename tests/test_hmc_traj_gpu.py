@@ -95,3 +95,18 @@ def test_fused_trajectory_random_shapes(dev):
             assert torch.equal(a, b), (target, N, D, L)
         assert torch.equal(ia.acceptance_rate, ib.acceptance_rate) and torch.equal(ia.energy, ib.energy)
         assert torch.equal(ia.proposal.momentum, ib.proposal.momentum)
+
+
+def test_window_adaptation_hmc_with_an_engine_resident_target(dev):
+    """window_adaptation(hmc, fuse_target=True): every warm-up transition is one launch; the adapted step sizes,
+    metrics and the final state equal the default warm-up's bit for bit."""
+    N, D, T = 200, 256, 70
+    fn, q0, _, _ = _case(dev, "gauss", N, D, False)
+    kw = dict(adaptation_info_fn=None, initial_step_size=0.2, num_integration_steps=6)
+    (st_a, par_a), _ = bjx.window_adaptation(bjx.hmc, fn, **kw).run(bjx.random.key(4), q0, T)
+    (st_b, par_b), _ = bjx.window_adaptation(bjx.hmc, fn, fuse_target=True, **kw).run(bjx.random.key(4), q0, T)
+    assert torch.equal(st_a.position, st_b.position)
+    assert torch.equal(par_a["step_size"], par_b["step_size"])
+    assert torch.equal(par_a["inverse_mass_matrix"], par_b["inverse_mass_matrix"])
+    with pytest.raises(NotImplementedError):
+        bjx.window_adaptation(bjx.nuts, fn, fuse_target=True)
