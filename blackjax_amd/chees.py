@@ -350,7 +350,7 @@ def chees_adaptation(logdensity_fn: Callable, num_chains: int, *, jitter_generat
                      mass_matrix_estimation: Optional[str] = None,
                      mass_matrix_window_fraction: float = 0.5, _whiten_criterion: bool = True,
                      _length_floor: bool = True, chain_offset: int = 0,
-                     process_group=None) -> AdaptationAlgorithm:
+                     process_group=None, fuse_target: bool = False) -> AdaptationAlgorithm:
     """blackjax/adaptation/chees_adaptation.py:574-1025.
 
     ``num_chains`` is the number of chains THIS process holds (``positions.shape[0]``);
@@ -360,7 +360,11 @@ def chees_adaptation(logdensity_fn: Callable, num_chains: int, *, jitter_generat
 
     ``run(rng_key, positions, step_size, optim, num_steps=1000, *, max_sampling_steps=1000)`` returns
     ``(AdaptationResults(last_states, parameters), info)`` with ``parameters`` ready for
-    ``blackjax_amd.dynamic_hmc(logdensity_fn, **parameters)``."""
+    ``blackjax_amd.dynamic_hmc(logdensity_fn, **parameters)``.
+
+    ``fuse_target=True`` (engine-resident or ``targets.DeviceTarget`` log-densities; OUTSIDE the external-callable
+    contract): every warm-up transition is one launch (``hmc.build_fused_target_kernel``), the pooled statistics
+    are unchanged; results equal the default warm-up's bit for bit."""
     if mass_matrix_estimation not in (None, "diagonal"):
         raise ValueError("mass_matrix_estimation must be None or 'diagonal', got "
                          f"{mass_matrix_estimation!r}.")
@@ -391,7 +395,7 @@ def chees_adaptation(logdensity_fn: Callable, num_chains: int, *, jitter_generat
             jitter_gn = lambda i: f32(f32(halton_sequence(int(i), max_bits) * ja) + jb)
             integration_steps_fn = halton_steps_fn(max_bits, float(jitter_amount))
 
-        kernel = hmc.build_kernel()
+        kernel = hmc.build_fused_target_kernel() if fuse_target else hmc.build_kernel()
         init, update = base(jitter_gn, next_random_arg_fn, optim, target_acceptance_rate, decay_rate,
                             max_leapfrog_steps, _whiten_criterion, process_group=process_group)
         window_start = int(mass_matrix_window_fraction * num_steps) if estimate_mass_matrix else num_steps

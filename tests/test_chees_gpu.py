@@ -294,3 +294,28 @@ def test_pool_reductions_full_size(dev):
     both = torch.cat([props, inits], 0).double()
     np.testing.assert_allclose(t2n(blk.mean), t2n(both.mean(0)), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(t2n(blk.m2) / (2 * N - 1), t2n(both.var(0)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("kwargs", [{}, {"mass_matrix_estimation": "diagonal"}])
+def test_chees_warmup_with_an_engine_resident_target(dev, kwargs):
+    """chees_adaptation(..., fuse_target=True): every warm-up transition is one launch
+    (hmc.build_fused_target_kernel); step sizes, trajectory lengths, positions and the returned parameters equal
+    the default warm-up's bit for bit."""
+    N, D, num_steps = 256, 256, 40
+    std = torch.as_tensor((10.0 ** np.linspace(-0.5, 0.7, D)).astype(f32), device=dev)
+    fn = bjx.targets.DiagGaussian((1.0 / (std * std)).contiguous())
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    q0 = std * torch.randn(N, D, device=dev, generator=g)
+    out = []
+    for fuse in (False, True):
+        warm = bjx.chees_adaptation(fn, N, fuse_target=fuse, **kwargs)
+        (st, par), info = warm.run(prng.key(11), q0, 0.1, bjx.optim.adam(0.5, b1=0, b2=0.95), num_steps)
+        out.append((st, par, info))
+    (st_a, par_a, info_a), (st_b, par_b, info_b) = out
+    assert torch.equal(st_a.position, st_b.position)
+    assert par_a["step_size"] == par_b["step_size"]
+    assert par_a["integration_steps_params"] == par_b["integration_steps_params"]
+    assert torch.equal(par_a["inverse_mass_matrix"], par_b["inverse_mass_matrix"])
+    assert torch.equal(info_a.adaptation_state.trajectory_length, info_b.adaptation_state.trajectory_length)
+    assert torch.equal(info_a.info.acceptance_rate, info_b.info.acceptance_rate)

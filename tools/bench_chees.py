@@ -30,6 +30,9 @@ ap.add_argument("--num-steps", type=int, default=60)
 ap.add_argument("--step-size", type=float, default=0.05)
 ap.add_argument("--mass-matrix", action="store_true", help='mass_matrix_estimation="diagonal" (no length floor)')
 ap.add_argument("--length-floor", action="store_true", help="also the slow-direction length floor (D x D block)")
+ap.add_argument("--fuse-target", action="store_true",
+                help="every warm-up transition as ONE launch with the built-in Gaussian evaluated in registers "
+                     "(engine-resident target: OUTSIDE the external-callable contract, a separately labelled figure)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 N, D = args.chains, args.dim
@@ -40,7 +43,7 @@ if args.mass_matrix or args.length_floor:
     kw = {"mass_matrix_estimation": "diagonal", "_length_floor": bool(args.length_floor),
           "mass_matrix_window_fraction": 0.25}
 warm = bjx.chees_adaptation(fn, N, adaptation_info_fn=bjx.adaptation.get_filter_adapt_info_fn(
-    set(), {"num_integration_steps"}, {"step_size", "trajectory_length"}), **kw)
+    set(), {"num_integration_steps"}, {"step_size", "trajectory_length"}), fuse_target=args.fuse_target, **kw)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
 q0 = sig * torch.randn(N, D, device=dev, generator=g)
