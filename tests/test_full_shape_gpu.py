@@ -70,12 +70,21 @@ def test_c2_full_shape_all_chains_vs_c_port_and_subset_vs_numpy(dev):
     st_s = ohmc.HMCState(q[idx].copy(), lp[idx].copy(), g[idx].copy())
 
     alg = bjx.hmc(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), eps, dev_t(imm, dev), L)
+    # the opt-in engine-resident path (one launch per transition, csrc/bjx_traj.hip) on the same keys: held
+    # against the oracle directly, all chains
+    alg_f = bjx.hmc(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), eps, dev_t(imm, dev), L, fuse_target=True)
     st_g = alg.init(dev_t(q0, dev))
+    st_f = st_g
     assert np.array_equal(t2n(st_g.logdensity), lp)
     n_rej = 0
     for k in prng.split(prng.key(0), T):
         st_g, info_g = alg.step(k, st_g)
+        st_f, info_f = alg_f.step(k, st_f)
         acc, ia, idv = cport.hmc_diag_gaussian_step(k, q, lp, g, eps, imm, inv_var, L)
+        assert np.array_equal(t2n(info_f.is_accepted), ia) and np.array_equal(t2n(info_f.acceptance_rate), acc)
+        assert np.array_equal(t2n(st_f.position), q) and np.array_equal(t2n(st_f.logdensity), lp)
+        assert np.array_equal(t2n(st_f.logdensity_grad), g)
+        assert torch.equal(info_f.proposal.momentum, info_g.proposal.momentum)
         st_s, info_s = ohmc.kernel(None, st_s, fn_o, f32(eps), imm, L,
                                    chain_keys_override=prng.split_at(k, idx))
         # every chain vs the C port: decisions, acceptance probabilities, positions, gradients
@@ -114,6 +123,12 @@ def test_c3_full_shape_nuts_subset_vs_numpy(dev):
     run_key = prng.key(11)
     keys = prng.split(run_key, T)
     final, positions, rinfo = alg.run(run_key, st0, T)  # free-running chains, step-major keys
+    # the opt-in engine-resident path (funnel evaluated inside the multi-tick kernel): the same run, every chain
+    final_f, positions_f, rinfo_f = alg.run(run_key, st0, T, fuse_target=True)
+    assert torch.equal(positions_f, positions) and torch.equal(final_f.logdensity_grad, final.logdensity_grad)
+    for name in ("num_integration_steps", "num_trajectory_expansions", "is_turning", "is_divergent", "energy",
+                 "acceptance_rate", "logdensity"):
+        assert torch.equal(getattr(rinfo_f, name), getattr(rinfo, name)), name
     total_leaves = rinfo.num_integration_steps.sum(0)
     deepest = np.concatenate([t2n(torch.topk(total_leaves, 8).indices),
                               t2n(torch.topk(rinfo.num_integration_steps.max(0).values, 8).indices)])
