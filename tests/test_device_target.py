@@ -175,3 +175,22 @@ def test_device_target_through_the_free_running_warmup_and_step(dev):
     sa, ia = ref.step(bjx.random.key(3), st_a)
     sb, ib = fused.step(bjx.random.key(3), st_a)
     assert torch.equal(sa.position, sb.position) and torch.equal(ia.num_integration_steps, ib.num_integration_steps)
+
+
+def test_fuse_target_switches_validate_their_arguments_without_a_gpu():
+    """Construction-time checks of the opt-in engine-resident switches (no device work involved)."""
+    fn = lambda q: -0.5 * (q * q).sum(-1)  # noqa: E731
+    with pytest.raises(NotImplementedError):
+        bjx.hmc(fn, 0.1, torch.ones(256), 3, fuse_target=True, integrator=bjx.integrators.mclachlan)
+    with pytest.raises(NotImplementedError):
+        bjx.nuts(fn, 0.1, torch.ones(256), fuse_target=True, integrator=bjx.integrators.yoshida)
+    with pytest.raises(NotImplementedError):
+        bjx.window_adaptation(bjx.nuts, fn, fuse_target=True)
+    with pytest.raises(NotImplementedError):
+        bjx.window_adaptation(bjx.hmc, fn, fuse_target=True, is_mass_matrix_diagonal=False, num_integration_steps=3)
+    with pytest.raises(ValueError):
+        bjx.targets.DeviceTarget(QUARTIC, params=torch.ones(4, dtype=torch.float64))
+    tgt = bjx.targets.DeviceTarget(QUARTIC)
+    assert tgt._bjx_fused_target(256) == ("rtc", tgt) and tgt._bjx_fused_target(2048) is None
+    assert bjx.rtc.nuts_kernel_name(256) == "bjx_rtc_nuts_multi_1_full" and bjx.rtc.nuts_kernel_name(320) == "bjx_rtc_nuts_multi_2"
+    assert bjx.rtc.ni_for(132) == 1 and bjx.rtc.ni_for(512) == 2 and bjx.rtc.ni_for(1024) == 4
