@@ -194,3 +194,10 @@ def test_fuse_target_switches_validate_their_arguments_without_a_gpu():
     assert tgt._bjx_fused_target(256) == ("rtc", tgt) and tgt._bjx_fused_target(2048) is None
     assert bjx.rtc.nuts_kernel_name(256) == "bjx_rtc_nuts_multi_1_full" and bjx.rtc.nuts_kernel_name(320) == "bjx_rtc_nuts_multi_2"
     assert bjx.rtc.ni_for(132) == 1 and bjx.rtc.ni_for(512) == 2 and bjx.rtc.ni_for(1024) == 4
+
+
+def test_nuts_translation_unit_compiles_for_gfx950_without_a_gpu():
+    """hiprtc compiles csrc/bjx_nuts.hip itself (device part) around the user's struct: guards against a host
+    include or host-only construct slipping into the device part of that file."""
+    code = bjx.rtc.compile(bjx.rtc.NUTS_TU % {"source": QUARTIC, "struct": "Target"}, "nuts_user_test.hip")
+    assert code[:4] == b"\x7fELF" and b"bjx_rtc_nuts_multi_1_full" in code
