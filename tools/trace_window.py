@@ -25,6 +25,11 @@ for r in win:
 span = (int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])) / 1e3
 n_anchor = sum(1 for r in win if anchor in r["Kernel_Name"])
 print(f"window: {len(win)} kernels, {span:.0f} us, {n_anchor} x '{anchor}' -> {span / max(n_anchor, 1):.2f} us per anchor kernel")
+starts = [int(r["Start_Timestamp"]) for r in win if anchor in r["Kernel_Name"]]
+per = sorted((b - a) / 1e3 for a, b in zip(starts, starts[1:]))
+if per:
+    print(f"start-to-start period of the anchor kernel: median {per[len(per) // 2]:.2f} us, p10 {per[len(per) // 10]:.2f}, "
+          f"p90 {per[len(per) * 9 // 10]:.2f}, mean {sum(per) / len(per):.2f}")
 for k in sorted(dur, key=lambda k: -sum(dur[k])):
     d, g = dur[k], gap[k] or [0.0]
     print(f"{k:66s} x{len(d):5d} dur median {statistics.median(d):6.2f} mean {sum(d)/len(d):6.2f}  gap median "
