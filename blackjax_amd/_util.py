@@ -84,6 +84,10 @@ def _one(like: torch.Tensor) -> torch.Tensor:
     key = (like.device, like.dtype)
     t = _ONES.get(key)
     if t is None:
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a tensor created under capture lives in the graph's private pool and its fill is only
+            # recorded, never run: do not cache it -- the recorded graph owns this one
+            return torch.ones((), device=like.device, dtype=like.dtype)
         t = _ONES[key] = torch.ones((), device=like.device, dtype=like.dtype)
     return t
 

@@ -261,6 +261,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         raise ValueError(
             f"imm_shrinkage_to_previous must be >= 0.0, got {imm_shrinkage_to_previous}")
     mcmc_kernel = algorithm.build_kernel(integrator)  # the sampler validates the integrator
+    step_extra = extra_parameters  # what every step of the kernel receives
     if fuse_target:
         from .hmc import build_fused_target_kernel as _fused, build_kernel as _hmc_build_kernel
 
@@ -271,7 +272,10 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             raise NotImplementedError("fuse_target=True: velocity Verlet and a diagonal mass matrix")
         fused_kwargs = {}
         if "divergence_threshold" in extra_parameters:
+            # a build-time argument of the fused kernel, not a per-step one: it stays in the
+            # returned parameters, but is not forwarded to every step
             fused_kwargs["divergence_threshold"] = extra_parameters["divergence_threshold"]
+            step_extra = {k: v for k, v in extra_parameters.items() if k != "divergence_threshold"}
         mcmc_kernel = _fused(**fused_kwargs)
 
     def _run_free_running(rng_key, state, imm, ss, eps0, num_steps, chain_offset, fuse_target=False):
@@ -360,7 +364,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             if is_mass_matrix_diagonal and imm_arg.ndim == 2:  # per-chain diagonals, not a dense matrix
                 imm_arg = metrics.PerChainDiag(imm_arg)
             state, info = mcmc_kernel(ChainMajorKey(run_key, t), state, logdensity_fn, ws.step_size,
-                                      imm_arg, chain_offset=chain_offset, **extra_parameters)
+                                      imm_arg, chain_offset=chain_offset, **step_extra)
             imm_state = ws.imm_state
             if stage == 1:  # slow_update: staged_adaptation.py:200-231
                 imm_state = MassMatrixAdaptationState(

@@ -953,21 +953,24 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
   if (ga.b_symmetric && aligned && full) {
     static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
     // staggered start: only when the launch is at most one round of resident workgroups (2 per CU)
+#ifdef BJX_DENSE_PROBE
     static const double stagger_us = [] { const char* e = getenv("BJX_DENSE_STAGGER_US"); return e ? atof(e) : 0.0; }();
     static const int stagger_mode = [] { const char* e = getenv("BJX_DENSE_STAGGER_MODE"); return e ? atoi(e) : 0; }();
     if (stagger_us > 0.0 && grid.x <= 512u && grid.x >= 2u) {
       ga.stagger_ticks = (int32_t)(stagger_us * 100.0);
       ga.stagger_mode = stagger_mode;
     }
+#endif
 #define BJX_LAUNCH_TN(E, K)                                                                   \
   do {                                                                                        \
     if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga); \
     else hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga);         \
   } while (0)
     int kicks = ga.G ? ga.n_kicks : 0;
-    // BJX_DENSE_ABLATE (measurement aid, RESULTS INVALID): where do the microseconds of the fused launch go?
-    // bit 0: no store of the kicked momentum; bit 1: store-only epilogue (no read of q, no drift);
-    // bit 2: no kick prologue (no gradient loads).  DESIGN.md section 8, round 3.
+#ifdef BJX_DENSE_PROBE
+    // BJX_DENSE_ABLATE (measurement aid, RESULTS INVALID -- compiled only into PROBE builds, `make
+    // CXXFLAGS+=-DBJX_DENSE_PROBE`; the shipped library ignores the variable): bit 0 no store of the kicked
+    // momentum; bit 1 store-only epilogue (no read of q, no drift); bit 2 no kick prologue (no gradient loads).
     static const int ablate = [] { const char* e = getenv("BJX_DENSE_ABLATE"); return e ? atoi(e) : 0; }();
     if (ablate) {
       if (ablate & 1) ga.A_out = nullptr;
@@ -977,6 +980,7 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
       }
       if (ablate & 4) kicks = 0;
     }
+#endif
     if (epi == EPI_STORE) {
       if (kicks == 0) BJX_LAUNCH_TN(EPI_STORE, 0); else if (kicks == 1) BJX_LAUNCH_TN(EPI_STORE, 1); else BJX_LAUNCH_TN(EPI_STORE, 2);
     } else {

@@ -39,6 +39,21 @@ __global__ void __launch_bounds__(kBlock) k_rng_uniform(Key key, int64_t off, in
   if (i < N) u[i] = key_uniform(key_child(key, (uint64_t)(i + off)));
 }
 
+// the key used AS IS (no per-chain child): z[j] = normal(key, (D,))[j], u = uniform(key, ()),
+// children[i] = split(key, .)[i] -- the probe the doc-sourced jax.random pins are held against
+__global__ void __launch_bounds__(kBlock) k_rng_key_probe(Key key, int64_t D, float* __restrict__ z,
+                                                           float* __restrict__ u, int64_t n_children,
+                                                           uint32_t* __restrict__ children) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D) z[i] = normal_from_bits(key_bits32(key, (uint64_t)i));
+  if (i < n_children) {
+    const Key c = key_child(key, (uint64_t)i);
+    children[2 * i] = c.k0;
+    children[2 * i + 1] = c.k1;
+  }
+  if (i == 0 && u) u[0] = key_uniform(key);
+}
+
 // ------------------------------------------------------------------------------ momentum draw
 // p0 = (1/sqrt(imm)) * normal(km, (D,)) ; ke0 = 0.5 * sum (imm*p0)*p0   (fp64 accumulate)
 // KICK: the opening half kick and the drift of the trajectory's first leapfrog in the same launch (the
@@ -662,6 +677,16 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
   hipLaunchKernelGGL(k_rng_uniform, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, Key{key0, key1}, chain_offset, N, u_out);
   return bjx_check_launch("bjx_rng_uniform");
+}
+
+int bjx_rng_key_probe(void* stream, uint32_t key0, uint32_t key1, int64_t D, float* z_out, float* u_out,
+                      int64_t n_children, uint32_t* children_out) {
+  BJX_CHECK_ARG(D >= 0 && n_children >= 0 && (D == 0 || z_out) && (n_children == 0 || children_out),
+                "bjx_rng_key_probe: bad arguments");
+  const int64_t n = D > n_children ? D : n_children;
+  hipLaunchKernelGGL(k_rng_key_probe, dim3((unsigned)((n > 0 ? n : 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     (hipStream_t)stream, Key{key0, key1}, D, z_out, u_out, n_children, children_out);
+  return bjx_check_launch("bjx_rng_key_probe");
 }
 
 int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

@@ -237,15 +237,15 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         else:
             # dense metric.  One matrix per chain, and small shared-matrix problems: fp64-accumulated
             # matrix-vector kernels throughout (bit-compatible with the oracle's "f64" mode).  A SHARED
-            # matrix on a batch large enough to fill GEMM tiles (dense_gemm="auto": >= 512 chains and
-            # D >= 128; True forces it): every product v = M^{-1} p of a leaf is ONE fp32 MFMA GEMM
+            # matrix with D >= 128 (dense_gemm="auto"; True forces it at any D): every product v = M^{-1} p of a leaf is ONE fp32 MFMA GEMM
             # over the live rows (bjx_nuts_dense_kick -> bjx_dense_apply_imm -> kernels reading
             # bjx_nuts_t.v_pre) instead of D^2 words per chain -- the oracle's "f32chain" mode
             # (metrics.py:263-304 with util.py:58-61).
             from . import dense
 
-            gemm = metric.kind == "dense" and (dense_gemm is True or (dense_gemm == "auto" and N >= 512
-                                                                      and D >= 128))
+            # "auto" looks at the metric alone (shared matrix, D >= 128), never at the local batch size: a
+            # chain's arithmetic must not depend on how many chains share its process
+            gemm = metric.kind == "dense" and (dense_gemm is True or (dense_gemm == "auto" and D >= 128))
             v0 = dense.momentum(stream, metric, k0, k1, int(chain_offset), fold, N, D, p0, ke0,
                                 force_pc=not gemm)
             metric = metric._replace(kind="dense_gemm") if gemm else metric

@@ -55,6 +55,14 @@ int bjx_rng_normal(void* stream, uint32_t key0, uint32_t key1, int64_t chain_off
                    int64_t N, int64_t D, float* z_out);
 int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
                     int64_t N, float* u_out);
+/* The same device functions with the key used AS IS (no per-chain child key):
+ *   z_out[j] = jax.random.normal(key, (D,))[j] ; u_out[0] = jax.random.uniform(key, ()) (may be NULL) ;
+ *   children_out[i][0..1] = jax.random.split(key, n_children)[i]  (device uint32[n_children][2]).
+ * The probe the jax.random values printed in JAX's documentation are held against (tests/golden/
+ * reference_kats.json "jax_docs_streams").  Replaces: jax.random.normal / uniform / split as used at
+ * blackjax/util.py:90, mcmc/proposal.py:226, mcmc/hmc.py:299. */
+int bjx_rng_key_probe(void* stream, uint32_t key0, uint32_t key1, int64_t D, float* z_out, float* u_out,
+                      int64_t n_children, uint32_t* children_out);
 
 /* Momentum draw for a diagonal metric + initial kinetic energy.
  *   k_i = split(key, .)[chain_offset+i]; km = split(k_i, 2)[0]

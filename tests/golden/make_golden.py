@@ -96,6 +96,12 @@ kats = {
         "split_key0": [[1797259609, 2579123966], [928981903, 3453687069]],
         "normal_key42_scalar": -0.028304616,
         "legacy_split_key0_words": [4146024105, 2718843009],
+        # three more values printed in JAX's documentation (jax.random module docs / "Pseudorandom numbers"
+        # tutorial, partitionable layout), supplied by the round-3 review; same status: doc-sourced,
+        # not reproducible here
+        "uniform_key0_scalar": 0.947667,
+        "split_key42": [[1832780943, 270669613], [64467757, 2916123636]],
+        "normal_key0_3": [1.6226422, 2.0252647, -0.43359444],
     },
 }
 

@@ -49,6 +49,39 @@ def test_rng_normal_uniform(dev, N, D):
     np.testing.assert_allclose(zz, z_ref, rtol=2e-7, atol=0)
 
 
+def test_device_rng_matches_jax_docs_values(dev):
+    """Row a34: the DEVICE threefry / uniform / erf_inv code (bjx_rng_key_probe: key used as is) against
+    the six jax.random values printed in JAX's own documentation (tests/golden/reference_kats.json
+    "jax_docs_streams": doc-sourced, no JAX on any box) -- and against the oracle on the same keys."""
+    import json
+    import os
+
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["jax_docs_streams"]
+
+    def probe(seed, D, n_children):
+        k = prng.key(seed)
+        z = torch.zeros(max(D, 1), device=dev)
+        u = torch.zeros(1, device=dev)
+        ch = torch.zeros(max(n_children, 1), 2, device=dev, dtype=torch.int32)
+        _lib.call("bjx_rng_key_probe", _lib.current_stream(), int(k[0]), int(k[1]), D, z.data_ptr(), u.data_ptr(),
+                  n_children, ch.data_ptr())
+        return t2n(z)[:D], float(t2n(u)[0]), t2n(ch).view(np.uint32)[:n_children]
+
+    z0, u0, c0 = probe(0, 3, 3)
+    assert c0[:2].tolist() == d["split_key0"]
+    assert c0[2].tolist() == d["legacy_split_key0_words"]
+    assert abs(u0 - d["uniform_key0_scalar"]) < 5e-7 and np.float32(u0) == prng.uniform(prng.key(0))
+    np.testing.assert_allclose(z0, np.float32(d["normal_key0_3"]), rtol=0, atol=2.4e-7)
+    assert np.array_equal(z0, prng.normal(prng.key(0), (3,)))
+    z42, _, c42 = probe(42, 1, 2)
+    assert c42.tolist() == d["split_key42"]
+    assert abs(float(z42[0]) - d["normal_key42_scalar"]) < 1e-8
+    # a longer stream through the same probe against the oracle (counter i = element i)
+    z, u, c = probe(2024, 4096, 100)
+    assert np.array_equal(z, prng.normal(prng.key(2024), (4096,)))
+    assert np.array_equal(c, prng.split(prng.key(2024), 100))
+
+
 def test_rng_normal_large_sample_bit_exact(dev):
     """8.4 M normals: the device's fast correctly-rounded log1p path (bjx_log1p.h) against the
     oracle's fp64 log1p -- every draw bit-identical."""

@@ -21,6 +21,22 @@ def test_streams_match_jax_docs_values():
     assert abs(float(prng.normal(prng.key(42), ())) - d["normal_key42_scalar"]) < 1e-8
     # legacy layout words reappear as threefry(key0, (0, 2)) -- ties the block function to JAX's
     assert prng.split(prng.key(0), 3)[2].tolist() == d["legacy_split_key0_words"]
+    # the three values added in round 4 (six doc-sourced pins in all)
+    assert abs(float(prng.uniform(prng.key(0))) - d["uniform_key0_scalar"]) < 5e-7
+    assert prng.split(prng.key(42), 2).tolist() == d["split_key42"]
+    np.testing.assert_allclose(prng.normal(prng.key(0), (3,)), np.float32(d["normal_key0_3"]), rtol=0, atol=2.4e-7)
+
+
+def test_host_helpers_match_jax_docs_values():
+    """The PRODUCT's host helpers (blackjax_amd.random -> bjx_keys_split in libbjxhip.so; host code, no
+    GPU needed) against the same doc-sourced values."""
+    import blackjax_amd as bjx
+
+    d = KATS["jax_docs_streams"]
+    assert bjx.random.split(bjx.random.key(0), 2).tolist() == d["split_key0"]
+    assert bjx.random.split(bjx.random.key(42), 2).tolist() == d["split_key42"]
+    assert bjx.random.split(bjx.random.key(0), 3)[2].tolist() == d["legacy_split_key0_words"]
+    assert abs(float(bjx.random.uniform(bjx.random.key(0))) - d["uniform_key0_scalar"]) < 5e-7
 
 
 def test_fold_in_is_split_row_and_offsets():

@@ -25,9 +25,20 @@ def _ulps(a, b):
     return np.abs(ai - bi)
 
 
+def _add_jax_site():
+    """``BJX_JAX_SITE``: os.pathsep-separated site-packages directories of a JAX installed outside this
+    interpreter's path (a driver-side venv); appended to sys.path, so nothing already importable is shadowed."""
+    import sys
+
+    for p in os.environ.get("BJX_JAX_SITE", "").split(os.pathsep):
+        if p and os.path.isdir(p) and p not in sys.path:
+            sys.path.append(p)
+
+
 def check(dev=None) -> str:
     try:
         os.environ.setdefault("JAX_PLATFORMS", "cpu")
+        _add_jax_site()
         import jax
         import jax.numpy as jnp
     except Exception as e:  # ModuleNotFoundError on every box seen so far
