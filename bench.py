@@ -782,6 +782,224 @@ def bench_c4(args, ctx):
     }
 
 
+# ------------------------------------------------------------------------------------ C3
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def bench_c3(args, ctx, T=None, lockstep_steps=8):
+    """configs[2]: NUTS (iterative tree doubling, max_depth = 10) on the 256-dim Neal funnel, 32 768
+    chains PER GPU, eps = 0.1, identity metric -- under the external-callable contract (the funnel is
+    the library's HIP callable, evaluated between two tick launches; ``fuse_target`` stays off).
+    Timed region = ONE ``alg.run(key, state, T)`` (free-running chains: every chain walks through its own
+    T trees); ``value`` = leapfrogs all chains took / wall.  A second region times
+    ``lockstep_steps`` calls of ``alg.step`` (the reference's API: all chains in lockstep)."""
+    import blackjax_amd as bjx
+    from blackjax_amd import _lib
+
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    N, D = args.chains or 32768, args.dim or 256
+    T = int(T or args.steps)
+    eps, max_depth = 0.1, 10
+    alg = bjx.nuts(bjx.targets.NealFunnel(), eps, torch.ones(D, device=dev), max_num_doublings=max_depth,
+                   chain_offset=rank * N, use_graph=True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=gen))
+    n_warm = max(args.warmup, 4)  # the lockstep driver records one HIP graph per batch bucket on first use
+    keys = bjx.random.split(bjx.random.key(0), n_warm + lockstep_steps)
+    for t in range(n_warm):
+        state, info = alg.step(keys[t], state)
+    alg.run(bjx.random.key(5), state, 2, store_positions=False)  # first use of the tick kernels / tail graphs
+    torch.cuda.synchronize()
+    box = {}
+
+    def whole_run(i):
+        box["res"] = alg.run(bjx.random.key(1), state, T, store_positions=False)
+
+    dt, per, _ = timed_region(ctx, whole_run, 1)
+    st_run, _, rinfo = box["res"]
+    steps_pc = rinfo.num_integration_steps.sum(0)  # (N,) leapfrogs of each chain over the run
+    mine = torch.stack([steps_pc.sum().double(), steps_pc.max().double(),
+                        rinfo.num_trajectory_expansions.float().mean().double(),
+                        rinfo.is_divergent.float().mean().double()]).reshape(1, 4)
+    pooled = ctx.gather_rows(mine)
+    tot = float(pooled[:, 0].sum())
+    ticks = int(pooled[:, 1].max())
+    value = tot / dt
+
+    # ---- lockstep step(): the only call the reference's API has
+    acc = torch.zeros((), device=dev, dtype=torch.float64)
+    st_box = {"state": state}
+
+    def one_step(i):
+        st, info = alg.step(keys[n_warm + i], st_box["state"])
+        st_box["state"] = st
+        acc.add_(info.num_integration_steps.sum())
+
+    dt_l, per_l, _ = timed_region(ctx, one_step, lockstep_steps)
+    tot_l = float(ctx.gather_rows(acc.reshape(1, 1)).sum())
+
+    # ---- one full-ensemble tick bracketed with HIP events (plain launches, no graph), rank 0
+    tick_us = None
+    if rank == 0 and not args.no_launch_timing:
+        try:
+            alg_t = bjx.nuts(bjx.targets.NealFunnel(), eps, torch.ones(D, device=dev), max_num_doublings=max_depth,
+                             chain_offset=rank * N, use_graph=False, run_use_graph=False)
+            tick_timer = _lib.LaunchTimer(["bjx_nuts_async_tick"], every=4, capacity=4096)
+            _lib.set_timer(tick_timer)
+            alg_t.run(bjx.random.key(1), state, 3, store_positions=False)
+            torch.cuda.synchronize()
+            _lib.set_timer(None)
+            d_ms = tick_timer.durations_ms("bjx_nuts_async_tick")[:24]  # the first ticks: every chain has a leaf
+            tick_us = float(np.mean(d_ms)) * 1e3 if d_ms else None
+        except Exception as e:
+            _lib.set_timer(None)
+            tick_us = None
+            print(f"bench.py: c3 tick bracket failed: {e!r}", file=sys.stderr)
+    if rank != 0:
+        return None
+    peak_rate = HBM_PEAK_GBS * 1e9 / (52.0 * D)  # chain-leapfrogs/s per GPU at 52 B per element
+    roofline = {
+        "bound": "hbm", "kernel": "k_nuts_async_tick2 (leaf) + k_nuts_async_end_list + funnel callable, whole run",
+        "achieved": value / world * 52.0 * D / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": value / world / peak_rate, "traffic": None,
+        "algorithmic_bytes_per_chain_leapfrog": 52.0 * D,
+        "algorithmic_note": "SURVEY.md section 8(d): ~13 words per element and chain-leapfrog (leapfrog 7 incl. the "
+                            "callable, momentum sum 2, checkpoint write 1, U-turn checkpoint reads ~2, proposal copy <1); "
+                            "whole-run figure: useful leapfrogs x 52 B x D / wall, tail of few live chains included",
+        "full_ensemble_tick_us": tick_us,
+        "full_ensemble_tick_achieved_GBps": (52.0 * D * N / (tick_us * 1e-6) / 1e9) if tick_us else None,
+        "full_ensemble_tick_note": "one tick = leaf kernel + transition-end kernel (+ the callable's launch is outside this "
+                                   "bracket) over all chains, first 24 bracketed ticks of a plain-launch run",
+    }
+    return {
+        "metric": "NUTS useful chain-leapfrog-steps/sec (whole node), 32 768 chains x 256-dim funnel",
+        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": T, "warmup": n_warm,
+        "ms_per_step": dt / T * 1e3, "ms_per_transition": dt / T * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"C3: NUTS (iterative tree doubling, max_depth={max_depth}) on the {D}-dim Neal funnel, "
+                        f"{N} chains/GPU, eps={eps}, identity metric, user log-density = HIP NealFunnel callable "
+                        f"(external-callable contract), free-running chains alg.run(T={T})",
+            "chains_per_gpu": N, "dim": D, "global_chains": world * N, "transitions": T,
+            "parallelism": f"chains sharded x{world}, no data-path collective",
+        },
+        "per_rank_ms_per_step": [p / T * 1e3 for p in per],
+        "mean_leapfrogs_per_chain_transition": tot / (world * N * T),
+        "ticks": ticks, "utilisation": tot / (world * N * max(ticks, 1)),
+        "tick_period_avg_us": dt / max(ticks, 1) * 1e6,
+        "mean_depth": float(pooled[:, 2].mean()), "frac_divergent": float(pooled[:, 3].mean()),
+        "lockstep_step": {
+            "value": tot_l / dt_l, "unit": "chain-leapfrog-steps/s", "steps": lockstep_steps,
+            "ms_per_transition": dt_l / lockstep_steps * 1e3,
+            "mean_leapfrogs_per_chain_transition": tot_l / (world * N * lockstep_steps),
+            "frac_of_52B_roofline": tot_l / dt_l / world / peak_rate,
+            "note": "alg.step (the reference's kernel API: all chains in lockstep, HIP-graph driver); a transition lasts "
+                    "as long as the deepest tree of the ensemble"},
+        "roofline": roofline,
+    }
+
+
+# ------------------------------------------------------------------------------------ C5
+def bench_c5(args, ctx, steps=None):
+    """configs[4]: dense mass-matrix HMC on the 512-dim AR(1) Gaussian (Sigma_ij = 0.9^|i-j|), 16 384
+    chains PER GPU, L = 20, eps = 0.5; every velocity v = M^-1 p is one fused fp32 MFMA GEMM launch
+    (kick prologue, drift epilogue), as is the momentum draw p = L^-T z."""
+    import blackjax_amd as bjx
+    from blackjax_amd import _lib
+
+    dev, world, rank = ctx.dev, ctx.world, ctx.rank
+    N, D, L = args.chains or 16384, args.dim or 512, 20
+    K = int(steps or args.steps)
+    tgt = bjx.targets.AR1Gaussian(0.9, D)
+    cov = tgt.covariance(dev)
+    alg = bjx.hmc(tgt, 0.5, cov, L, chain_offset=rank * N)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    state = alg.init(torch.randn(N, D, device=dev, generator=gen))
+    keys = bjx.random.split(bjx.random.key(0), args.warmup + K)
+    for t in range(args.warmup):
+        state, info = alg.step(keys[t], state)
+    torch.cuda.synchronize()
+    timer = None
+    if rank == 0 and not args.no_launch_timing:
+        timer = _lib.LaunchTimer(["bjx_leapfrog_dense"], every=4, capacity=L * K + 8)
+        _lib.set_timer(timer)
+    box = {"state": state}
+    acc = torch.zeros((), device=dev)
+
+    def one(i):
+        st, info = alg.step(keys[args.warmup + i], box["state"])
+        box["state"] = st
+        acc.add_(info.acceptance_rate.mean())
+
+    dt, per, _ = timed_region(ctx, one, K)
+    _lib.set_timer(None)
+    if rank != 0:
+        return None
+    flops = 2.0 * N * D * D
+    roofline = None
+    if timer is not None:
+        d_ms = timer.durations_ms("bjx_leapfrog_dense")
+        avg = float(np.mean(d_ms)) * 1e-3
+        roofline = {"bound": "mfma", "kernel": "k_dense_gemm_tn8<EPI_DRIFT, kicks> (kick + v = M^-1 p + drift, one launch)",
+                    "achieved": flops / avg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / avg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_flops_per_launch": flops, "avg_launch_us": avg * 1e6,
+                    "launches_timed": len(d_ms), "timed_every": 4}
+    value = world * N * L * K / dt
+    return {
+        "metric": "dense-mass HMC chain-leapfrog-steps/sec (whole node), 16 384 chains x 512-dim",
+        "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": dt / K * 1e3, "ms_per_transition": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"C5: dense mass-matrix HMC on the {D}-dim correlated Gaussian (AR(1) rho=0.9), {N} chains/GPU, "
+                        f"L={L}, eps=0.5, MFMA momentum-resample GEMM + one fused GEMM per leapfrog",
+            "chains_per_gpu": N, "dim": D, "leapfrogs": L, "global_chains": world * N,
+            "parallelism": f"chains sharded x{world}, no data-path collective",
+        },
+        "per_rank_ms_per_step": [p / K * 1e3 for p in per],
+        "mean_acceptance": float(acc) / K,
+        "end_to_end_TFLOPs": value / world * 2.0 * D * D / 1e12,
+        "roofline": roofline,
+    }
+
+
+def sub_configs(args, ctx):
+    """After the C2 headline (one GPU, default run): BASELINE.json configs[2..4] as labelled sub-objects,
+    each with its own timed region (barrier + synchronize on both sides), workload string and roofline."""
+    import copy
+    import gc
+
+    out = {}
+
+    def run(name, fn, **over):
+        a = copy.copy(args)
+        a.chains = a.dim = 0
+        for k, v in over.items():
+            setattr(a, k, v)
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            res = fn(a)
+            for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data"):
+                res.pop(k, None)
+            res["wall_s_including_warmup"] = time.perf_counter() - t0
+            out[name] = res
+        except Exception as e:  # a sub-object never fails the headline
+            out[name] = {"value": None, "error": repr(e)[:400]}
+
+    run("c3_nuts", lambda a: bench_c3(a, ctx), steps=100, warmup=4)
+    run("c5_dense", lambda a: bench_c5(a, ctx), steps=10, warmup=2)
+    run("c4_shard", lambda a: bench_c4(a, ctx), steps=200, warmup=3, leapfrogs=50)
+    if "c4_shard" in out and out["c4_shard"].get("value") is not None:
+        out["c4_shard"]["steps_note"] = ("a complete 200-step Stan schedule (the 1 000-step warm-up of configs[3] is "
+                                         "`bench.py --config c4`): 75 fast steps, 75 slow steps in two windows (two metric updates), 50 fast")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -791,9 +1009,12 @@ def main():
                     help="timed steps (0 = the config's default: c2 40 transitions, c4 the 1 000-step warm-up "
                          "BASELINE.json configs[3] names)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2")
-    ap.add_argument("--chains", type=int, default=0, help="chains PER GPU (0 = the config's: 65 536 / 32 768)")
-    ap.add_argument("--dim", type=int, default=0, help="0 = the config's: 1 024 / 4 096")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--no-sub-configs", action="store_true",
+                    help="c2 default run: skip the C3 / C5 / C4-shard sub-objects")
+    ap.add_argument("--chains", type=int, default=0,
+                    help="chains PER GPU (0 = the config's: c2 65 536, c3 32 768, c4 32 768, c5 16 384)")
+    ap.add_argument("--dim", type=int, default=0, help="0 = the config's: 1 024 / 256 / 4 096 / 512")
     ap.add_argument("--leapfrogs", type=int, default=50)
     ap.add_argument("--eps", type=float, default=0.25)
     ap.add_argument("--chain-block", type=int, default=-1,
@@ -822,7 +1043,7 @@ def main():
     if args.steps < 0:
         ap.error("--steps must be >= 1")
     if args.steps == 0:
-        args.steps = 1000 if args.config == "c4" else 40
+        args.steps = {"c2": 40, "c3": 100, "c4": 1000, "c5": 20}[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)  # does not return
@@ -851,7 +1072,10 @@ def main():
             selftest_control_flow(args, ctx, emit)
             return
         seen = ctx.ranks_seen()
-        out = bench_c2(args, ctx) if args.config == "c2" else bench_c4(args, ctx)
+        out = {"c2": bench_c2, "c3": bench_c3, "c4": bench_c4, "c5": bench_c5}[args.config](args, ctx)
+        if (args.config == "c2" and ctx.world == 1 and not ctx.collective and not args.headline_only
+                and not args.only_mode and not args.no_sub_configs and args.chains == 0 and args.dim == 0):
+            out.update(sub_configs(args, ctx))
         if ctx.rank == 0:
             out["ranks_seen"] = seen
             out["backend"] = ctx.backend

@@ -106,3 +106,41 @@ def test_bench_c4_tiny():
     j = _json_line(r.stdout)
     assert "window_adaptation" in j["metric"] and j["config"]["workload"].startswith("C4")
     assert j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] == 24.0 * 512 * 1024
+
+
+@pytest.mark.gpu
+def test_bench_c3_tiny():
+    r = _run(["--config", "c3", "--chains", "512", "--dim", "64", "--steps", "6", "--warmup", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["config"]["workload"].startswith("C3: NUTS") and j["value"] > 0 and j["steps"] == 6
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["algorithmic_bytes_per_chain_leapfrog"] == 52.0 * 64
+    assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-12
+    assert j["lockstep_step"]["value"] > 0 and 1.0 <= j["mean_leapfrogs_per_chain_transition"] <= 1023.0
+
+
+@pytest.mark.gpu
+def test_bench_c5_tiny():
+    r = _run(["--config", "c5", "--chains", "1024", "--dim", "128", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["config"]["workload"].startswith("C5: dense") and j["value"] > 0
+    roof = j["roofline"]
+    assert roof["bound"] == "mfma" and roof["algorithmic_flops_per_launch"] == 2.0 * 1024 * 128 * 128
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_c3_c5_c4_sub_objects():
+    """The default run (no --chains / --dim): C2 headline + BASELINE.json configs[2..4] as sub-objects.
+    Shortened with --steps; the sub-objects keep their own step counts."""
+    r = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-torch-callable", "--no-ess-nonresonant"],
+             timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    for k, start in (("c3_nuts", "C3: NUTS"), ("c5_dense", "C5: dense"), ("c4_shard", "C4: window_adaptation")):
+        assert k in j, k
+        assert j[k].get("value"), j[k]
+        assert j[k]["config"]["workload"].startswith(start)
+        assert j[k]["roofline"]["frac"] > 0
+    assert j["c3_nuts"]["steps"] == 100 and j["c4_shard"]["steps"] == 200
