@@ -1232,13 +1232,16 @@ k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
 // The trajectory-end states are NOT kept after a transition ends (run_free does not expose them).
 enum { LZ_L = 1, LZ_R = 2, LZ_P = 4, LZ_M = 8 };
 // words of rec[c] (BJX_NUTS_REC_WORDS = 32 per chain)
+// words 0 .. 15: what a leaf that keeps integrating reads and writes; 16 .. 27: touched only when a subtree
+// is merged or a transition starts (the v3 leaf loads them there)
 enum {
-  RW_H0 = 0, RW_SW, RW_SSLPA, RW_SLOGP, RW_SENERGY, RW_PW, RW_PSLPA, RW_PLOGP, RW_PENERGY, RW_ACC,
-  RW_DEPTH, RW_SUBN, RW_DIR, RW_LAZY, RW_NSTATES, RW_KT, RW_KTB, RW_KP, RW_KPB, RW_IK, RW_IKB,
-  RW_DIV, RW_TURN, RW_EPS,
-  RW_U0  // .. RW_U0 + 3: the progressive-sampling uniforms of leaves (s & ~3) .. (s | 3) of the current subtree
+  RW_H0 = 0, RW_SW, RW_SSLPA, RW_SLOGP, RW_SENERGY, RW_DEPTH, RW_SUBN, RW_DIR, RW_LAZY, RW_KT, RW_KTB, RW_EPS,
+  RW_U0,  // .. RW_U0 + 3: the progressive-sampling uniforms of leaves (s & ~3) .. (s | 3) of the current subtree
+  RW_PW = RW_U0 + 4, RW_PSLPA, RW_PLOGP, RW_PENERGY, RW_ACC, RW_NSTATES, RW_KP, RW_KPB, RW_IK, RW_IKB,
+  RW_DIV, RW_TURN,
+  RW_END
 };
-static_assert(RW_U0 + 3 < BJX_NUTS_REC_WORDS, "record layout");
+static_assert(RW_U0 == 12 && RW_PW == 16 && RW_END == 28 && RW_END <= BJX_NUTS_REC_WORDS, "record layout");
 
 __device__ __forceinline__ int rec_i(int w, int k) { return __builtin_amdgcn_readlane(w, k); }
 __device__ __forceinline__ float rec_f(int w, int k) { return __int_as_float(__builtin_amdgcn_readlane(w, k)); }
@@ -1997,6 +2000,453 @@ k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float
     async_tick2_row<NI, 1, TGT>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(list[i]));
 }
 
+// ------------------------------------------------------------------------------------ free-running chains, v3
+// (round 4) FOUR CHAINS PER WAVE for the busy phase of rows of at most 256 floats: one DPP row of 16 lanes
+// per chain, up to four 16-byte pieces per lane.  The v2 leaf above spends one wave on one 1 KB row: four
+// floats per lane of row arithmetic against ~600 wave-uniform "scalar" vector instructions (threefry blocks,
+// fp64 exp / log1p of the sampling step, checkpoint index arithmetic, decisions) that all 64 lanes repeat --
+// 673 vector instructions per row and leaf (SQ counters, profiles/r03), i.e. half of a launch is instruction
+// issue.  Here a lane of the scalar chain serves one of FOUR chains (the four rows of a wave take the same
+// instruction stream with their own operands; branches are uniform within a DPP row), so the scalar chain is
+// paid once per four leaves, and a wave keeps four chains' rows in flight.
+// Same data movement, same keys, same arithmetic, expression for expression, as async_leaf2_chain.  The
+// reductions reproduce wave_sum's summation TREE for a v2 row (lane l of v2 = piece l / 16, lane l % 16 here):
+// per piece a balanced adjacent-pair tree over the row's 16 lanes (the xor butterfly below builds the same
+// tree as the row_shr scan; every node adds the same two operands, and IEEE addition commutes), then
+// (r3 + r2) + (r1 + r0) as row_bcast:15 / row_bcast:31 combine them -- so every sum, hence every decision
+// and every record, is bit-identical to the v2 kernels (tests/test_nuts_free_gpu.py).
+// MODE 0 only (leaf work; transition ends go on the work list of k_nuts_async_end_list, unchanged).
+#ifndef __HIPCC_RTC__
+constexpr int kRecHot = 16;   // words 0 .. 15: loaded with the rows
+constexpr int kRecCold = 12;  // words 16 .. 27: loaded by a leaf that merges its subtree
+static_assert(RW_PW == kRecHot && RW_END == kRecHot + kRecCold, "record layout");
+
+template <int N_>
+__device__ __forceinline__ int row_bcast_i(int v) {  // lane N_ of every 16-lane DPP row to the whole row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N_, 0xf, 0xf, false);  // row_newbcast:N_
+}
+template <int N_>
+__device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast_i<N_>(__float_as_int(v))); }
+
+// sum over the 16 lanes of a DPP row, in every lane of the row (see the header comment for the tree)
+__device__ __forceinline__ double row_sum16(double v) {
+  v = dpp_add_f64<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add_f64<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add_f64<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add_f64<0x140, 0xf>(v);  // row_mirror
+  return v;
+}
+// total of a chain's row from its per-piece lane partials: wave_sum's tree for the v2 layout
+template <int NI>
+__device__ __forceinline__ double chain_sum(const double (&a)[NI]) {
+  double r[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < NI; ++k) r[k] = row_sum16(a[k]);
+  return (r[3] + r[2]) + (r[1] + r[0]);
+}
+
+// scalars3 for a DPP row: lanes 0, 1, 2 of the row take the three operands (same expressions)
+__device__ __forceinline__ Scalars3 scalars3_row(double arg0, float a1, float b1, float a2, float b2) {
+  const int g = threadIdx.x & 15;
+  const double xa = g == 1 ? (double)a1 : (double)a2;
+  const double xb = g == 1 ? (double)b1 : (double)b2;
+  const double t = xa - xb;
+  const double e = exp(g == 0 ? arg0 : -fabs(t));
+  const double l1p = log1p(e);
+  double r;
+  if (g == 0) r = 1.0 / (1.0 + e);
+  else if (xa == xb) r = xa + 0.6931471805599453;
+  else if (t > 0) r = xa + l1p;
+  else if (t <= 0) r = xb + l1p;
+  else r = t;  // NaN
+  const float rf = (float)r, ef = (float)e;
+  return Scalars3{row_bcast_f<0>(ef), row_bcast_f<0>(rf), row_bcast_f<1>(rf), row_bcast_f<2>(rf)};
+}
+
+#define RF(k_) __int_as_float(rw[k_])
+#define RSETF(k_, v_) rw[k_] = __float_as_int(v_)
+#define CF(k_) __int_as_float(rc[(k_) - kRecHot])
+#define CI(k_) rc[(k_) - kRecHot]
+#define CSETF(k_, v_) rc[(k_) - kRecHot] = __float_as_int(v_)
+
+// One leaf of chain c (phase 1) by the 16 lanes of its DPP row.  Returns true when the transition is
+// complete (phase 3 written).  Transcription of async_leaf2_chain<1> (LOOP = false) with three changes in
+// what is held where (none in what is computed): the subtree's momentum sum after this leaf, S + P, is
+// recomputed where it is used instead of kept beside S (the same single rounding each time); the words of
+// the record only a merge touches are loaded, and stored, by a merging leaf; the two merge rows of a
+// subtree's last leaf are requested into L2 up front (one word per cache line) instead of into registers.
+template <int NI>
+__device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf, float lp,
+                                                int64_t c, int64_t b, int* recp, int (&rw)[kRecHot],
+                                                LeafRows<NI>& R) {
+  constexpr int VEC = 4;
+  const int g = threadIdx.x & 15;
+  const int32_t depth = rw[RW_DEPTH];
+  const int32_t s = rw[RW_SUBN];
+  const int dir = rw[RW_DIR];
+  int lazy = rw[RW_LAZY];
+  const float eps = RF(RW_EPS);
+  const float deps = (float)dir * eps;
+  const float h = deps * 0.5f;
+  const int64_t base = c * nt.D;
+  float* fpp = ax.front_p + base;
+  float* qn = qf + b * nt.D;
+  float* sm = nt.Smsum + base;
+  const float H0 = RF(RW_H0), sw = RF(RW_SW), sslpa = RF(RW_SSLPA);
+  const bool last = (s + 1) >= (1 << depth);
+  const uint32_t us = (uint32_t)s;  // checkpoint indices (termination.py:75-84)
+  const int idx_max = __popc(us >> 1);
+  const int nsub = __popc((~us & (us + 1u)) - 1u);
+  const int idx_min = idx_max - nsub + 1;
+  const bool even = (us & 1u) == 0u;
+  uint32_t j0[NI];
+  bool ok[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    j0[k] = ((uint32_t)g + 16u * k) * VEC;
+    ok[k] = j0[k] < (uint32_t)nt.D;
+  }
+  const int other_bit = dir > 0 ? LZ_L : LZ_R;
+  const float* op = ((lazy & other_bit) ? nt.p0 : (dir > 0 ? nt.Lp : nt.Rp)) + base;
+  const float* ms_src = ((lazy & LZ_M) ? nt.p0 : nt.msum) + base;
+  // second round trip, issued now: first checkpoint level of an odd leaf (its momentum-SUM row is the S row
+  // already in registers, see async_leaf2_chain); the merge rows and the cold record words of a last leaf
+  // are pulled into L2 (one word per 64-byte line; volatile: the values are not used)
+  Row<VEC> C0[NI];
+  if (nsub > 0) {
+    const float* r_ck = nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) C0[k] = ldr<VEC>(r_ck + j0[k]);
+  }
+  if (last && (uint32_t)g * 16u < (uint32_t)nt.D) {
+    (void)*(const volatile float*)(ms_src + g * 16);
+    (void)*(const volatile float*)(op + g * 16);
+  }
+  // four leaves' uniforms per draw (lanes g & 3 of the row), as in the v2 leaf
+  if ((s & 3) == 0) {
+    const Key kt{(uint32_t)rw[RW_KT], (uint32_t)rw[RW_KTB]};
+    const uint32_t sl = (uint32_t)s + ((uint32_t)g & 3u);
+    const float ul = key_uniform(key_child(kt, (uint64_t)sl));
+    RSETF(RW_U0 + 0, row_bcast_f<0>(ul));
+    RSETF(RW_U0 + 1, row_bcast_f<1>(ul));
+    RSETF(RW_U0 + 2, row_bcast_f<2>(ul));
+    RSETF(RW_U0 + 3, row_bcast_f<3>(ul));
+  }
+  const int sq = s & 3;
+  const float u = sq == 0 ? RF(RW_U0) : (sq == 1 ? RF(RW_U0 + 1) : (sq == 2 ? RF(RW_U0 + 2) : RF(RW_U0 + 3)));
+
+  // pass 1: closing half kick, kinetic energy
+  double a1[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    a1[k] = 0.0;
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
+        a1[k] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)R.P[k].v[e];
+      }
+    }
+  }
+  const float ke = 0.5f * (float)chain_sum<NI>(a1);
+  const float e_new = -lp + ke;  // hmc_energy (trajectory.py:745-748)
+  float wgt = H0 - e_new;        // proposal.py:91-95
+  if (wgt != wgt) wgt = -__builtin_inff();
+  const float slpa_new = fminf(wgt, 0.0f);
+  const bool sdiv = (-wgt) > nt.divergence_threshold;  // trajectory.py:325
+  bool take;
+  float Wn, Sn;
+  if (s == 0) {
+    take = true;
+    Wn = wgt;
+    Sn = slpa_new;
+  } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
+    const Scalars3 sc = scalars3_row(-(double)(wgt - sw), sw, wgt, sslpa, slpa_new);
+    take = u < sc.r0;
+    Wn = sc.lae1;
+    Sn = sc.lae2;
+  }
+  // the subtree's momentum sum after this leaf (R.S keeps the sum BEFORE it: the U-turn check needs both)
+#define S_AFTER(k_, e_) (s != 0 ? R.S[k_].v[e_] + R.P[k_].v[e_] : R.P[k_].v[e_])
+
+  // pass 2: checkpoint store, subtree-proposal state copy
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      if (even && !last && !sdiv) {
+        str<VEC>(nt.ckpt_r + (c * nt.max_depth + idx_max) * nt.D + j0[k], R.P[k]);
+        if ((us & 3u) == 0u) {
+          Row<VEC> sn;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sn.v[e] = S_AFTER(k, e);
+          str<VEC>(nt.ckpt_rs + (c * nt.max_depth + idx_max) * nt.D + j0[k], sn);
+        }
+      }
+      if (take) {
+        str<VEC>(nt.Sq + base + j0[k], R.X[k]);
+        str<VEC>(nt.Sg + base + j0[k], R.G[k]);
+      }
+    }
+
+  // pass 3: iterative U-turn over the checkpoints idx_max .. idx_min (termination.py:86-104); the first
+  // level's momentum-sum checkpoint is the S row in registers, deeper levels load both rows
+  bool turning = false;
+#define BJX_UTURN_LEVEL(C1_)                                                      \
+  do {                                                                            \
+    double al[NI], ar[NI];                                                        \
+    _Pragma("unroll") for (int k = 0; k < NI; ++k) {                              \
+      al[k] = 0.0;                                                                \
+      ar[k] = 0.0;                                                                \
+      if (ok[k]) {                                                                \
+        _Pragma("unroll") for (int e = 0; e < VEC; ++e) {                         \
+          const float rl = C0[k].v[e];                                            \
+          const float ssum = (S_AFTER(k, e) - C1_[k].v[e]) + rl;                  \
+          const float rho = ssum - (R.P[k].v[e] + rl) * 0.5f; /* metrics.py:300 */ \
+          al[k] += (double)(R.M[k].v[e] * rl) * (double)rho;                      \
+          ar[k] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)rho;             \
+        }                                                                         \
+      }                                                                           \
+    }                                                                             \
+    const double a_left = chain_sum<NI>(al);                                      \
+    const double a_right = chain_sum<NI>(ar);                                     \
+    turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);                \
+  } while (0)
+  if (nsub > 0) BJX_UTURN_LEVEL(R.S);
+  for (int i = idx_max - 1; i >= idx_min && !turning; --i) {
+    Row<VEC> C1[NI];
+    const float* r_ck = nt.ckpt_r + (c * nt.max_depth + i) * nt.D;
+    const float* rs_ck = nt.ckpt_rs + (c * nt.max_depth + i) * nt.D;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        C0[k] = ldr<VEC>(r_ck + j0[k]);
+        C1[k] = ldr<VEC>(rs_ck + j0[k]);
+      }
+    BJX_UTURN_LEVEL(C1);
+  }
+#undef BJX_UTURN_LEVEL
+  const bool stop = sdiv || turning;
+  if (!(stop || last)) {  // the subtree keeps integrating: opening half of leaf s + 1
+    RSETF(RW_SW, Wn);
+    RSETF(RW_SSLPA, Sn);
+    if (take) {
+      RSETF(RW_SLOGP, lp);
+      RSETF(RW_SENERGY, e_new);
+    }
+    rw[RW_SUBN] = s + 1;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (ok[k]) {
+        Row<VEC> sn;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          sn.v[e] = S_AFTER(k, e);
+          R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
+          R.X[k].v[e] = fmaf(deps, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+        }
+        str<VEC>(fpp + j0[k], R.P[k]);
+        str<VEC>(qn + j0[k], R.X[k]);
+        str<VEC>(sm + j0[k], sn);  // the subtree's momentum sum is only stored while it keeps growing
+      }
+    return false;
+  }
+
+  // ---- the subtree is complete: merge it (trajectory.py:680-727, proposal.py:146-176)
+  int rc[kRecCold];
+#pragma unroll
+  for (int k = 0; k < kRecCold / 4; ++k) {
+    const int4 t = *reinterpret_cast<const int4*>(recp + kRecHot + 4 * k);
+    rc[4 * k] = t.x; rc[4 * k + 1] = t.y; rc[4 * k + 2] = t.z; rc[4 * k + 3] = t.w;
+  }
+  Row<VEC> MS[NI], OP[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+    if (ok[k]) {
+      MS[k] = ldr<VEC>(ms_src + j0[k]);
+      OP[k] = ldr<VEC>(op + j0[k]);
+    }
+  const float pw = CF(RW_PW), pslpa = CF(RW_PSLPA);
+  bool take_m = false;
+  float new_pw = pw;
+  const Scalars3 scm = scalars3_row((double)(Wn - pw), pslpa, Sn, pw, Wn);
+  const float new_pslpa = scm.lae1;
+  if (!stop) {  // progressive_biased_sampling
+    const Key kp{(uint32_t)CI(RW_KP), (uint32_t)CI(RW_KPB)};
+    take_m = key_uniform(kp) < min1_nan(scm.e0);
+    new_pw = scm.lae2;
+  }
+  double al[NI], ar[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    al[k] = 0.0;
+    ar[k] = 0.0;
+    if (ok[k]) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float pl = dir > 0 ? OP[k].v[e] : R.P[k].v[e];
+        const float pr = dir > 0 ? R.P[k].v[e] : OP[k].v[e];
+        MS[k].v[e] = MS[k].v[e] + S_AFTER(k, e);
+        const float rho = MS[k].v[e] - (pr + pl) * 0.5f;
+        al[k] += (double)(R.M[k].v[e] * pl) * (double)rho;
+        ar[k] += (double)(R.M[k].v[e] * pr) * (double)rho;
+      }
+      str<VEC>(nt.msum + base + j0[k], MS[k]);
+      if (take_m) {
+        // the subtree's proposal: this leaf's state when the leaf itself was taken, else rows an
+        // earlier leaf of the subtree stored
+        str<VEC>(nt.Pq + base + j0[k], take ? R.X[k] : ldr<VEC>(nt.Sq + base + j0[k]));
+        str<VEC>(nt.Pg + base + j0[k], take ? R.G[k] : ldr<VEC>(nt.Sg + base + j0[k]));
+      }
+    }
+  }
+  lazy &= ~LZ_M;
+  if (take_m) lazy &= ~LZ_P;
+  const double a_left = chain_sum<NI>(al);
+  const double a_right = chain_sum<NI>(ar);
+  const bool turn = turning || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
+  const bool grow = !sdiv && !turn && depth + 1 < nt.max_depth;
+  const int n = CI(RW_NSTATES) + s + 1;
+  CSETF(RW_PW, new_pw);
+  CSETF(RW_PSLPA, new_pslpa);
+  if (take_m) {
+    CSETF(RW_PLOGP, take ? lp : RF(RW_SLOGP));
+    CSETF(RW_PENERGY, take ? e_new : RF(RW_SENERGY));
+  }
+  CSETF(RW_ACC, exp_cr(new_pslpa) / (float)n);  // nuts.py:303-305
+  CI(RW_NSTATES) = n;
+  CI(RW_DIV) = sdiv ? 1 : 0;
+  CI(RW_TURN) = turn ? 1 : 0;
+  rw[RW_DEPTH] = depth + 1;
+  bool done = false;
+  if (!grow) {  // the transition is complete
+    rw[RW_LAZY] = lazy;
+    if (g == 0) ax.phase[c] = 3;
+    done = true;
+  } else {
+    // ---- next doubling (trajectory.py:645-670): direction and keys (begin_doubling_rec)
+    const Key ik{(uint32_t)CI(RW_IK), (uint32_t)CI(RW_IKB)};
+    const Key subkey = key_child(ik, (uint64_t)(depth + 1));
+    const Key ch = key_child(subkey, (uint64_t)(g < 3 ? g : 0));  // split(subkey, 3) in lanes 0 .. 2 of the row
+    const Key kd{(uint32_t)row_bcast_i<0>((int)ch.k0), (uint32_t)row_bcast_i<0>((int)ch.k1)};
+    const int dir2 = key_uniform(kd) < 0.5f ? 1 : -1;
+    rw[RW_KT] = row_bcast_i<1>((int)ch.k0);
+    rw[RW_KTB] = row_bcast_i<1>((int)ch.k1);
+    CI(RW_KP) = row_bcast_i<2>((int)ch.k0);
+    CI(RW_KPB) = row_bcast_i<2>((int)ch.k1);
+    rw[RW_DIR] = dir2;
+    rw[RW_SUBN] = 0;
+    const float deps2 = (float)dir2 * eps;
+    const float h2 = deps2 * 0.5f;
+    if (dir2 == dir) {  // the end just reached keeps moving: its state is in registers
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            R.P[k].v[e] = fmaf(h2, R.G[k].v[e], R.P[k].v[e]);
+            R.X[k].v[e] = fmaf(deps2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+          }
+          str<VEC>(fpp + j0[k], R.P[k]);
+          str<VEC>(qn + j0[k], R.X[k]);
+        }
+    } else {  // park this end in its arrays, continue from the other one
+      float* eq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+      float* eg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+      float* ep = (dir > 0 ? nt.Rp : nt.Lp) + base;
+      const bool z0 = (lazy & other_bit) != 0;
+      const float* oq = (z0 ? nt.q0 : (dir2 > 0 ? nt.Rq : nt.Lq)) + base;
+      const float* og = (z0 ? nt.g0 : (dir2 > 0 ? nt.Rg : nt.Lg)) + base;
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          str<VEC>(eq + j0[k], R.X[k]);
+          str<VEC>(eg + j0[k], R.G[k]);
+          str<VEC>(ep + j0[k], R.P[k]);
+          const Row<VEC> g2 = ldr<VEC>(og + j0[k]);
+          Row<VEC> q2 = ldr<VEC>(oq + j0[k]);
+          Row<VEC> p2 = OP[k];  // the other end's momentum was loaded for the merge
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            p2.v[e] = fmaf(h2, g2.v[e], p2.v[e]);
+            q2.v[e] = fmaf(deps2, R.M[k].v[e] * p2.v[e], q2.v[e]);
+          }
+          str<VEC>(fpp + j0[k], p2);
+          str<VEC>(qn + j0[k], q2);
+        }
+      lazy &= ~other_bit;
+    }
+    rw[RW_LAZY] = lazy;
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < kRecCold / 4; ++k)
+      *reinterpret_cast<int4*>(recp + kRecHot + 4 * k) = make_int4(rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
+  }
+  return done;
+}
+#undef S_AFTER
+#undef RF
+#undef RSETF
+#undef CF
+#undef CI
+#undef CSETF
+
+#ifndef BJX_TICK3_WAVES
+#define BJX_TICK3_WAVES 2
+#endif
+// Leaf kernel of a two-kernel tick, four compact rows per 64-thread workgroup (one wave).
+template <int NI>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BJX_TICK3_WAVES)))
+k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                   const float* __restrict__ gf) {
+  constexpr int VEC = 4;
+  if (ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
+    ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
+  const int64_t n_rows = async_n_rows(ax);
+  const int g = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
+  if (b >= n_rows) return;  // uniform within a DPP row
+  const int64_t c = ax.rows ? (int64_t)ax.rows[b] : b;
+  // first round trip: the phase, the record and every row of a leaf, all at once
+  const int phase = ax.phase[c];
+  int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
+  int rw[kRecHot];
+#pragma unroll
+  for (int k = 0; k < kRecHot / 4; ++k) {
+    const int4 t = *reinterpret_cast<const int4*>(recp + 4 * k);
+    rw[4 * k] = t.x; rw[4 * k + 1] = t.y; rw[4 * k + 2] = t.z; rw[4 * k + 3] = t.w;
+  }
+  LeafRows<NI> R;
+  const int64_t base = c * nt.D;
+  const float* im = nt.imm + c * nt.imm_stride;
+  const float lp = logp_f[b];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const uint32_t j = ((uint32_t)g + 16u * k) * VEC;
+    if (j < (uint32_t)nt.D) {
+      R.G[k] = ldr<VEC>(gf + b * nt.D + j);
+      R.M[k] = ldr<VEC>(im + j);
+      R.P[k] = ldr<VEC>(ax.front_p + base + j);
+      R.X[k] = ldr<VEC>(qf + b * nt.D + j);
+      R.S[k] = ldr<VEC>(nt.Smsum + base + j);
+    }
+  }
+  if (phase == 1) {
+    const bool done = async_leaf3_row<NI>(nt, ax, qf, lp, c, b, recp, rw, R);
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < kRecHot / 4; ++k)
+        *reinterpret_cast<int4*>(recp + 4 * k) = make_int4(rw[4 * k], rw[4 * k + 1], rw[4 * k + 2], rw[4 * k + 3]);
+      if (done && ax.end_list)  // rows whose transition ended go on the work list of the second kernel
+        ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
+    }
+  } else if (phase == 0 && ax.end_list && g == 0) {  // first tick of a run: every chain starts
+    ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
+  }
+}
+#endif  // !__HIPCC_RTC__
+
 // Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
 // One 1024-thread workgroup (same ballot + LDS scan as k_nuts_compact); src[b'] remembers the old
 // row so the pending positions can be gathered by k_nuts_async_gather.
@@ -2379,6 +2829,8 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
     const bool tgt = run->target_kind != BJX_TARGET_NONE;
     static const int multi_waves = [] { const char* e = getenv("BJX_MULTI_WAVES"); return e ? atoi(e) : 2; }();
+    // v3 leaf kernel (four chains per wave, D <= 256) for the busy phase; BJX_NUTS_V3=0 keeps the v2 leaf (A/B)
+    static const bool use_v3 = [] { const char* e = getenv("BJX_NUTS_V3"); return e ? atoi(e) != 0 : true; }();
 #define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
   do {                                                                                                            \
     if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
@@ -2407,7 +2859,14 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
       if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
       else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
-      if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);            \
+      if (use_v3 && NI_ == 1 && !tgt && run->end_list && run->end_count) {                 \
+        const dim3 g3((unsigned)((run->n_rows + 3) / 4));                                  \
+        const int ni3 = (int)((nuts->D + 63) / 64);                                        \
+        if (ni3 == 1) hipLaunchKernelGGL((k_nuts_async_tick3<1>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
+        else if (ni3 == 2) hipLaunchKernelGGL((k_nuts_async_tick3<2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+        else if (ni3 == 3) hipLaunchKernelGGL((k_nuts_async_tick3<3>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+        else hipLaunchKernelGGL((k_nuts_async_tick3<4>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);               \
+      } else if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);     \
       if (run->end_list && run->end_count)                                                 \
         BJX_END_LIST(NI_);                                                                 \
       else                                                                                 \
