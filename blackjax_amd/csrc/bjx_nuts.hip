@@ -2021,12 +2021,20 @@ constexpr int kRecHot = 16;   // words 0 .. 15: loaded with the rows
 constexpr int kRecCold = 12;  // words 16 .. 27: loaded by a leaf that merges its subtree
 static_assert(RW_PW == kRecHot && RW_END == kRecHot + kRecCold, "record layout");
 
-template <int N_>
-__device__ __forceinline__ int row_bcast_i(int v) {  // lane N_ of every 16-lane DPP row to the whole row
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N_, 0xf, 0xf, false);  // row_newbcast:N_
+// GL = lanes per chain: 16 (one DPP row: four chains per wave) or 64 (the whole wave: one chain per wave,
+// chain-uniform values are wave-uniform and live in SGPRs)
+template <int GL, int N_>
+__device__ __forceinline__ int row_bcast_i(int v) {  // lane N_ of every chain's lane group to the whole group
+  if constexpr (GL == 64) return __builtin_amdgcn_readlane(v, N_);
+  else return __builtin_amdgcn_update_dpp(0, v, 0x150 + N_, 0xf, 0xf, false);  // row_newbcast:N_
 }
-template <int N_>
-__device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast_i<N_>(__float_as_int(v))); }
+template <int GL, int N_>
+__device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast_i<GL, N_>(__float_as_int(v))); }
+template <int GL>
+__device__ __forceinline__ int chain_uniform(int v) {  // tells the compiler a value is the same in all lanes of a chain
+  if constexpr (GL == 64) return __builtin_amdgcn_readfirstlane(v);
+  else return v;
+}
 
 // sum over the 16 lanes of a DPP row, in every lane of the row (see the header comment for the tree)
 __device__ __forceinline__ double row_sum16(double v) {
@@ -2037,8 +2045,12 @@ __device__ __forceinline__ double row_sum16(double v) {
   return v;
 }
 // total of a chain's row from its per-piece lane partials: wave_sum's tree for the v2 layout
-template <int NI>
+template <int GL, int NI>
 __device__ __forceinline__ double chain_sum(const double (&a)[NI]) {
+  if constexpr (GL == 64) {
+    static_assert(NI == 1, "one chain per wave: one piece per lane");
+    return wave_sum(a[0]);
+  }
   double r[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < NI; ++k) r[k] = row_sum16(a[k]);
@@ -2046,8 +2058,9 @@ __device__ __forceinline__ double chain_sum(const double (&a)[NI]) {
 }
 
 // scalars3 for a DPP row: lanes 0, 1, 2 of the row take the three operands (same expressions)
+template <int GL>
 __device__ __forceinline__ Scalars3 scalars3_row(double arg0, float a1, float b1, float a2, float b2) {
-  const int g = threadIdx.x & 15;
+  const int g = threadIdx.x & (GL - 1);
   const double xa = g == 1 ? (double)a1 : (double)a2;
   const double xb = g == 1 ? (double)b1 : (double)b2;
   const double t = xa - xb;
@@ -2060,7 +2073,7 @@ __device__ __forceinline__ Scalars3 scalars3_row(double arg0, float a1, float b1
   else if (t <= 0) r = xb + l1p;
   else r = t;  // NaN
   const float rf = (float)r, ef = (float)e;
-  return Scalars3{row_bcast_f<0>(ef), row_bcast_f<0>(rf), row_bcast_f<1>(rf), row_bcast_f<2>(rf)};
+  return Scalars3{row_bcast_f<GL, 0>(ef), row_bcast_f<GL, 0>(rf), row_bcast_f<GL, 1>(rf), row_bcast_f<GL, 2>(rf)};
 }
 
 #define RF(k_) __int_as_float(rw[k_])
@@ -2075,12 +2088,12 @@ __device__ __forceinline__ Scalars3 scalars3_row(double arg0, float a1, float b1
 // recomputed where it is used instead of kept beside S (the same single rounding each time); the words of
 // the record only a merge touches are loaded, and stored, by a merging leaf; the two merge rows of a
 // subtree's last leaf are requested into L2 up front (one word per cache line) instead of into registers.
-template <int NI>
+template <int GL, int NI>
 __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf, float lp,
                                                 int64_t c, int64_t b, int* recp, int (&rw)[kRecHot],
                                                 LeafRows<NI>& R) {
   constexpr int VEC = 4;
-  const int g = threadIdx.x & 15;
+  const int g = threadIdx.x & (GL - 1);
   const int32_t depth = rw[RW_DEPTH];
   const int32_t s = rw[RW_SUBN];
   const int dir = rw[RW_DIR];
@@ -2103,7 +2116,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   bool ok[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    j0[k] = ((uint32_t)g + 16u * k) * VEC;
+    j0[k] = ((uint32_t)g + (uint32_t)GL * k) * VEC;
     ok[k] = j0[k] < (uint32_t)nt.D;
   }
   const int other_bit = dir > 0 ? LZ_L : LZ_R;
@@ -2128,10 +2141,10 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
     const Key kt{(uint32_t)rw[RW_KT], (uint32_t)rw[RW_KTB]};
     const uint32_t sl = (uint32_t)s + ((uint32_t)g & 3u);
     const float ul = key_uniform(key_child(kt, (uint64_t)sl));
-    RSETF(RW_U0 + 0, row_bcast_f<0>(ul));
-    RSETF(RW_U0 + 1, row_bcast_f<1>(ul));
-    RSETF(RW_U0 + 2, row_bcast_f<2>(ul));
-    RSETF(RW_U0 + 3, row_bcast_f<3>(ul));
+    RSETF(RW_U0 + 0, (row_bcast_f<GL, 0>(ul)));
+    RSETF(RW_U0 + 1, (row_bcast_f<GL, 1>(ul)));
+    RSETF(RW_U0 + 2, (row_bcast_f<GL, 2>(ul)));
+    RSETF(RW_U0 + 3, (row_bcast_f<GL, 3>(ul)));
   }
   const int sq = s & 3;
   const float u = sq == 0 ? RF(RW_U0) : (sq == 1 ? RF(RW_U0 + 1) : (sq == 2 ? RF(RW_U0 + 2) : RF(RW_U0 + 3)));
@@ -2149,7 +2162,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
       }
     }
   }
-  const float ke = 0.5f * (float)chain_sum<NI>(a1);
+  const float ke = 0.5f * (float)chain_sum<GL, NI>(a1);
   const float e_new = -lp + ke;  // hmc_energy (trajectory.py:745-748)
   float wgt = H0 - e_new;        // proposal.py:91-95
   if (wgt != wgt) wgt = -__builtin_inff();
@@ -2162,7 +2175,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
     Wn = wgt;
     Sn = slpa_new;
   } else {  // progressive uniform sampling (trajectory.py:329-339, proposal.py:118-143)
-    const Scalars3 sc = scalars3_row(-(double)(wgt - sw), sw, wgt, sslpa, slpa_new);
+    const Scalars3 sc = scalars3_row<GL>(-(double)(wgt - sw), sw, wgt, sslpa, slpa_new);
     take = u < sc.r0;
     Wn = sc.lae1;
     Sn = sc.lae2;
@@ -2208,8 +2221,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
         }                                                                         \
       }                                                                           \
     }                                                                             \
-    const double a_left = chain_sum<NI>(al);                                      \
-    const double a_right = chain_sum<NI>(ar);                                     \
+    const double a_left = chain_sum<GL, NI>(al);                                      \
+    const double a_right = chain_sum<GL, NI>(ar);                                     \
     turning = ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);                \
   } while (0)
   if (nsub > 0) BJX_UTURN_LEVEL(R.S);
@@ -2257,7 +2270,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 #pragma unroll
   for (int k = 0; k < kRecCold / 4; ++k) {
     const int4 t = *reinterpret_cast<const int4*>(recp + kRecHot + 4 * k);
-    rc[4 * k] = t.x; rc[4 * k + 1] = t.y; rc[4 * k + 2] = t.z; rc[4 * k + 3] = t.w;
+    rc[4 * k] = chain_uniform<GL>(t.x); rc[4 * k + 1] = chain_uniform<GL>(t.y);
+    rc[4 * k + 2] = chain_uniform<GL>(t.z); rc[4 * k + 3] = chain_uniform<GL>(t.w);
   }
   Row<VEC> MS[NI], OP[NI];
 #pragma unroll
@@ -2269,7 +2283,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   const float pw = CF(RW_PW), pslpa = CF(RW_PSLPA);
   bool take_m = false;
   float new_pw = pw;
-  const Scalars3 scm = scalars3_row((double)(Wn - pw), pslpa, Sn, pw, Wn);
+  const Scalars3 scm = scalars3_row<GL>((double)(Wn - pw), pslpa, Sn, pw, Wn);
   const float new_pslpa = scm.lae1;
   if (!stop) {  // progressive_biased_sampling
     const Key kp{(uint32_t)CI(RW_KP), (uint32_t)CI(RW_KPB)};
@@ -2302,8 +2316,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   }
   lazy &= ~LZ_M;
   if (take_m) lazy &= ~LZ_P;
-  const double a_left = chain_sum<NI>(al);
-  const double a_right = chain_sum<NI>(ar);
+  const double a_left = chain_sum<GL, NI>(al);
+  const double a_right = chain_sum<GL, NI>(ar);
   const bool turn = turning || ((float)a_left <= 0.0f) || ((float)a_right <= 0.0f);
   const bool grow = !sdiv && !turn && depth + 1 < nt.max_depth;
   const int n = CI(RW_NSTATES) + s + 1;
@@ -2328,12 +2342,12 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
     const Key ik{(uint32_t)CI(RW_IK), (uint32_t)CI(RW_IKB)};
     const Key subkey = key_child(ik, (uint64_t)(depth + 1));
     const Key ch = key_child(subkey, (uint64_t)(g < 3 ? g : 0));  // split(subkey, 3) in lanes 0 .. 2 of the row
-    const Key kd{(uint32_t)row_bcast_i<0>((int)ch.k0), (uint32_t)row_bcast_i<0>((int)ch.k1)};
+    const Key kd{(uint32_t)row_bcast_i<GL, 0>((int)ch.k0), (uint32_t)row_bcast_i<GL, 0>((int)ch.k1)};
     const int dir2 = key_uniform(kd) < 0.5f ? 1 : -1;
-    rw[RW_KT] = row_bcast_i<1>((int)ch.k0);
-    rw[RW_KTB] = row_bcast_i<1>((int)ch.k1);
-    CI(RW_KP) = row_bcast_i<2>((int)ch.k0);
-    CI(RW_KPB) = row_bcast_i<2>((int)ch.k1);
+    rw[RW_KT] = row_bcast_i<GL, 1>((int)ch.k0);
+    rw[RW_KTB] = row_bcast_i<GL, 1>((int)ch.k1);
+    CI(RW_KP) = row_bcast_i<GL, 2>((int)ch.k0);
+    CI(RW_KPB) = row_bcast_i<GL, 2>((int)ch.k1);
     rw[RW_DIR] = dir2;
     rw[RW_SUBN] = 0;
     const float deps2 = (float)dir2 * eps;
@@ -2392,24 +2406,25 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 #undef CI
 #undef CSETF
 
-#ifndef BJX_TICK3_WAVES
-#define BJX_TICK3_WAVES 2
-#endif
-// Leaf kernel of a two-kernel tick, four compact rows per 64-thread workgroup (one wave).
-template <int NI>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BJX_TICK3_WAVES)))
+// Leaf kernel of a two-kernel tick: 64 / GL compact rows per 64-thread workgroup (one wave).
+//   <16, NI>    four chains per wave (rows of at most 64 NI floats); two waves per SIMD (252 VGPRs at NI = 4)
+//   <64, 1>     one chain per wave, the v2 leaf's layout with this function's lower register pressure
+template <int GL, int NI, int WAVES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
   constexpr int VEC = 4;
+  constexpr int CPW = 64 / GL;  // chains per wave
   if (ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
   const int64_t n_rows = async_n_rows(ax);
-  const int g = threadIdx.x & 15;
-  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
-  if (b >= n_rows) return;  // uniform within a DPP row
-  const int64_t c = ax.rows ? (int64_t)ax.rows[b] : b;
+  const int g = threadIdx.x & (GL - 1);
+  const int64_t b = (int64_t)blockIdx.x * CPW + (threadIdx.x / GL);
+  if (b >= n_rows) return;  // uniform within a chain's lanes
+  int64_t c = ax.rows ? (int64_t)ax.rows[b] : b;
+  if constexpr (GL == 64) c = (int64_t)__builtin_amdgcn_readfirstlane((int)c);
   // first round trip: the phase, the record and every row of a leaf, all at once
-  const int phase = ax.phase[c];
+  int phase = ax.phase[c];
   int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
   int rw[kRecHot];
 #pragma unroll
@@ -2420,10 +2435,10 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
   LeafRows<NI> R;
   const int64_t base = c * nt.D;
   const float* im = nt.imm + c * nt.imm_stride;
-  const float lp = logp_f[b];
+  float lp = logp_f[b];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    const uint32_t j = ((uint32_t)g + 16u * k) * VEC;
+    const uint32_t j = ((uint32_t)g + (uint32_t)GL * k) * VEC;
     if (j < (uint32_t)nt.D) {
       R.G[k] = ldr<VEC>(gf + b * nt.D + j);
       R.M[k] = ldr<VEC>(im + j);
@@ -2432,8 +2447,14 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
       R.S[k] = ldr<VEC>(nt.Smsum + base + j);
     }
   }
+  if constexpr (GL == 64) {  // wave-uniform: into SGPRs (after every load has been issued)
+    phase = __builtin_amdgcn_readfirstlane(phase);
+    lp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lp)));
+#pragma unroll
+    for (int k = 0; k < kRecHot; ++k) rw[k] = __builtin_amdgcn_readfirstlane(rw[k]);
+  }
   if (phase == 1) {
-    const bool done = async_leaf3_row<NI>(nt, ax, qf, lp, c, b, recp, rw, R);
+    const bool done = async_leaf3_row<GL, NI>(nt, ax, qf, lp, c, b, recp, rw, R);
     if (g == 0) {
 #pragma unroll
       for (int k = 0; k < kRecHot / 4; ++k)
@@ -2829,8 +2850,9 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
     const bool tgt = run->target_kind != BJX_TARGET_NONE;
     static const int multi_waves = [] { const char* e = getenv("BJX_MULTI_WAVES"); return e ? atoi(e) : 2; }();
-    // v3 leaf kernel (four chains per wave, D <= 256) for the busy phase; BJX_NUTS_V3=0 keeps the v2 leaf (A/B)
-    static const bool use_v3 = [] { const char* e = getenv("BJX_NUTS_V3"); return e ? atoi(e) != 0 : true; }();
+    // Round-4 leaf kernels of the busy phase (D <= 256), BJX_NUTS_LEAF3: 0 = the v2 leaf; 16 = four chains per
+    // wave; 64 + w = one chain per wave with the lean register layout at w in {3, 4, 5, 6} waves per SIMD
+    static const int leaf3 = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 68; }();
 #define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
   do {                                                                                                            \
     if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
@@ -2859,13 +2881,21 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
       if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
       else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
-      if (use_v3 && NI_ == 1 && !tgt && run->end_list && run->end_count) {                 \
-        const dim3 g3((unsigned)((run->n_rows + 3) / 4));                                  \
-        const int ni3 = (int)((nuts->D + 63) / 64);                                        \
-        if (ni3 == 1) hipLaunchKernelGGL((k_nuts_async_tick3<1>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
-        else if (ni3 == 2) hipLaunchKernelGGL((k_nuts_async_tick3<2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-        else if (ni3 == 3) hipLaunchKernelGGL((k_nuts_async_tick3<3>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-        else hipLaunchKernelGGL((k_nuts_async_tick3<4>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);               \
+      if (leaf3 != 0 && NI_ == 1 && !tgt && run->end_list && run->end_count) {             \
+        if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
+          const dim3 g1((unsigned)run->n_rows);                                            \
+          if (leaf3 == 64 + 5) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 5>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
+          else if (leaf3 == 64 + 6) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 6>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else if (leaf3 == 64 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 3>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 4>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                      \
+        } else {            /* four chains per wave */                                     \
+          const dim3 g3((unsigned)((run->n_rows + 3) / 4));                                \
+          const int ni3 = (int)((nuts->D + 63) / 64);                                      \
+          if (ni3 == 1) hipLaunchKernelGGL((k_nuts_async_tick3<16, 1, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
+          else if (ni3 == 2) hipLaunchKernelGGL((k_nuts_async_tick3<16, 2, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else if (ni3 == 3) hipLaunchKernelGGL((k_nuts_async_tick3<16, 3, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else hipLaunchKernelGGL((k_nuts_async_tick3<16, 4, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);               \
+        }                                                                                  \
       } else if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);     \
       if (run->end_list && run->end_count)                                                 \
         BJX_END_LIST(NI_);                                                                 \

@@ -1,10 +1,10 @@
-"""The round-4 leaf kernel of the free-running NUTS ticks (k_nuts_async_tick3: four chains per wave, one
-16-lane DPP row per chain, rows of at most 256 floats) against the v2 leaf it replaces in the busy phase and
-against the oracle.
+"""The round-4 leaf kernels of the free-running NUTS ticks (k_nuts_async_tick3<GL, NI, WAVES>, rows of at most
+256 floats: GL = 64 one chain per wave with half the registers of the v2 leaf -- the default of the busy phase
+-- and GL = 16 four chains per wave, one 16-lane DPP row per chain) against the v2 leaf and the oracle.
 
 The product takes the v3 leaf only for two-kernel ticks (more than BJX_NUTS_FUSED_ROWS = 8 192 live rows), so
 the small shapes here run in a subprocess with BJX_NUTS_FUSED_ROWS=0 -- every tick of the run is then
-[leaf kernel, transition-end kernel] -- once with BJX_NUTS_V3=1 and once with BJX_NUTS_V3=0.  The kernels
+[leaf kernel, transition-end kernel] -- with BJX_NUTS_LEAF3 = 68, 0 (the v2 leaf) and 16.  The kernels
 promise the same bits (same expressions, same summation tree): every record and every position must be
 IDENTICAL, and the v3 run must satisfy the oracle as the default path does.  The full C3 shape goes through
 the v3 leaf by default: tests/test_full_shape_gpu.py::test_c3_*."""
@@ -70,18 +70,20 @@ WORKER = textwrap.dedent("""
 
 def _run(tmp_path, v3):
     path = str(tmp_path / f"v3_{v3}.npz")
-    env = dict(os.environ, BJX_NUTS_FUSED_ROWS="0", BJX_NUTS_V3=str(v3))
+    env = dict(os.environ, BJX_NUTS_FUSED_ROWS="0", BJX_NUTS_LEAF3=str(v3))
     r = subprocess.run([sys.executable, "-c", WORKER, path], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return dict(np.load(path))
 
 
 def test_v3_leaf_is_bit_identical_to_v2_and_matches_the_oracle(tmp_path, dev):
-    a = _run(tmp_path, 1)
-    b = _run(tmp_path, 0)
-    assert a.keys() == b.keys()
+    a = _run(tmp_path, 68)  # one chain per wave, lean register layout (the default of the busy phase)
+    b = _run(tmp_path, 0)   # the v2 leaf
+    c = _run(tmp_path, 16)  # four chains per wave (kept as a measured alternative)
+    assert a.keys() == b.keys() == c.keys()
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(c[k], b[k], equal_nan=True), k
     # trees of several depths, divergences and max-depth stops were in the comparison
     assert len(np.unique(a["funnel256.num_trajectory_expansions"])) >= 4
     assert a["perchain.num_trajectory_expansions"].max() == 5
