@@ -2884,7 +2884,9 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
       if (leaf3 != 0 && NI_ == 1 && !tgt && run->end_list && run->end_count) {             \
         if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
           const dim3 g1((unsigned)run->n_rows);                                            \
-          if (leaf3 == 64 + 5) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 5>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
+          if (leaf3 == 64 + 8) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 8>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else if (leaf3 == 64 + 7) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 7>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else if (leaf3 == 64 + 5) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 5>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
           else if (leaf3 == 64 + 6) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 6>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
           else if (leaf3 == 64 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 3>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
           else hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 4>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                      \
