@@ -184,6 +184,8 @@ class NutsAsync(ctypes.Structure):
         ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("n_rows_dev", c_void_p),
         ("mass_sqrt_t", c_void_p), ("v0", c_void_p),
         ("target_kind", ctypes.c_int32), ("ticks_per_launch", ctypes.c_int32), ("target_vec", c_void_p),
+        ("int_stages", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+        ("int_mid_kick", c_float * 6), ("int_mid_drift", c_float * 6),  # BJX_NUTS_MAX_MID
     ]
 
 
@@ -191,6 +193,7 @@ class NutsAsync(ctypes.Structure):
 NUTS_AT = {"FLAGS": 0, "DA_REG": 1, "DA_INV_REG": 2, "DA_ETA": 3, "DA_COEF": 4, "WEL_N": 5,
            "FIN_NM1": 6, "FIN_BETA_DATA": 7, "FIN_BETA_PREV": 8, "FIN_REG": 9}
 NUTS_ADAPT_COLS = 12
+NUTS_MAX_MID = 6  # BJX_NUTS_MAX_MID: middle stages of a multi-stage integrator in the free-running tick kernels
 NUTS_REC_WORDS = 32  # BJX_NUTS_REC_WORDS: packed per-chain record of the low-traffic tick kernels
 NUTS_TARGET_USER = 3  # BJX_TARGET_USER (include/bjx_nuts.h): kernels compiled at run time around a user target
 

@@ -1239,9 +1239,10 @@ enum {
   RW_U0,  // .. RW_U0 + 3: the progressive-sampling uniforms of leaves (s & ~3) .. (s | 3) of the current subtree
   RW_PW = RW_U0 + 4, RW_PSLPA, RW_PLOGP, RW_PENERGY, RW_ACC, RW_NSTATES, RW_KP, RW_KPB, RW_IK, RW_IKB,
   RW_DIV, RW_TURN,
-  RW_END
+  RW_END,
+  RW_STAGE = RW_END  // multi-stage integrators (bjx_nuts_async_t.int_stages > 1): gradients of the leaf in flight already used
 };
-static_assert(RW_U0 == 12 && RW_PW == 16 && RW_END == 28 && RW_END <= BJX_NUTS_REC_WORDS, "record layout");
+static_assert(RW_U0 == 12 && RW_PW == 16 && RW_END == 28 && RW_STAGE < BJX_NUTS_REC_WORDS, "record layout");
 
 __device__ __forceinline__ int rec_i(int w, int k) { return __builtin_amdgcn_readlane(w, k); }
 __device__ __forceinline__ float rec_f(int w, int k) { return __int_as_float(__builtin_amdgcn_readlane(w, k)); }
@@ -1315,7 +1316,8 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   int lazy = rec_i(w, RW_LAZY);
   const float eps = rec_f(w, RW_EPS);
   const float deps = (float)dir * eps;
-  const float h = deps * 0.5f;
+  const float h = deps * int_kick(nt);    // closing kick b_K = b_1, and the next leaf's opening kick (0.5 for velocity Verlet)
+  const float dd = deps * int_drift(nt);  // first drift a_1 of the next leaf (deps * 1.0f == deps for velocity Verlet)
   const int64_t base = c * nt.D;
   float* fpp = ax.front_p + base;
   float* qn = qf + b * nt.D;
@@ -1500,7 +1502,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
-          R.X[k].v[e] = fmaf(deps, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+          R.X[k].v[e] = fmaf(dd, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
         }
         str<VEC>(fpp + j0[k], R.P[k]);
         str<VEC>(qn + j0[k], R.X[k]);
@@ -1582,7 +1584,8 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
   const Key ik{(uint32_t)rec_i(w, RW_IK), (uint32_t)rec_i(w, RW_IKB)};
   const int dir2 = begin_doubling_rec(w, ik, depth + 1);
   const float deps2 = (float)dir2 * eps;
-  const float h2 = deps2 * 0.5f;
+  const float h2 = deps2 * int_kick(nt);
+  const float dd2 = deps2 * int_drift(nt);
   if (dir2 == dir) {  // the end just reached keeps moving: its state is in registers
 #pragma unroll
     for (int k = 0; k < NI; ++k)
@@ -1590,7 +1593,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           R.P[k].v[e] = fmaf(h2, R.G[k].v[e], R.P[k].v[e]);
-          R.X[k].v[e] = fmaf(deps2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+          R.X[k].v[e] = fmaf(dd2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
         }
         str<VEC>(fpp + j0[k], R.P[k]);
         str<VEC>(qn + j0[k], R.X[k]);
@@ -1614,7 +1617,7 @@ __device__ __forceinline__ int async_leaf2_chain(const bjx_nuts_t& nt, const bjx
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           p2.v[e] = fmaf(h2, g2.v[e], p2.v[e]);
-          q2.v[e] = fmaf(deps2, R.M[k].v[e] * p2.v[e], q2.v[e]);
+          q2.v[e] = fmaf(dd2, R.M[k].v[e] * p2.v[e], q2.v[e]);
         }
         str<VEC>(fpp + j0[k], p2);
         str<VEC>(qn + j0[k], q2);
@@ -1744,14 +1747,16 @@ __device__ __forceinline__ bool async_end2_chain(const bjx_nuts_t& nt, const bjx
   rec_set_f(w, RW_EPS, eps);
   const int dir = begin_doubling_rec(w, ik, 0);
   const float deps = (float)dir * eps;
-  const float h = deps * 0.5f;
+  const float h = deps * int_kick(nt);
+  const float dd = deps * int_drift(nt);
+  rec_set_i(w, RW_STAGE, 0);
 #pragma unroll
   for (int k = 0; k < NI; ++k)
     if (ok[k]) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         P[k].v[e] = fmaf(h, G[k].v[e], P[k].v[e]);
-        Q[k].v[e] = fmaf(deps, M[k].v[e] * P[k].v[e], Q[k].v[e]);
+        Q[k].v[e] = fmaf(dd, M[k].v[e] * P[k].v[e], Q[k].v[e]);
       }
       str<VEC>(ax.front_p + base + j0[k], P[k]);
       str<VEC>(qrow + j0[k], Q[k]);
@@ -1830,7 +1835,30 @@ __device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_
   phase = __builtin_amdgcn_readfirstlane(phase);
   const int w_in = w;
   bool pending = false;  // a new position for the callable was written to qf[b]
-  if (MODE != 1 && phase == 1) {
+  if (MODE != 1 && phase == 1 && ax.int_stages > 1 && rec_i(w, RW_STAGE) < ax.int_stages - 1) {
+    // a middle stage of a multi-stage integrator (integrators.py:104-150): kick b_i with the gradient just
+    // evaluated, drift a_i -- the leaf's bookkeeping waits for the gradient at the leaf's LAST position
+    const int st = rec_i(w, RW_STAGE);
+    const float deps = (float)rec_i(w, RW_DIR) * rec_f(w, RW_EPS);
+    const float hk = deps * ax.int_mid_kick[st], dk = deps * ax.int_mid_drift[st];
+    const int64_t base = c * nt.D;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const uint32_t j = ((uint32_t)lane + 64u * k) * VEC;
+      if (j < (uint32_t)nt.D) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          R.P[k].v[e] = fmaf(hk, R.G[k].v[e], R.P[k].v[e]);
+          R.X[k].v[e] = fmaf(dk, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+        }
+        str<VEC>(ax.front_p + base + j, R.P[k]);
+        str<VEC>(qf + b * nt.D + j, R.X[k]);
+      }
+    }
+    rec_set_i(w, RW_STAGE, st + 1);
+    pending = true;
+  } else if (MODE != 1 && phase == 1) {
+    rec_set_i(w, RW_STAGE, 0);
     const int done = async_leaf2_chain<NI>(nt, ax, qf, lp, c, b, w, R);
     pending = !done;
     if (MODE == 2 && done) {
@@ -2100,7 +2128,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   int lazy = rw[RW_LAZY];
   const float eps = RF(RW_EPS);
   const float deps = (float)dir * eps;
-  const float h = deps * 0.5f;
+  const float h = deps * int_kick(nt);
+  const float dd = deps * int_drift(nt);
   const int64_t base = c * nt.D;
   float* fpp = ax.front_p + base;
   float* qn = qf + b * nt.D;
@@ -2256,7 +2285,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
         for (int e = 0; e < VEC; ++e) {
           sn.v[e] = S_AFTER(k, e);
           R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
-          R.X[k].v[e] = fmaf(deps, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+          R.X[k].v[e] = fmaf(dd, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
         }
         str<VEC>(fpp + j0[k], R.P[k]);
         str<VEC>(qn + j0[k], R.X[k]);
@@ -2351,7 +2380,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
     rw[RW_DIR] = dir2;
     rw[RW_SUBN] = 0;
     const float deps2 = (float)dir2 * eps;
-    const float h2 = deps2 * 0.5f;
+    const float h2 = deps2 * int_kick(nt);
+    const float dd2 = deps2 * int_drift(nt);
     if (dir2 == dir) {  // the end just reached keeps moving: its state is in registers
 #pragma unroll
       for (int k = 0; k < NI; ++k)
@@ -2359,7 +2389,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             R.P[k].v[e] = fmaf(h2, R.G[k].v[e], R.P[k].v[e]);
-            R.X[k].v[e] = fmaf(deps2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+            R.X[k].v[e] = fmaf(dd2, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
           }
           str<VEC>(fpp + j0[k], R.P[k]);
           str<VEC>(qn + j0[k], R.X[k]);
@@ -2383,7 +2413,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             p2.v[e] = fmaf(h2, g2.v[e], p2.v[e]);
-            q2.v[e] = fmaf(deps2, R.M[k].v[e] * p2.v[e], q2.v[e]);
+            q2.v[e] = fmaf(dd2, R.M[k].v[e] * p2.v[e], q2.v[e]);
           }
           str<VEC>(fpp + j0[k], p2);
           str<VEC>(qn + j0[k], q2);
@@ -2432,6 +2462,8 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
     const int4 t = *reinterpret_cast<const int4*>(recp + 4 * k);
     rw[4 * k] = t.x; rw[4 * k + 1] = t.y; rw[4 * k + 2] = t.z; rw[4 * k + 3] = t.w;
   }
+  int stage = 0;
+  if (ax.int_stages > 1) stage = recp[RW_STAGE];
   LeafRows<NI> R;
   const int64_t base = c * nt.D;
   const float* im = nt.imm + c * nt.imm_stride;
@@ -2453,7 +2485,27 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
 #pragma unroll
     for (int k = 0; k < kRecHot; ++k) rw[k] = __builtin_amdgcn_readfirstlane(rw[k]);
   }
-  if (phase == 1) {
+  stage = chain_uniform<GL>(stage);
+  if (phase == 1 && ax.int_stages > 1 && stage < ax.int_stages - 1) {
+    // a middle stage of a multi-stage integrator: kick b_i with the gradient just evaluated, drift a_i
+    const float deps = (float)rw[RW_DIR] * __int_as_float(rw[RW_EPS]);
+    const float hk = deps * ax.int_mid_kick[stage], dk = deps * ax.int_mid_drift[stage];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const uint32_t j = ((uint32_t)g + (uint32_t)GL * k) * VEC;
+      if (j < (uint32_t)nt.D) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          R.P[k].v[e] = fmaf(hk, R.G[k].v[e], R.P[k].v[e]);
+          R.X[k].v[e] = fmaf(dk, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
+        }
+        str<VEC>(ax.front_p + base + j, R.P[k]);
+        str<VEC>(qf + b * nt.D + j, R.X[k]);
+      }
+    }
+    if (g == 0) recp[RW_STAGE] = stage + 1;
+  } else if (phase == 1) {
+    if (ax.int_stages > 1 && g == 0) recp[RW_STAGE] = 0;
     const bool done = async_leaf3_row<GL, NI>(nt, ax, qf, lp, c, b, recp, rw, R);
     if (g == 0) {
 #pragma unroll

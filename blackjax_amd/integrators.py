@@ -5,9 +5,11 @@ alternating, ``generalized_two_stage_integrator`` 62-152).  ``velocity_verlet`` 
 every sampler and metric; ``mclachlan``, ``yoshida`` and ``omelyan`` (any palindromic list) run through
 the general-coefficient kernels: ``hmc`` and ``dynamic_hmc`` with diagonal and dense metrics
 (``bjx_leapfrog_*_coef`` / ``bjx_hmc_finish_*_coef``), ``mhmc`` / ``dmhmc`` with diagonal metrics
-(``bjx_mhmc_step_diag_coef``), and ``nuts`` -- lockstep ``step`` and ``run`` -- with diagonal and dense
-metrics (``bjx_nuts_t.int_kick / int_drift`` + ``bjx_nuts_mid``); the free-running NUTS tick kernels
-and ``window_adaptation(..., free_running=True)`` integrate with velocity Verlet.  The non-Euclidean
+(``bjx_mhmc_step_diag_coef``), and ``nuts`` -- lockstep ``step`` with diagonal and dense metrics
+(``bjx_nuts_t.int_kick / int_drift`` + ``bjx_nuts_mid``) and, round 4, ``run`` on the FREE-RUNNING tick kernels
+for a diagonal metric with 16-byte rows of at most 512 floats (a leaf lasts K ticks,
+``bjx_nuts_async_t.int_stages``; other shapes run the same transitions as lockstep steps);
+``window_adaptation(..., free_running=True)`` integrates with velocity Verlet.  The non-Euclidean
 integrators of the reference (isokinetic, maruyama, implicit midpoint) are out of scope.
 """
 from __future__ import annotations

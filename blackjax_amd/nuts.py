@@ -425,6 +425,16 @@ def _os_environ():
     return os.environ
 
 
+def free_running_supports(integrator, metric_kind: str, dim: int) -> bool:
+    """Can the free-running tick kernels integrate with ``integrator``?  Velocity Verlet: always.  A general
+    palindromic list: on the low-traffic kernels (diagonal metric, 16-byte rows of at most 512 floats) with at
+    most ``NUTS_MAX_MID`` middle stages."""
+    if integrator is integrators.velocity_verlet:
+        return True
+    return (metric_kind == "diag" and dim % 4 == 0 and dim <= 512
+            and integrator.num_gradients_per_step - 1 <= _lib.NUTS_MAX_MID)
+
+
 def auto_row_block(n_rows: int, dim: int) -> int:
     """Rows per group of the free-running schedule.  Default: ALL rows in one group.  Ticking the
     ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; set
@@ -458,7 +468,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
              sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
-             row_block=None, fuse_target: bool = False):
+             row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -498,6 +508,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     results are bit for bit those of the default path.  This leaves the external-callable contract of
     the engine (any PyTorch callable between two ticks) -- it shows what that contract costs: the tail of
     a run is two dependent launches per leapfrog, ~10-14 us, against one.
+
+    ``integrator``: any palindromic coefficient list of ``blackjax_amd.integrators`` (round 4).  With K > 1
+    gradients per leapfrog a leaf lasts K ticks -- K - 1 middle stages (kick b_i, drift a_i) and the tick that
+    closes the leaf and does its bookkeeping (``bjx_nuts_async_t.int_stages``) -- on the low-traffic tick
+    kernels (``free_running_supports``); results equal ``num_steps`` lockstep steps with the same integrator.
 
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
@@ -545,6 +560,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             adapt_m2=ad["m2"].data_ptr(), adapt_imm=ad["imm"].data_ptr(),
             out_step_size=out_step_size.data_ptr())
     metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
+    integrators.check_supported(integrator, allow_general=True)
+    general = integrator is not integrators.velocity_verlet
+    kick_c, drift_c = integrator.coefficients[0::2], integrator.coefficients[1::2]
+    if general and (fuse_target or not free_running_supports(integrator, metric.kind, D)):
+        raise NotImplementedError(
+            "free-running ticks with a multi-stage integrator: diagonal metric, D % 4 == 0, D <= 512, at most "
+            f"{_lib.NUTS_MAX_MID + 1} gradients per leapfrog and no fuse_target (nuts(...).run falls back to "
+            "lockstep steps for other shapes)")
     if metric.kind != "diag" and adaptation is not None:
         raise NotImplementedError("free-running per-chain adaptation is implemented for the diagonal metric")
     eps, eps_pc = step_size_args(step_size, N, dev)
@@ -602,7 +625,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         divergence_threshold=float(divergence_threshold), key0=k0, key1=k1,
         chain_offset=int(chain_offset), step_fold=-1, q0=q.data_ptr(), g0=g.data_ptr(),
         p0=p.data_ptr(), ckpt_r=ck_r.data_ptr(), ckpt_rs=ck_rs.data_ptr(), fs=fs.data_ptr(),
-        is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"])
+        is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"],
+        int_kick=kick_c[0] if general else 0.0, int_drift=drift_c[0] if general else 0.0)
     run = _lib.NutsAsync(
         step_keys=_lib.ptr(step_keys), t_first=t_first, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
         logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
@@ -615,6 +639,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         rec=_lib.ptr(rec), front_p=_lib.ptr(front_p), end_list=end_list.data_ptr(),
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
+    if general and len(drift_c) > 1:  # middle stages (b_2, a_2), ..., (b_K, a_K); the closing kick b_1 is int_kick
+        run.int_stages = len(drift_c)
+        for i in range(1, len(drift_c)):
+            run.int_mid_kick[i - 1], run.int_mid_drift[i - 1] = kick_c[i], drift_c[i]
     fused = False
     rtc_module = None
     # with an engine-resident target a whole chunk of ticks is ONE launch for batches of at most this many
@@ -1021,14 +1049,18 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
                store_positions: bool = True, fuse_target: bool = fuse_default):
         if general:
-            # the free-running tick kernels integrate with velocity Verlet; with another integrator the
-            # same num_steps transitions run as lockstep steps (identical draws, chain c at transition t
-            # uses the same key either way)
-            return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
+            # multi-stage integrators run free on the low-traffic tick kernels (diagonal metric, D % 4 == 0,
+            # D <= 512: a leaf lasts K ticks); other shapes take the same num_steps transitions as lockstep
+            # steps (identical draws: chain c at transition t uses the same key either way)
+            kind = metrics.default_metric(inverse_mass_matrix, state.position.shape[0], state.position.shape[1],
+                                          state.position.device).kind
+            if not free_running_supports(integrator, kind, state.position.shape[1]):
+                return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,
                         store_positions=store_positions,
-                        use_graph=True if use_graph is True else run_use_graph, fuse_target=fuse_target)
+                        use_graph=True if use_graph is True else run_use_graph, fuse_target=fuse_target,
+                        integrator=integrator)
 
     return SamplingAlgorithm(init_fn, step_fn, run_fn)

@@ -203,6 +203,7 @@ int bjx_nuts_merge(void* stream, const bjx_nuts_t* nuts, int32_t depth, int64_t 
  *
  * The host loops   bjx_nuts_async_tick -> user callable on qf (all N rows) -> bjx_nuts_async_tick ...
  * until *n_done == N.  max_depth >= 1.  Diagonal or dense metric (per-chain adaptation: diagonal). */
+#define BJX_NUTS_MAX_MID 6
 typedef struct {
   const uint32_t* step_keys;  /* (n_steps, 2) device table of the run's per-transition keys
                                  (step-major layout: chain key = split(step_keys[t], N)[c]); NULL:
@@ -289,6 +290,17 @@ typedef struct {
                                  evaluated in place, so nothing separates two leapfrogs of a chain but the
                                  wave's own stores); 0 or 1: one tick per launch */
   const float* target_vec;
+  /* Multi-stage palindromic integrators [b1, a1, b2, a2, ..., b1] (blackjax/mcmc/integrators.py:270-369; round 4,
+   * low-traffic tick kernels only: diagonal metric, rec / front_p given): int_stages = gradients per leapfrog
+   * (0 or 1: velocity Verlet / any one-gradient integrator; b1, a1 are bjx_nuts_t.int_kick / int_drift).  A leaf
+   * then lasts int_stages ticks: after the opening (b1, a1) each of the first int_stages - 1 gradients drives a
+   * middle stage p += (dir eps int_mid_kick[i]) g ; q += (dir eps int_mid_drift[i]) M^-1 p, i = 0 .. int_stages - 2
+   * (the coefficients b_2, a_2, ...), and the last one the closing kick b1 and the leaf's bookkeeping.
+   * At most BJX_NUTS_MAX_MID middle stages. */
+  int32_t int_stages;
+  int32_t reserved3;
+  float int_mid_kick[BJX_NUTS_MAX_MID];
+  float int_mid_drift[BJX_NUTS_MAX_MID];
 } bjx_nuts_async_t;
 
 enum {

@@ -192,6 +192,51 @@ def test_dynamic_hmc_general_integrator_dense_metric(dev):
         np.testing.assert_allclose(t2n(st_g.position), st_o.position, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("N,D,key_layout", [(40, 64, "step_major"), (300, 256, "chain_major"), (25, 132, "step_major")])
+def test_nuts_free_running_with_a_multi_stage_integrator(dev, name, N, D, key_layout):
+    """Round 4: ``run`` with mclachlan / yoshida / omelyan stays on the FREE-RUNNING tick kernels (a leaf lasts
+    K ticks: K - 1 middle stages + the closing tick, ``bjx_nuts_async_t.int_stages``) instead of degrading to
+    lockstep steps -- every record and position equals ``T`` lockstep steps with the same integrator bit for
+    bit, and (small case) the oracle's generalized_two_stage_integrator inside its NUTS."""
+    from blackjax_amd.nuts import free_running_supports
+
+    T, max_depth = 4, 6
+    integ = getattr(bjx.integrators, name)
+    assert free_running_supports(integ, "diag", D)
+    sig = (10.0 ** (-0.5 + 1.0 * np.arange(D) / (D - 1))).astype(np.float32)
+    inv_var = (np.float32(1) / (sig * sig)).astype(np.float32)
+    imm = np.linspace(0.5, 2.0, D).astype(np.float32)
+    q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(np.float32)
+    alg = bjx.nuts(bjx.targets.DiagGaussian(dev_t(inv_var, dev)), 0.25, dev_t(imm, dev), max_num_doublings=max_depth,
+                   integrator=integ, chain_offset=5)
+    st0 = alg.init(dev_t(q0, dev))
+    final, positions, info = alg.run(prng.key(7), st0, T, key_layout=key_layout)
+    # the same transitions as lockstep steps (same keys)
+    st = st0
+    for t in range(T):
+        if key_layout == "step_major":
+            k = prng.split(prng.key(7), T)[t]
+        else:
+            k = bjx.random.ChainMajorKey(prng.key(7), t)
+        st, inf = alg.step(k, st)
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps), t
+        assert torch.equal(info.num_trajectory_expansions[t], inf.num_trajectory_expansions)
+        assert torch.equal(info.is_turning[t], inf.is_turning) and torch.equal(info.is_divergent[t], inf.is_divergent)
+        assert torch.equal(positions[t], st.position), t
+        assert torch.equal(info.energy[t], inf.energy) and torch.equal(info.acceptance_rate[t], inf.acceptance_rate)
+    assert torch.equal(final.position, st.position) and torch.equal(final.logdensity_grad, st.logdensity_grad)
+    assert len(torch.unique(info.num_trajectory_expansions)) > 1
+    if N <= 40 and key_layout == "step_major":  # the oracle's NUTS is a Python loop per leaf
+        fn_o = otargets.diag_gaussian(inv_var)
+        st_o = ohmc.init(q0, fn_o)
+        for t, k in enumerate(prng.split(prng.key(7), T)):
+            st_o, info_o = onuts.kernel(k, st_o, fn_o, np.float32(0.25), imm, max_depth, chain_offset=5,
+                                        coefficients=getattr(oint, name))
+            assert np.array_equal(t2n(info.num_integration_steps[t]), info_o.num_integration_steps), t
+            np.testing.assert_allclose(t2n(positions[t]), st_o.position, rtol=1e-6, atol=1e-6)
+
+
 def test_where_general_integrators_are_not_available():
     with pytest.raises(NotImplementedError):
         bjx.hmc.build_kernel(object())

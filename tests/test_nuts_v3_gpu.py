@@ -56,6 +56,15 @@ WORKER = textwrap.dedent("""
     q0 = torch.as_tensor((prng.normal(prng.key(1), (N, D)) * sig).astype(np.float32), device=dev)
     run_case("gauss", bjx.targets.DiagGaussian(torch.as_tensor(1.0 / (sig * sig), device=dev)), N, D, 4, 6, 0.3,
              torch.as_tensor(sig * sig, device=dev), q0)
+    # a multi-stage integrator: a leaf lasts three ticks (two middle stages + the closing tick)
+    N, D = 70, 200
+    q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
+    alg = bjx.nuts(bjx.targets.NealFunnel(), 0.15, torch.ones(D, device=dev), max_num_doublings=6,
+                   integrator=bjx.integrators.yoshida)
+    final, pos, info = alg.run(bjx.random.key(9), alg.init(q0), 3)
+    out["yoshida.pos"] = pos.cpu().numpy()
+    out["yoshida.n"] = info.num_integration_steps.cpu().numpy()
+    out["yoshida.energy"] = info.energy.cpu().numpy()
     # free-running warm-up (per-chain adaptation inside the transition-end kernel)
     N, D = 96, 32
     q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
