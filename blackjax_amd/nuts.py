@@ -671,7 +671,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         fused = True
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
-    max_ticks = T * ((1 << max_depth) - 1) + 2
+    max_ticks = T * ((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 2  # K ticks per leaf
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
@@ -1048,13 +1048,19 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
 
     def run_fn(rng_key, state, num_steps: int, *, key_layout: str = "step_major",
                store_positions: bool = True, fuse_target: bool = fuse_default):
+        n_, d_ = state.position.shape
+        kind = metrics.default_metric(inverse_mass_matrix, n_, d_, state.position.device).kind
+        if kind == "dense" and not fuse_target and (dense_gemm is True or (dense_gemm == "auto" and d_ >= 128)):
+            # ONE shared dense matrix on the GEMM path (the arithmetic `step` uses for this metric: every
+            # product v = M^-1 p is an fp32 MFMA GEMM over the live rows): the free-running tick kernels apply
+            # a dense metric per chain in fp64 -- other roundings, and 20 x slower at 16 384 x 512 -- so the
+            # run is made of lockstep steps: same keys, run(T) == T x step bit for bit
+            return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
         if general:
             # multi-stage integrators run free on the low-traffic tick kernels (diagonal metric, D % 4 == 0,
             # D <= 512: a leaf lasts K ticks); other shapes take the same num_steps transitions as lockstep
             # steps (identical draws: chain c at transition t uses the same key either way)
-            kind = metrics.default_metric(inverse_mass_matrix, state.position.shape[0], state.position.shape[1],
-                                          state.position.device).kind
-            if not free_running_supports(integrator, kind, state.position.shape[1]):
+            if not free_running_supports(integrator, kind, d_):
                 return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,

@@ -225,3 +225,28 @@ def test_nuts_shared_dense_metric_on_the_gemm(dev, N, D, use_graph, name):
         np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=1e-5, atol=1e-7)
         depths += list(info_o.num_trajectory_expansions)
     assert len(set(depths)) > 1
+
+
+@pytest.mark.parametrize("N,D", [(40, 128), (600, 128)])
+def test_run_with_a_shared_dense_metric_is_made_of_gemm_steps_at_any_batch_size(dev, N, D):
+    """ADVICE r3 + VERDICT r3 "next" #6: with ONE dense matrix and D >= 128, ``dense_gemm="auto"`` takes the
+    fp32 MFMA GEMM arithmetic whatever the local batch size (a chain's roundings must not depend on how many
+    chains share its process), and ``run(T)`` uses the same arithmetic as ``step`` -- run(T) == T x step bit for
+    bit, and a chain's draws do not change when it is run in a smaller batch (chain_offset)."""
+    rho, T = 0.8, 3
+    imm = dev_t(otargets.ar1_covariance(rho, D), dev)
+    q0 = dev_t(prng.normal(prng.key(6), (N, D)).astype(np.float32), dev)
+    alg = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.4, imm, max_num_doublings=5)
+    st0 = alg.init(q0)
+    final, positions, info = alg.run(prng.key(3), st0, T)
+    st = st0
+    for t, k in enumerate(prng.split(prng.key(3), T)):
+        st, inf = alg.step(k, st)
+        assert torch.equal(positions[t], st.position), t
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps)
+        assert torch.equal(info.energy[t], inf.energy)
+    assert torch.equal(final.position, st.position)
+    # the last 8 chains alone (their global indices through chain_offset): same draws, same positions
+    sub = bjx.nuts(bjx.targets.AR1Gaussian(rho, D), 0.4, imm, max_num_doublings=5, chain_offset=N - 8)
+    f2, p2, i2 = sub.run(prng.key(3), sub.init(q0[N - 8:].contiguous()), T)
+    assert torch.equal(p2, positions[:, N - 8:]) and torch.equal(i2.num_integration_steps, info.num_integration_steps[:, N - 8:])
