@@ -60,7 +60,9 @@ k_ghmc_init(Key key, int64_t off, int64_t N, int64_t D, float* __restrict__ p_ou
 // KICK: the opening half kick and the drift of the transition's one leapfrog ride along (the arithmetic of
 // k_leapfrog_diag with n_kicks = 1: p_half = fma(eps/2, g0, p); q1 = fma(eps, imm * p_half, q0)) -- the
 // refresh is bound by its RNG arithmetic, so the leapfrog's five words per element cost nothing here.
-template <int VEC, bool KICK>
+// HOIST (round 4, as k_momentum_diag): one shared inverse mass matrix, 16-byte rows of at most 1 024 floats --
+// mass_sqrt = 1 / sqrt(imm) of a lane's <= 16 columns is computed once per wave, every wave sweeps several rows.
+template <int VEC, bool KICK, bool HOIST = false>
 __global__ void __launch_bounds__(kBlock)
 k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
                int64_t imm_stride, float alpha_s, const float* __restrict__ alpha_pc, float delta_s,
@@ -70,6 +72,15 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
                const float* __restrict__ eps_pc, const float* __restrict__ q0, const float* __restrict__ g0,
                float* __restrict__ q1_out, float* __restrict__ p_half_out) {
   const int lane = threadIdx.x & 63;
+  float msh[HOIST ? 16 : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t j = (int64_t)lane * 4 + 256 * it;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) msh[4 * it + e] = j < D ? 1.0f / sqrtf(imm[j + e]) : 0.0f;
+    }
+  }
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const Key kc = chain_key(key, (uint64_t)(r + off), fold);
     const Key km = key_child(kc, 0);  // key_momentum, key_noise = split(rng_key)
@@ -80,14 +91,14 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
     const float eps = KICK ? (eps_pc ? eps_pc[r] : eps_s) : 0.0f;
     const float h = eps * 0.5f, ed = eps * 1.0f;
     double acc = 0.0;
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
+    auto piece = [&](int64_t j, const float* msv) {  // msv: this piece's hoisted mass_sqrt values, or null
       float m[VEC], pp[VEC], pn[VEC];
       ldv<VEC>(im + j, m);
       ldv<VEC>(p_prev + base + j, pp);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
-        const float fresh = (1.0f / sqrtf(m[e])) * z;  // metrics.py:704-709 (two roundings)
+        const float fresh = (msv ? msv[e] : 1.0f / sqrtf(m[e])) * z;  // metrics.py:704-709 (two roundings)
         const float t1 = pp[e] * s1, t2 = s2 * fresh;  // two products, one sum (ghmc.py:216-221)
         pn[e] = t1 + t2;
         acc += (double)(m[e] * pn[e]) * (double)pn[e];
@@ -105,6 +116,15 @@ k_ghmc_refresh(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const f
         stv<VEC>(p_half_out + base + j, ph);
         stv<VEC>(q1_out + base + j, qn);
       }
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t j = (int64_t)lane * 4 + 256 * it;
+        if (j < D) piece(j, msh + 4 * it);
+      }
+    } else {
+      for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) piece(j, nullptr);
     }
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -339,7 +359,12 @@ int bjx_ghmc_refresh(void* stream, uint32_t key0, uint32_t key1, int64_t chain_o
                      step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain, delta, delta_per_chain,     \
                      p_prev, slice_prev, p_out, slice_out, ke_out, 0.0f, nullptr, nullptr, nullptr,        \
                      nullptr, nullptr)
-  if (bjx_vec4_ok(D, imm, p_prev, p_out)) BJX_REFRESH(4);
+  if (bjx_vec4_ok(D, imm, p_prev, p_out) && imm_stride == 0 && D <= 1024 && N >= 4096)
+    hipLaunchKernelGGL((k_ghmc_refresh<4, false, true>), dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, key, chain_offset, step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain,
+                       delta, delta_per_chain, p_prev, slice_prev, p_out, slice_out, ke_out, 0.0f, nullptr, nullptr,
+                       nullptr, nullptr, nullptr);
+  else if (bjx_vec4_ok(D, imm, p_prev, p_out)) BJX_REFRESH(4);
   else BJX_REFRESH(1);
 #undef BJX_REFRESH
   return bjx_check_launch("bjx_ghmc_refresh");
@@ -363,7 +388,12 @@ int bjx_ghmc_refresh_kick(void* stream, uint32_t key0, uint32_t key1, int64_t ch
                      step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain, delta, delta_per_chain,     \
                      p_prev, slice_prev, p_out, slice_out, ke_out, eps, eps_per_chain, q0, g0, q1_out,     \
                      p_half_out)
-  if (bjx_vec4_ok(D, imm, p_prev, p_out, q0, g0, q1_out, p_half_out)) BJX_REFRESH_KICK(4);
+  if (bjx_vec4_ok(D, imm, p_prev, p_out, q0, g0, q1_out, p_half_out) && imm_stride == 0 && D <= 1024 && N >= 4096)
+    hipLaunchKernelGGL((k_ghmc_refresh<4, true, true>), dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, key, chain_offset, step_fold, N, D, imm, imm_stride, alpha, alpha_per_chain,
+                       delta, delta_per_chain, p_prev, slice_prev, p_out, slice_out, ke_out, eps, eps_per_chain, q0, g0,
+                       q1_out, p_half_out);
+  else if (bjx_vec4_ok(D, imm, p_prev, p_out, q0, g0, q1_out, p_half_out)) BJX_REFRESH_KICK(4);
   else BJX_REFRESH_KICK(1);
 #undef BJX_REFRESH_KICK
   return bjx_check_launch("bjx_ghmc_refresh_kick");

@@ -59,13 +59,26 @@ __global__ void __launch_bounds__(kBlock) k_rng_key_probe(Key key, int64_t D, fl
 // KICK: the opening half kick and the drift of the trajectory's first leapfrog in the same launch (the
 // arithmetic of k_leapfrog_diag with n_kicks = 1) -- this kernel is bound by its per-element RNG
 // arithmetic, so the leapfrog's words ride along.
-template <int VEC, bool KICK>
+// HOIST (round 4): ONE inverse mass matrix for all chains (imm_stride == 0), 16-byte rows of at most 1 024
+// floats -- a lane meets the same <= 16 columns in every row it sweeps, so mass_sqrt = 1 / sqrt(imm) (an IEEE
+// square root and an IEEE division: ~25 instructions per element, a tenth of this issue-bound kernel) is
+// computed once per wave and the launch gives every wave several rows.  Same values, same results.
+template <int VEC, bool KICK, bool HOIST = false>
 __global__ void __launch_bounds__(kBlock)
 k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const float* __restrict__ imm,
                 int64_t imm_stride, float* __restrict__ p_out, float* __restrict__ ke_out, float eps_s,
                 const float* __restrict__ eps_pc, const float* __restrict__ q0, const float* __restrict__ g0,
                 float* __restrict__ q1_out, float* __restrict__ p_half_out) {
   const int lane = threadIdx.x & 63;
+  float msh[HOIST ? 16 : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t j = (int64_t)lane * 4 + 256 * it;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) msh[4 * it + e] = j < D ? 1.0f / sqrtf(imm[j + e]) : 0.0f;
+    }
+  }
   for (int64_t r = wave_row0(); r < N; r += wave_row_stride()) {
     const Key kc = chain_key(key, (uint64_t)(r + off), fold);
     const Key km = key_child(kc, 0);  // split(kc, 2)[0]
@@ -74,7 +87,7 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
     const float eps = KICK ? (eps_pc ? eps_pc[r] : eps_s) : 0.0f;
     const float h = eps * 0.5f, ed = eps * 1.0f;
     double acc = 0.0;
-    for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) {
+    auto piece = [&](int64_t j, const float* msv) {  // msv: this piece's four hoisted mass_sqrt values, or null
       float m[VEC], pv[VEC];
       if constexpr (VEC == 4) {
         F4 t = ld4(im + j);
@@ -85,7 +98,7 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
-        const float ms = 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
+        const float ms = msv ? msv[e] : 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
         pv[e] = ms * z;
         const float v = m[e] * pv[e];
         acc += (double)v * (double)pv[e];
@@ -115,6 +128,15 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
           q1_out[r * D + j] = qn[0];
         }
       }
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t j = (int64_t)lane * 4 + 256 * it;
+        if (j < D) piece(j, msh + 4 * it);
+      }
+    } else {
+      for (int64_t j = (int64_t)lane * VEC; j < D; j += 64 * VEC) piece(j, nullptr);
     }
     acc = wave_sum(acc);
     if (lane == 0) ke_out[r] = 0.5f * (float)acc;
@@ -708,7 +730,12 @@ int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t ch
     else if (D <= 64) BJX_MOM_SHORT(16);
     else BJX_MOM_SHORT(32);
 #undef BJX_MOM_SHORT
-  } else if (bjx_vec4_ok(D, imm, p_out))
+  } else if (bjx_vec4_ok(D, imm, p_out) && imm_stride == 0 && D <= 1024 && N >= 4096)
+    // one shared metric: mass_sqrt hoisted out of the row loop, four rows per wave (k_momentum_diag, HOIST)
+    hipLaunchKernelGGL((k_momentum_diag<4, false, true>), dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, key, chain_offset, step_fold, N, D, imm, imm_stride, p_out, ke_out, 0.0f,
+                       nullptr, nullptr, nullptr, nullptr, nullptr);
+  else if (bjx_vec4_ok(D, imm, p_out))
     hipLaunchKernelGGL((k_momentum_diag<4, false>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
                        step_fold, N, D, imm, imm_stride, p_out, ke_out, 0.0f, nullptr, nullptr, nullptr, nullptr,
                        nullptr);
@@ -729,7 +756,11 @@ int bjx_hmc_momentum_kick_diag(void* stream, uint32_t key0, uint32_t key1, int64
   BJX_CHECK_ARG(imm_stride == 0 || imm_stride == D, "bjx_hmc_momentum_kick_diag: imm_stride must be 0 or D");
   const dim3 grid(bjx_row_grid(N, kWavesPerBlock)), block(kBlock);
   const Key key{key0, key1};
-  if (bjx_vec4_ok(D, imm, q0, g0, p_out, q1_out, p_half_out))
+  if (bjx_vec4_ok(D, imm, q0, g0, p_out, q1_out, p_half_out) && imm_stride == 0 && D <= 1024 && N >= 4096)
+    hipLaunchKernelGGL((k_momentum_diag<4, true, true>), dim3(bjx_row_grid((N + 3) / 4, kWavesPerBlock)), block, 0,
+                       (hipStream_t)stream, key, chain_offset, step_fold, N, D, imm, imm_stride, p_out, ke_out, eps,
+                       eps_per_chain, q0, g0, q1_out, p_half_out);
+  else if (bjx_vec4_ok(D, imm, q0, g0, p_out, q1_out, p_half_out))
     hipLaunchKernelGGL((k_momentum_diag<4, true>), grid, block, 0, (hipStream_t)stream, key, chain_offset,
                        step_fold, N, D, imm, imm_stride, p_out, ke_out, eps, eps_per_chain, q0, g0, q1_out,
                        p_half_out);

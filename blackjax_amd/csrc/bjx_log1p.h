@@ -6,7 +6,8 @@
 // the same contract in ~30 fp64 operations:
 //   fast path  y ~= log1p(t) with relative error < 2^-47:
 //              u = 1 + t (exact for |t| >= 2^-29, otherwise the rounding error c = t - (u - 1) is
-//              added back), u = m * 2^e with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1),
+//              added back), u = m * 2^e with m in [sqrt(1/2), sqrt(2)) (split with integer operations on
+//              the high word of u), s = (m - 1) / (m + 1),
 //              log m = 2 s (1 + z/3 + z^2/5 + ... + z^8/17), z = s^2 <= 0.0295 (next term 2^-50),
 //              y = e ln2 + log m + c.
 //   Ziv test   when y lies within 2^-44 (relative) of a midpoint between two adjacent fp32 values
@@ -43,6 +44,11 @@ BJX_L1P_FN int64_t bjx_l1p_bits(double v) {
   memcpy(&b, &v, 8);
   return b;
 }
+BJX_L1P_FN double bjx_l1p_from_bits(int64_t b) {
+  double v;
+  memcpy(&v, &b, 8);
+  return v;
+}
 #else
 #define BJX_L1P_FN __device__ __forceinline__
 BJX_L1P_FN double bjx_l1p_fma(double a, double b, double c) { return fma(a, b, c); }
@@ -53,19 +59,28 @@ BJX_L1P_FN double bjx_l1p_rcp(double d) {
   return r;
 }
 BJX_L1P_FN int64_t bjx_l1p_bits(double v) { return __double_as_longlong(v); }
+BJX_L1P_FN double bjx_l1p_from_bits(int64_t b) { return __longlong_as_double(b); }
 #endif
 
 // -log1p(t) in fp64 with relative error < 2^-47.  Requires -1 < t <= 0.
+// Round 4: the exponent / mantissa split of u = 1 + t and the sqrt(1/2) threshold are integer operations on
+// the HIGH WORD of u (u is a positive normal number: t > -1 means u >= 2^-24) instead of frexp + an fp64
+// compare, multiply and select -- the threshold only picks which of two equally valid argument reductions
+// is used (one hi-word quantum = 2^-20 relative off sqrt(1/2) moves z by 2^-21 of its bound), and the
+// exhaustive host check below covers every fp32 input.
 BJX_L1P_FN double bjx_neg_log1p_core(float t) {
   const double td = (double)t;
   const double u = 1.0 + td;
   const double c = td - (u - 1.0);  // exact; non-zero only for |t| < 2^-29 where u ~= 1
-  int e;
-  double m = frexp(u, &e);  // m in [0.5, 1)
-  if (m < 0.70710678118654752440) {
-    m *= 2.0;
+  const int64_t ub = bjx_l1p_bits(u);
+  uint32_t hi = (uint32_t)((uint64_t)ub >> 32);
+  int e = (int)(hi >> 20) - 1022;              // u = m * 2^e, m in [0.5, 1)   (frexp's convention)
+  hi = (hi & 0x000FFFFFu) | 0x3FE00000u;
+  if (hi < 0x3FE6A09Eu) {                      // m < sqrt(1/2), to the precision of the high word
+    hi += 0x00100000u;                         // m *= 2
     e -= 1;
   }
+  const double m = bjx_l1p_from_bits((int64_t)(((uint64_t)hi << 32) | ((uint64_t)ub & 0xFFFFFFFFull)));
   const double f = m - 1.0;  // exact
   const double s = f * bjx_l1p_rcp(m + 1.0);
   const double z = s * s;
@@ -89,9 +104,9 @@ BJX_L1P_FN double bjx_neg_log1p_core(float t) {
 // returns false (ambiguous: the caller must use the library log1p) otherwise.
 BJX_L1P_FN bool bjx_neg_log1p_fast(float t, float* w) {
   const double r = bjx_neg_log1p_core(t);
-  // Ziv rounding test on the 29 mantissa bits fp32 discards
-  const int64_t low = bjx_l1p_bits(r) & ((1ll << 29) - 1);
-  const int64_t dist = low > (1ll << 28) ? low - (1ll << 28) : (1ll << 28) - low;
+  // Ziv rounding test on the 29 mantissa bits fp32 discards (all of them in the low word)
+  const uint32_t low = (uint32_t)bjx_l1p_bits(r) & 0x1FFFFFFFu;
+  const uint32_t dist = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
   *w = (float)r;
-  return dist > 512;
+  return dist > 512u;
 }
