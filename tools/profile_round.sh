@@ -6,7 +6,7 @@
 #   cache  : --chain-block <auto> Infinity-Cache blocks                                  (cache_assisted_frac)
 # and the two PMC passes of the streaming mode (FETCH_SIZE / WRITE_SIZE in SEPARATE runs, as
 # MI355X_MICROARCH.md prescribes).  Outputs land in gpurun_out/round_prof/;
-# `python tools/collect_profiles.py <tag> r03` then copies the summaries into profiles/r03/.
+# `python tools/collect_profiles.py <tag> r04` then copies the summaries into profiles/r04/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/round_prof
