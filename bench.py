@@ -446,7 +446,7 @@ def bench_c2(args, ctx):
                                 streams=ns_)
                 st_t = alg_t.init(q_init)
                 # 3 priming transitions (graph recording, allocator) + 5 timed ones: with 2 + 2 the
-                # candidates within 3 % of each other were ranked by noise
+                # candidates within 3 % of each other were ranked by noise (NOTEBOOK.md section 5)
                 for kk in bjx.random.split(bjx.random.key(777), 3):
                     st_t, _ = alg_t.step(kk, st_t)
                 torch.cuda.synchronize()
@@ -791,7 +791,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
     chains PER GPU, eps = 0.1, identity metric -- under the external-callable contract (the funnel is
     the library's HIP callable, evaluated between two tick launches; ``fuse_target`` stays off).
     Timed region = ONE ``alg.run(key, state, T)`` (free-running chains: every chain walks through its own
-    T trees); ``value`` = leapfrogs all chains took / wall.  A second region times
+    T trees, NOTEBOOK.md section 7); ``value`` = leapfrogs all chains took / wall.  A second region times
     ``lockstep_steps`` calls of ``alg.step`` (the reference's API: all chains in lockstep)."""
     import blackjax_amd as bjx
     from blackjax_amd import _lib

@@ -1,6 +1,6 @@
 // Device-side building blocks shared by every kernel of libbjxhip (gfx950 only).
 //
-// Floating-point contract (see DESIGN.md "Numerics"): built with -ffp-contract=off;
+// Floating-point contract (see NOTEBOOK.md "Numerics"): built with -ffp-contract=off;
 // every fused multiply-add is an explicit fmaf(); reductions and scalar
 // transcendentals are evaluated in fp64 and rounded once to fp32.
 #pragma once
@@ -129,7 +129,7 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
 // lanes (row_shr 1, 2, 4, 8, zeros shifted in), lane 15 of rows 0 / 2 added into rows 1 / 3
 // (row_bcast:15), lane 31 into rows 2 and 3 (row_bcast:31); lane 63 then holds the total, which
 // readlane broadcasts.  The summation order differs from the butterfly's; in fp64 that moves the
-// sum by ~1e-16 relative, far below the fp32 rounding every caller applies.
+// sum by ~1e-16 relative, far below the fp32 rounding every caller applies (NOTEBOOK.md section 3).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);

@@ -40,7 +40,7 @@ ColGeom col_geom(int64_t N, int64_t D, int vec) {
   if (g.ncb < 1) g.ncb = 1;
   // 512 slabs = 2 workgroups per CU on a large batch: more slabs buy occupancy but every slab writes
   // (and k_colfinal re-reads) K * D doubles; 256 / 512 / 1024 slabs measured 131 / 136 / 143 us for the
-  // fused ChEES pass at 65 536 x 1 024
+  // fused ChEES pass at 65 536 x 1 024 (NOTEBOOK.md section 11)
   int64_t want = 512 / g.ncb;
   if (want < 1) want = 1;
   // rows are dealt to the slabs in chunks of kColU * rp rows, round robin (slab b takes chunks b,
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_chees_wcol(int64_t N, int64_t D, int tp
 // (scalar loads), and nothing synchronises inside the row loop -- the four waves of a workgroup only
 // meet at the end, where they add their column sums into LDS one after the other (fixed order).
 // Measured at 65 536 x 1 024 against k_chees_wcol (a row spread over four waves, one barrier per eight
-// rows): see DESIGN.md section 11.
+// rows): see NOTEBOOK.md section 11.
 // FULL: D == NI * 256, every lane owns NI valid pieces -- no exec-masked branches around the loads, so
 // the compiler counts the outstanding loads exactly (with them it falls back to vmcnt(0) and the
 // pipeline degenerates).

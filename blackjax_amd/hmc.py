@@ -63,7 +63,7 @@ def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:
     return HMCState(position, logp, grad)
 
 
-_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switch
+_FUSE_FIRST = __import__("os").environ.get("BJX_HMC_FUSE_FIRST", "1") != "0"  # A/B switch (NOTEBOOK.md section 5)
 
 
 def _launch_leapfrog(stream, metric, N, D, n_kicks, eps, eps_pc, q_in, p_in, g, q_out, p_out):

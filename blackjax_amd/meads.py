@@ -11,7 +11,7 @@ its own whitened positions, and every ``K`` steps the chains are reshuffled over
 Scope: the diagonal momentum metric (``low_rank_rank=None``, the reference's default and "the
 original behavior"); the MEADS-LRD low-rank extension raises.  Single process: the folds and the
 reshuffle span the whole ensemble, so under chain sharding this warm-up would exchange entire states
-every ``K`` steps -- run it on one GPU.
+every ``K`` steps -- run it on one GPU (NOTEBOOK.md section 11).
 
 Where the work is: the GHMC transition is HIP (include/bjx_ghmc.h), and since round 3 so are the
 per-step fold statistics (``bjx_meads_fold_moments / _build / _params``; the two Gram matrices per fold

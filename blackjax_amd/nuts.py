@@ -441,7 +441,7 @@ def auto_row_block(n_rows: int, dim: int) -> int:
     ``BJX_NUTS_ROW_BLOCK=n`` or pass ``row_block=n``) was measured SLOWER at the C3 shape (32 768 x
     256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s; on the
     final kernels 184-191 vs 164 / 131): a tick moves more than the cache holds between two uses of
-    a row whatever the grouping, and the smaller launches cost."""
+    a row whatever the grouping, and the smaller launches cost (NOTEBOOK.md section 7)."""
     import os
 
     v = os.environ.get("BJX_NUTS_ROW_BLOCK", "")
@@ -507,7 +507,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     device function the stand-alone target kernel runs, so a tick is one launch instead of two and the
     results are bit for bit those of the default path.  This leaves the external-callable contract of
     the engine (any PyTorch callable between two ticks) -- it shows what that contract costs: the tail of
-    a run is two dependent launches per leapfrog, ~10-14 us, against one.
+    a run is two dependent launches per leapfrog, ~10-14 us, against one (NOTEBOOK.md section 7).
 
     ``integrator``: any palindromic coefficient list of ``blackjax_amd.integrators`` (round 4).  With K > 1
     gradients per leapfrog a leaf lasts K ticks -- K - 1 middle stages (kick b_i, drift a_i) and the tick that
@@ -646,7 +646,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     fused = False
     rtc_module = None
     # with an engine-resident target a whole chunk of ticks is ONE launch for batches of at most this many
-    # rows (default: always; 0 = one launch per tick).  Measured at C3: every chunk as
+    # rows (default: always; 0 = one launch per tick).  Measured at C3 (NOTEBOOK.md section 7): every chunk as
     # one launch 322 / 340 / 220 M/s at T = 20 / 100 / 400, only below 8 192 rows 239 / 254 / 181, one launch
     # per tick 190 / 212 / 112, the external-callable path 172 / 200 / 99
     multi_tick_rows = int(_os_environ().get("BJX_NUTS_MULTI_TICK_ROWS", str(N)))

@@ -112,7 +112,7 @@ typedef struct {
    * bjx_dense_apply_imm (one GEMM for all live rows).  bjx_nuts_pre / _mid / _post (and their _ctl
    * forms) then read their velocities from it instead of running one fp64 mat-vec per chain
    * (D^2 words per chain and leapfrog).  The products are fp32 fmaf chains in the engine's stated k
-   * order, i.e. the oracle's "f32chain" mode.  post must then be called
+   * order (NOTEBOOK.md section 3 item 6), i.e. the oracle's "f32chain" mode.  post must then be called
    * with fuse_next = 0 (the next leaf's opening velocity needs its own product).  NULL: as before. */
   const float* v_pre;
 } bjx_nuts_t;
@@ -282,7 +282,7 @@ typedef struct {
    * target kernel runs (csrc/bjx_targets_dev.h: identical results), written to logp_f[b] / gf[b] -- the
    * arrays passed to bjx_nuts_async_tick, which are then in/out -- so the caller launches NO callable
    * between ticks: one launch per leapfrog instead of two.  This is outside the external-callable
-   * contract of the engine: it exists for the targets the library itself ships.
+   * contract of the engine (NOTEBOOK.md section 7): it exists for the targets the library itself ships.
    * BJX_TARGET_NEAL_FUNNEL: no parameters; BJX_TARGET_DIAG_GAUSSIAN: target_vec = inv_var (D,), D > 128. */
   int32_t target_kind;
   int32_t ticks_per_launch;   /* target_kind != 0: every wave advances ITS chain by this many ticks inside one

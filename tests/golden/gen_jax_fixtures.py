@@ -20,7 +20,7 @@ What it records (all under jax's default ``jax_threefry_partitionable``, float32
             (16 chains, 4 folds: freezing, cross-fold roll, three reshuffles)
 
 tests/test_jax_fixtures.py loads the file when present and compares the oracle (CPU) and the HIP
-path (GPU) with it; until then the RNG bit stream stays "parity unpinned" (DESIGN.md section 3).
+path (GPU) with it; until then the RNG bit stream stays "parity unpinned" (NOTEBOOK.md section 3).
 """
 import json
 import os

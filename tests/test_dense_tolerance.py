@@ -1,4 +1,4 @@
-"""THE stated tolerance of the dense-metric path (VERDICT r2 "next" #4).
+"""THE stated tolerance of the dense-metric path (VERDICT r2 "next" #4; NOTEBOOK.md section 3 item 6).
 
 The reference applies a dense metric with ``jnp.dot(..., precision="highest")`` (util.py:23-61), an
 fp32 dot whose summation ORDER is unspecified.  The engine's shared-matrix path is an fp32 fmaf chain in

@@ -3,7 +3,7 @@
 ``tests/golden/jax_fixtures.json`` is produced by ``tests/golden/gen_jax_fixtures.py`` on a machine
 with jax + blackjax (neither is installable in the build container: no wheel, no network).  Until
 someone has run it, these tests SKIP and the jax.random bit stream stays "parity unpinned"
-(SURVEY.md section 8c / a34); once the file is committed they compare the
+(NOTEBOOK.md section 3); once the file is committed they compare the
 oracle (CPU) and the HIP path (GPU) with JAX's own output:
 
 * integer-derived draws (key words, split, fold_in, bits, uniform, bernoulli, randint): bit-exact

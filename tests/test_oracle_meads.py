@@ -1,7 +1,7 @@
 """CPU tests of the GHMC / MEADS oracle (oracle/ghmc.py, oracle/meads.py): the reference's own tests for
 this path restated on the oracle -- tests/adaptation/test_meads.py (base(), fold structure, validation)
 and tests/mcmc/test_sampling.py::test_ghmc / ::test_meads (statistical pins) -- plus the definition of
-``maximum_eigenvalue``.  The ``jax.random`` bit stream stays unpinned (no JAX here)."""
+``maximum_eigenvalue``.  The ``jax.random`` bit stream stays unpinned (no JAX here, NOTEBOOK.md section 3)."""
 import math
 
 import numpy as np

@@ -52,7 +52,7 @@ opt = bjx.optim.adam(0.5, b1=0, b2=0.95)
 warm.run(bjx.random.key(1), q0, args.step_size, opt, 3)
 names = ["bjx_chees_weights_colstats", "bjx_chees_weights", "bjx_chees_colstats", "bjx_chees_criterion", "bjx_pool_colsum", "bjx_leapfrog_diag"]
 # short leapfrog launches are sampled sparsely and all events come from a pre-recorded pool: creating
-# events inside the timed region slowed bench.py's region by 13 %
+# events inside the timed region slowed bench.py's region by 13 % (NOTEBOOK.md section 5)
 timer = _lib.LaunchTimer(names, every={"bjx_leapfrog_diag": 16}, capacity=4096)
 _lib.set_timer(timer)
 torch.cuda.synchronize()

@@ -32,7 +32,7 @@ warm = bjx.window_adaptation(bjx.hmc, fn, adaptation_info_fn=None, num_integrati
 g = torch.Generator(device=dev)
 g.manual_seed(args.rank)
 q0 = sig * torch.randn(N, D, device=dev, generator=g)
-# leapfrog launches are sampled sparsely, events come from a pre-recorded pool (DESIGN.md section 5:
+# leapfrog launches are sampled sparsely, events come from a pre-recorded pool (NOTEBOOK.md section 5:
 # creating events inside a timed region of ~50 us launches costs ~13 %)
 timer = _lib.LaunchTimer(["bjx_welford_update_diag", "bjx_da_update", "bjx_leapfrog_diag"],
                          every={"bjx_leapfrog_diag": 16}, capacity=4096)
