@@ -2439,13 +2439,17 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 // Leaf kernel of a two-kernel tick: 64 / GL compact rows per 64-thread workgroup (one wave).
 //   <16, NI>    four chains per wave (rows of at most 64 NI floats); two waves per SIMD (252 VGPRs at NI = 4)
 //   <64, 1>     one chain per wave, the v2 leaf's layout with this function's lower register pressure
-template <int GL, int NI, int WAVES>
+//   DEFER       (GL = 64) no second kernel: a chain whose transition ended in tick k (phase 3) is finished and
+//               restarted by ITS wave of tick k + 1's launch (async_end2_chain) -- the work-list kernel and its
+//               launch boundary disappear from the tick, an ending chain spends one extra tick per transition
+template <int GL, int NI, int WAVES, bool DEFER = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
   constexpr int VEC = 4;
   constexpr int CPW = 64 / GL;  // chains per wave
-  if (ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
+  static_assert(!DEFER || GL == 64, "deferred transition ends: one chain per wave");
+  if (!DEFER && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
     ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
   const int64_t n_rows = async_n_rows(ax);
   const int g = threadIdx.x & (GL - 1);
@@ -2511,10 +2515,17 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
 #pragma unroll
       for (int k = 0; k < kRecHot / 4; ++k)
         *reinterpret_cast<int4*>(recp + 4 * k) = make_int4(rw[4 * k], rw[4 * k + 1], rw[4 * k + 2], rw[4 * k + 3]);
-      if (done && ax.end_list)  // rows whose transition ended go on the work list of the second kernel
+      if (!DEFER && done && ax.end_list)  // rows whose transition ended go on the work list of the second kernel
         ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
     }
-  } else if (phase == 0 && ax.end_list && g == 0) {  // first tick of a run: every chain starts
+  } else if (DEFER && (phase == 3 || phase == 0)) {
+    if constexpr (GL == 64) {  // record, accept, adapt, momentum draw, tree start, first opening half
+      int w = recp[threadIdx.x & (BJX_NUTS_REC_WORDS - 1)];
+      const int w_in = w;
+      async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
+      if ((int)threadIdx.x < BJX_NUTS_REC_WORDS && w != w_in) recp[threadIdx.x] = w;
+    }
+  } else if (!DEFER && phase == 0 && ax.end_list && g == 0) {  // first tick of a run: every chain starts
     ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
   }
 }
@@ -2902,9 +2913,12 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
     const bool tgt = run->target_kind != BJX_TARGET_NONE;
     static const int multi_waves = [] { const char* e = getenv("BJX_MULTI_WAVES"); return e ? atoi(e) : 2; }();
-    // Round-4 leaf kernels of the busy phase (D <= 256), BJX_NUTS_LEAF3: 0 = the v2 leaf; 16 = four chains per
-    // wave; 64 + w = one chain per wave with the lean register layout at w in {3, 4, 5, 6} waves per SIMD
-    static const int leaf3 = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 68; }();
+    // Round-4 leaf kernels of the busy phase (D <= 256), BJX_NUTS_LEAF3: 0 = the v2 leaf + work-list kernel;
+    // 16 = four chains per wave; 64 + w = one chain per wave with the lean register layout (w = waves-per-SIMD
+    // hint) + work-list kernel; 128 + w (default 132) = the same leaf with the transition ends DEFERRED into the
+    // next tick's launch -- one kernel per tick instead of two (C3: 194 -> 220 M/s at T = 100 on one box)
+    static const int leaf3 = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 132; }();
+    bool deferred_ends = false;
 #define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
   do {                                                                                                            \
     if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
@@ -2934,7 +2948,12 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
       else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
       if (leaf3 != 0 && NI_ == 1 && !tgt && run->end_list && run->end_count) {             \
-        if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
+        if (leaf3 >= 128) {  /* 128 + w: one chain per wave, transition ends deferred into the next launch */ \
+          const dim3 g1((unsigned)run->n_rows);                                            \
+          if (leaf3 == 128 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 3, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 4, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                  \
+          deferred_ends = true;                                                            \
+        } else if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
           const dim3 g1((unsigned)run->n_rows);                                            \
           if (leaf3 == 64 + 8) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 8>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
           else if (leaf3 == 64 + 7) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 7>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
@@ -2951,7 +2970,8 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
           else hipLaunchKernelGGL((k_nuts_async_tick3<16, 4, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);               \
         }                                                                                  \
       } else if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);     \
-      if (run->end_list && run->end_count)                                                 \
+      if (deferred_ends) { /* no second kernel */ }                                        \
+      else if (run->end_list && run->end_count)                                            \
         BJX_END_LIST(NI_);                                                                 \
       else                                                                                 \
         BJX_TICK2_L(NI_, 1, 4);                                                            \

@@ -671,7 +671,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         fused = True
     dref, rref = ctypes.byref(desc), ctypes.byref(run)
     stream = _lib.current_stream()
-    max_ticks = T * ((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 2  # K ticks per leaf
+    # K ticks per leaf; + one tick per transition: the busy-phase leaf kernel finishes a transition in the
+    # tick AFTER the one that completed its tree (deferred transition ends, k_nuts_async_tick3<.., DEFER>)
+    max_ticks = T * (((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 1) + 4
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))

@@ -86,13 +86,15 @@ def _run(tmp_path, v3):
 
 
 def test_v3_leaf_is_bit_identical_to_v2_and_matches_the_oracle(tmp_path, dev):
-    a = _run(tmp_path, 68)  # one chain per wave, lean register layout (the default of the busy phase)
+    a = _run(tmp_path, 68)  # one chain per wave, lean register layout, work-list kernel for the transition ends
     b = _run(tmp_path, 0)   # the v2 leaf
     c = _run(tmp_path, 16)  # four chains per wave (kept as a measured alternative)
-    assert a.keys() == b.keys() == c.keys()
+    d = _run(tmp_path, 132)  # the default of the busy phase: the same leaf, transition ends deferred into the next launch
+    assert a.keys() == b.keys() == c.keys() == d.keys()
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
         assert np.array_equal(c[k], b[k], equal_nan=True), k
+        assert np.array_equal(d[k], b[k], equal_nan=True), k
     # trees of several depths, divergences and max-depth stops were in the comparison
     assert len(np.unique(a["funnel256.num_trajectory_expansions"])) >= 4
     assert a["perchain.num_trajectory_expansions"].max() == 5
