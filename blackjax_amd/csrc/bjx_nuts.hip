@@ -2886,14 +2886,23 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
   const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
-  static const int64_t fused_rows = [] {
+  // largest batch whose tick is ONE launch doing leaf and transition end in the same wave (round 2: 8 192).
+  // Round 4: where the lean leaf with deferred transition ends exists (diagonal metric, rows of at most 256
+  // floats, no engine-resident target: k_nuts_async_tick3<64, 1, W, DEFER>) it is ALSO one launch per tick and
+  // faster at every batch size (C3, T = 100 / 400: 221 / 105 M/s with the round-2 threshold, 234 / 113 at 512,
+  // 251 / 136 at 0), so the default threshold there is 0; -1 = "unset".
+  static const int64_t fused_rows_env = [] {
     const char* e = getenv("BJX_NUTS_FUSED_ROWS");
-    return e ? atoll(e) : (int64_t)8192;
+    return e ? atoll(e) : (int64_t)-1;
   }();
   // One launch per tick (leaf, fence, boundary in the same wave) unless nearly all chains of a large
   // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
   // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
   // one launch per tick for small batches -- and always when the launch carries several ticks per chain
+  static const int leaf3_env = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 132; }();
+  const bool lean_deferred = leaf3_env >= 128 && nuts->D <= 256 && run->target_kind == BJX_TARGET_NONE &&
+                             run->end_list && run->end_count && run->rec && run->front_p;
+  const int64_t fused_rows = fused_rows_env >= 0 ? fused_rows_env : (lean_deferred ? (int64_t)0 : (int64_t)8192);
   const bool fused = run->n_rows <= fused_rows || run->ticks_per_launch > 1;
   static const bool use_v2 = [] {
     const char* e = getenv("BJX_NUTS_V2");
