@@ -860,7 +860,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         return None
     peak_rate = HBM_PEAK_GBS * 1e9 / (52.0 * D)  # chain-leapfrogs/s per GPU at 52 B per element
     roofline = {
-        "bound": "hbm", "kernel": "k_nuts_async_tick2 (leaf) + k_nuts_async_end_list + funnel callable, whole run",
+        "bound": "hbm", "kernel": "k_nuts_async_tick3<64,1,W,DEFER> (leaf + deferred transition ends, one launch per tick) + funnel callable, whole run",
         "achieved": value / world * 52.0 * D / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": value / world / peak_rate, "traffic": None,
         "algorithmic_bytes_per_chain_leapfrog": 52.0 * D,
@@ -869,8 +869,9 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
                             "whole-run figure: useful leapfrogs x 52 B x D / wall, tail of few live chains included",
         "full_ensemble_tick_us": tick_us,
         "full_ensemble_tick_achieved_GBps": (52.0 * D * N / (tick_us * 1e-6) / 1e9) if tick_us else None,
-        "full_ensemble_tick_note": "one tick = leaf kernel + transition-end kernel (+ the callable's launch is outside this "
-                                   "bracket) over all chains, first 24 bracketed ticks of a plain-launch run",
+        "full_ensemble_tick_note": "one tick kernel launch (leaf work + the transition ends deferred from the tick before; "
+                                   "the callable's launch is outside this bracket) over all chains, first 24 bracketed "
+                                   "ticks of a plain-launch run",
     }
     return {
         "metric": "NUTS useful chain-leapfrog-steps/sec (whole node), 32 768 chains x 256-dim funnel",

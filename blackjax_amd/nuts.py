@@ -818,7 +818,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         def chunk_ticks(self):
             """Ticks per recorded sequence: the few-row tiers are pure launch latency (two dependent
             kernels per tick), so their sequences are longer -- fewer replay boundaries per tick."""
-            return self.n_ticks * (4 if (self.tiered and self.view <= 128) else 1)
+            mult = int(_os.environ.get("BJX_NUTS_TAIL_SEQ_MULT", "4"))
+            return self.n_ticks * (mult if (self.tiered and self.view <= 128) else 1)
 
         def enter(self, groups_in, n_active):
             off = 0

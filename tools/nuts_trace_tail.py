@@ -9,8 +9,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
-def is_tick(name):  # the one-launch tick: round-1 k_nuts_async_fused or k_nuts_async_tick2<NI, 2, WAVES>
-    if "async_fused" in name:
+def is_tick(name):  # the one-launch tick: round-1 k_nuts_async_fused, k_nuts_async_tick2<NI, 2, WAVES>, or (round 4)
+    # the lean leaf with deferred transition ends k_nuts_async_tick3<64, 1, W, true>
+    if "async_fused" in name or "async_tick3<" in name:
         return True
     return "async_tick2<" in name and name.split("async_tick2<")[1].split(",")[1].strip() == "2"
 

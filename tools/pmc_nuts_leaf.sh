@@ -7,8 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_nuts_leaf
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-for v in ${BJX_LEAF_VARIANTS:-68 0 16}; do
+for v in ${BJX_LEAF_VARIANTS:-132 68 0 16}; do
   export BJX_NUTS_LEAF3=$v
+  export BJX_NUTS_FUSED_ROWS=8192
   rocprofv3 --kernel-trace --output-format csv -d $OUT/kt$v -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing --run-graph off > $OUT/kt$v.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $OUT/c$v -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing --run-graph off > $OUT/c$v.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/d$v -- python $R/tools/bench_nuts.py --free-running --steps 20 --no-tick-timing --run-graph off > $OUT/d$v.log 2>&1
@@ -18,7 +19,7 @@ python - <<'PY'
 import csv, glob, json, collections
 import os
 KEYS = ("async_tick3", "async_tick2<1, 0", "async_tick2<1, 2", "async_end_list", "k_neal_funnel")
-VARIANTS = [int(x) for x in os.environ.get("BJX_LEAF_VARIANTS", "68 0 16").split()]
+VARIANTS = [int(x) for x in os.environ.get("BJX_LEAF_VARIANTS", "132 68 0 16").split()]
 def name_of(k):
     for key in KEYS:
         if key in k:
