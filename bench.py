@@ -827,6 +827,23 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
     ticks = int(pooled[:, 1].max())
     value = tot / dt
 
+    # ---- the tail-heavy regime: T = 400 (from the second hundred transitions on a handful of chains sit in the
+    # funnel's mouth and build depth-10 trees at every transition: 97 % of the run is a few live chains)
+    t400 = None
+    if world == 1 and not args.no_c3_t400 and N == 32768 and D == 256:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, ri4 = alg.run(bjx.random.key(1), state, 400, store_positions=False)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t0
+        tot4 = float(ri4.num_integration_steps.sum())
+        ticks4 = int(ri4.num_integration_steps.sum(0).max())
+        t400 = {"value": tot4 / dt4, "unit": "chain-leapfrog-steps/s", "transitions": 400, "seconds": dt4,
+                "ms_per_transition": dt4 / 400 * 1e3, "frac_of_52B_roofline": tot4 / dt4 / (HBM_PEAK_GBS * 1e9 / (52.0 * D)),
+                "busiest_chain_leapfrogs": ticks4, "tick_period_avg_us": dt4 / max(ticks4, 1) * 1e6,
+                "utilisation": tot4 / (N * max(ticks4, 1))}
+        del ri4
+
     # ---- lockstep step(): the only call the reference's API has
     acc = torch.zeros((), device=dev, dtype=torch.float64)
     st_box = {"state": state}
@@ -890,6 +907,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         "ticks": ticks, "utilisation": tot / (world * N * max(ticks, 1)),
         "tick_period_avg_us": dt / max(ticks, 1) * 1e6,
         "mean_depth": float(pooled[:, 2].mean()), "frac_divergent": float(pooled[:, 3].mean()),
+        "free_running_T400": t400,
         "lockstep_step": {
             "value": tot_l / dt_l, "unit": "chain-leapfrog-steps/s", "steps": lockstep_steps,
             "ms_per_transition": dt_l / lockstep_steps * 1e3,
@@ -1011,6 +1029,7 @@ def main():
                          "BASELINE.json configs[3] names)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--no-c3-t400", action="store_true", help="c3: skip the 400-transition (tail-heavy) region")
     ap.add_argument("--no-sub-configs", action="store_true",
                     help="c2 default run: skip the C3 / C5 / C4-shard sub-objects")
     ap.add_argument("--chains", type=int, default=0,

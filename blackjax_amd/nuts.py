@@ -380,8 +380,11 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
             # replay boundaries per leaf
             k = min(chunk_max if depth < 7 else 4 * chunk_max, n_leaves)
             for j, s_base in enumerate(range(0, n_leaves, k)):
-                if j > 0:
-                    # drop the chains whose subtree has stopped -- on the device, no host sync
+                if j > 0 and (n_cap > ws.MIN_BUCKET or (sync_every and j % sync_every == 0)):
+                    # drop the chains whose subtree has stopped -- on the device, no host sync.  Once the batch
+                    # is at its smallest recorded size nothing can shrink any more (the leaf kernels skip
+                    # stopped chains themselves), so the compaction launch is only made where the host reads
+                    # the live count (round 4: ~16 us per chunk in the deep doublings)
                     _lib.call("bjx_nuts_compact", stream, dref, I["SUB_ACTIVE"], -1, idx_ptr, idx_ptr,
                               ctl_ptr)
                     if sync_every and j % sync_every == 0:
