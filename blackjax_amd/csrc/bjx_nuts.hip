@@ -2075,10 +2075,7 @@ __device__ __forceinline__ double row_sum16(double v) {
 // total of a chain's row from its per-piece lane partials: wave_sum's tree for the v2 layout
 template <int GL, int NI>
 __device__ __forceinline__ double chain_sum(const double (&a)[NI]) {
-  if constexpr (GL == 64) {
-    static_assert(NI == 1, "one chain per wave: one piece per lane");
-    return wave_sum(a[0]);
-  }
+  if constexpr (GL == 64) return wave_sum(a[0]);  // one chain per wave: the partials of all pieces are in a[0] (ACC below)
   double r[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < NI; ++k) r[k] = row_sum16(a[k]);
@@ -2179,15 +2176,20 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   const float u = sq == 0 ? RF(RW_U0) : (sq == 1 ? RF(RW_U0 + 1) : (sq == 2 ? RF(RW_U0 + 2) : RF(RW_U0 + 3)));
 
   // pass 1: closing half kick, kinetic energy
+  // ACC: with one chain per wave (GL = 64) a lane adds the pieces of a row into ONE accumulator, piece after
+  // piece -- the order of the round-2 kernels for rows of more than 256 floats; with 16 lanes per chain every
+  // piece keeps its own partial (chain_sum combines them in wave_sum's order)
+#define ACC(k_) (GL == 64 ? 0 : (k_))
   double a1[NI];
 #pragma unroll
+  for (int k = 0; k < NI; ++k) a1[k] = 0.0;
+#pragma unroll
   for (int k = 0; k < NI; ++k) {
-    a1[k] = 0.0;
     if (ok[k]) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         R.P[k].v[e] = fmaf(h, R.G[k].v[e], R.P[k].v[e]);
-        a1[k] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)R.P[k].v[e];
+        a1[ACC(k)] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)R.P[k].v[e];
       }
     }
   }
@@ -2240,13 +2242,15 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
     _Pragma("unroll") for (int k = 0; k < NI; ++k) {                              \
       al[k] = 0.0;                                                                \
       ar[k] = 0.0;                                                                \
+    }                                                                             \
+    _Pragma("unroll") for (int k = 0; k < NI; ++k) {                              \
       if (ok[k]) {                                                                \
         _Pragma("unroll") for (int e = 0; e < VEC; ++e) {                         \
           const float rl = C0[k].v[e];                                            \
           const float ssum = (S_AFTER(k, e) - C1_[k].v[e]) + rl;                  \
           const float rho = ssum - (R.P[k].v[e] + rl) * 0.5f; /* metrics.py:300 */ \
-          al[k] += (double)(R.M[k].v[e] * rl) * (double)rho;                      \
-          ar[k] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)rho;             \
+          al[ACC(k)] += (double)(R.M[k].v[e] * rl) * (double)rho;                 \
+          ar[ACC(k)] += (double)(R.M[k].v[e] * R.P[k].v[e]) * (double)rho;        \
         }                                                                         \
       }                                                                           \
     }                                                                             \
@@ -2324,6 +2328,9 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   for (int k = 0; k < NI; ++k) {
     al[k] = 0.0;
     ar[k] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
     if (ok[k]) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -2331,8 +2338,8 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
         const float pr = dir > 0 ? R.P[k].v[e] : OP[k].v[e];
         MS[k].v[e] = MS[k].v[e] + S_AFTER(k, e);
         const float rho = MS[k].v[e] - (pr + pl) * 0.5f;
-        al[k] += (double)(R.M[k].v[e] * pl) * (double)rho;
-        ar[k] += (double)(R.M[k].v[e] * pr) * (double)rho;
+        al[ACC(k)] += (double)(R.M[k].v[e] * pl) * (double)rho;
+        ar[ACC(k)] += (double)(R.M[k].v[e] * pr) * (double)rho;
       }
       str<VEC>(nt.msum + base + j0[k], MS[k]);
       if (take_m) {
@@ -2429,6 +2436,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   }
   return done;
 }
+#undef ACC
 #undef S_AFTER
 #undef RF
 #undef RSETF
@@ -2900,7 +2908,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
   // one launch per tick for small batches -- and always when the launch carries several ticks per chain
   static const int leaf3_env = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 132; }();
-  const bool lean_deferred = leaf3_env >= 128 && nuts->D <= 256 && run->target_kind == BJX_TARGET_NONE &&
+  const bool lean_deferred = leaf3_env >= 128 && nuts->D <= 512 && run->target_kind == BJX_TARGET_NONE &&
                              run->end_list && run->end_count && run->rec && run->front_p;
   const int64_t fused_rows = fused_rows_env >= 0 ? fused_rows_env : (lean_deferred ? (int64_t)0 : (int64_t)8192);
   const bool fused = run->n_rows <= fused_rows || run->ticks_per_launch > 1;
@@ -2956,11 +2964,11 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
       if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
       else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
     } else {                                                                               \
-      if (leaf3 != 0 && NI_ == 1 && !tgt && run->end_list && run->end_count) {             \
+      if (leaf3 != 0 && (NI_ == 1 || leaf3 >= 128) && !tgt && run->end_list && run->end_count) { \
         if (leaf3 >= 128) {  /* 128 + w: one chain per wave, transition ends deferred into the next launch */ \
           const dim3 g1((unsigned)run->n_rows);                                            \
-          if (leaf3 == 128 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 3, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 4, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                  \
+          if (leaf3 == 128 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 3, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 4, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                  \
           deferred_ends = true;                                                            \
         } else if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
           const dim3 g1((unsigned)run->n_rows);                                            \
