@@ -39,7 +39,8 @@ WORKER = textwrap.dedent("""
             out[name + "." + f] = getattr(info, f).cpu().numpy()
 
     g = torch.Generator(device=dev); g.manual_seed(0)
-    for D in (8, 64, 100, 128, 200, 256, 260, 384, 512):  # > 256: two 16-byte pieces per lane (deferred kernel only)
+    # > 256: two 16-byte pieces per lane; > 512: three / four (there the alternative is the round-1 general kernels)
+    for D in (8, 64, 100, 128, 200, 256, 260, 384, 512, 640, 1024):
         N = 301 if D != 256 else 1030
         q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
         run_case(f"funnel{D}", bjx.targets.NealFunnel(), N, D, 5, 8, 0.1, torch.ones(D, device=dev), q0)
