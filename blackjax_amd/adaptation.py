@@ -296,7 +296,12 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             raise ValueError("free_running=True records a NUTSRunInfo, not adaptation_info_fn's output: "
                              "pass adaptation_info_fn=None (or the default) with it")
         if integrator is not integrators.velocity_verlet:
-            raise NotImplementedError("free_running=True is implemented for velocity_verlet only")
+            from .nuts import free_running_supports
+
+            if fuse_target or not free_running_supports(integrator, "diag", state.position.shape[1]):
+                raise NotImplementedError(
+                    "free_running=True with a multi-stage integrator: 16-byte rows of at most 512 floats, no "
+                    "fuse_target (nuts.free_running_supports)")
         if _schedule_fn is not None:
             raise NotImplementedError("free_running=True uses the Stan schedule (build_schedule)")
         n, d = state.position.shape
@@ -315,7 +320,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
         state, _, run_info = _nuts_run_free(
             rng_key, state, logdensity_fn, ad["step_size"], imm_pc, num_steps, max_depth,
             divergence_threshold=div_thr, chain_offset=chain_offset, key_layout="chain_major",
-            store_positions=False, adaptation=ad, fuse_target=fuse_target)
+            store_positions=False, adaptation=ad, fuse_target=fuse_target, integrator=integrator)
         step_size = torch.empty_like(ad["log_x_avg"])
         _lib.call("bjx_exp", _lib.current_stream(), n, ad["log_x_avg"].data_ptr(), step_size.data_ptr())
         parameters = {"step_size": step_size,

@@ -9,7 +9,7 @@ the general-coefficient kernels: ``hmc`` and ``dynamic_hmc`` with diagonal and d
 (``bjx_nuts_t.int_kick / int_drift`` + ``bjx_nuts_mid``) and, round 4, ``run`` on the FREE-RUNNING tick kernels
 for a diagonal metric with 16-byte rows of at most 512 floats (a leaf lasts K ticks,
 ``bjx_nuts_async_t.int_stages``; other shapes run the same transitions as lockstep steps);
-``window_adaptation(..., free_running=True)`` integrates with velocity Verlet.  The non-Euclidean
+``window_adaptation(..., free_running=True)`` takes the same integrators under the same conditions.  The non-Euclidean
 integrators of the reference (isokinetic, maruyama, implicit midpoint) are out of scope.
 """
 from __future__ import annotations

@@ -89,3 +89,29 @@ def test_free_running_warmup_with_an_engine_resident_target(dev, N, D, T):
         assert torch.equal(getattr(info_a, name), getattr(info_b, name)), name
     with pytest.raises(ValueError):
         warm.run(prng.key(2), q0, T, fuse_target=True)
+
+
+@pytest.mark.parametrize("name", ["mclachlan", "omelyan"])
+def test_free_running_warmup_with_a_multi_stage_integrator_equals_lockstep(dev, name):
+    """Round 4: the free-running warm-up takes any palindromic integrator the free-running tick kernels take
+    (a leaf lasts K ticks); step sizes, metrics, final states and per-step records equal the lockstep warm-up
+    with the same integrator bit for bit."""
+    N, D, T = 40, 64, 60
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    inv_var = (torch.rand(D, device=dev, generator=g) * 3.0 + 0.2).contiguous()
+    fn = bjx.targets.DiagGaussian(inv_var)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    integ = getattr(bjx.integrators, name)
+    kw = dict(initial_step_size=0.7, max_num_doublings=5, integrator=integ)
+    warm = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=bjx.adaptation.get_filter_adapt_info_fn(
+        set(), {"acceptance_rate", "num_integration_steps"}, {"step_size"}), **kw)
+    (st_l, par_l), hist = warm.run(prng.key(5), q0, T, chain_offset=2)
+    warm_f = bjx.window_adaptation(bjx.nuts, fn, adaptation_info_fn=None, **kw)
+    (st_f, par_f), info = warm_f.run(prng.key(5), q0, T, chain_offset=2, free_running=True)
+    assert torch.equal(st_f.position, st_l.position) and torch.equal(st_f.logdensity_grad, st_l.logdensity_grad)
+    assert torch.equal(par_f["step_size"], par_l["step_size"])
+    assert torch.equal(par_f["inverse_mass_matrix"], par_l["inverse_mass_matrix"])
+    assert torch.equal(info.acceptance_rate, hist.info.acceptance_rate)
+    assert torch.equal(info.num_integration_steps.to(hist.info.num_integration_steps.dtype),
+                       hist.info.num_integration_steps)
