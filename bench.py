@@ -800,8 +800,10 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
     N, D = args.chains or 32768, args.dim or 256
     T = int(T or args.steps)
     eps, max_depth = 0.1, 10
+    # "auto": the HIP-graph drivers for this recordable callable, with their fall-back to plain launches should a
+    # capture fail on some rank (a process group's watchdog thread) -- never an exception in a multi-rank run
     alg = bjx.nuts(bjx.targets.NealFunnel(), eps, torch.ones(D, device=dev), max_num_doublings=max_depth,
-                   chain_offset=rank * N, use_graph=True)
+                   chain_offset=rank * N, use_graph="auto")
     gen = torch.Generator(device=dev)
     gen.manual_seed(rank)
     state = alg.init(0.1 * torch.randn(N, D, device=dev, generator=gen))

@@ -249,7 +249,7 @@ class _GraphedTrajectory:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may poll events
             self.logp, self.g = self._body()
 
     def _body(self):

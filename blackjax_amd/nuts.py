@@ -180,7 +180,7 @@ class _GraphWorkspace:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may poll events
                 keep = self._chunk_body(k, n_cap)
             self.ctl.copy_(saved)
             g = self.graphs[(k, n_cap)] = (graph, keep)
@@ -749,7 +749,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 lp_s, g_s = self.logp_f.clone(), self.gf.clone()
                 try:
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg):
+                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
                         lp_e, g_e = self.chunk(n_ticks, lp_s, g_s)
                         if lp_e is not lp_s:
                             lp_s.copy_(lp_e)
@@ -882,7 +882,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             if can_record:
                 try:
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg):
+                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
                         self._body(k, n)
                     self.graph[(k, self.view)] = (cg, n)
                 except Exception:
