@@ -87,6 +87,10 @@ SIGNATURES = {
                                    c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p,
                                    _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p,
                                    _f32p, c_void_p],
+    "bjx_mhmc_step_dense_coef": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                 c_float, c_float, _f32p, _f32p, c_int64, c_float, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                 _f32p, _f32p, _f32p, _f32p, _f32p, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p,
+                                 _f32p, c_void_p],
     "bjx_pc_matvec_t": [c_void_p, c_int64, c_int64, _f32p, c_int64, _f32p, _f32p],
     "bjx_hmc_momentum_dense_pc": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
                                   _f32p, _f32p, c_int64, _f32p, _f32p, _f32p, _f32p],

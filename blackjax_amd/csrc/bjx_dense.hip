@@ -1250,7 +1250,8 @@ static int mhmc_step_dense(const char* who, void* stream, uint32_t key0, uint32_
                            const float* p, const float* g, const float* logp_new, float* p1_work,
                            float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
                            uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
-                           float* prop_logp, float* prop_energy, const int32_t* n_steps) {
+                           float* prop_logp, float* prop_energy, const int32_t* n_steps,
+                           float kick_coef = 0.5f) {
   if (N == 0) return 0;  // empty batch: no buffers to check, nothing to do
   if (!(N >= 0 && D > 0 && step >= 0 && step < ((int64_t)1 << 31) && imm && logp0 && ke0 && q && p && g &&
         logp_new && p1_work && v_work && weight && sum_log_p_accept && any_divergent && ever_accepted && prop_q &&
@@ -1260,16 +1261,19 @@ static int mhmc_step_dense(const char* who, void* stream, uint32_t key0, uint32_
     return 1;
   }
   hipStream_t s = (hipStream_t)stream;
-  // closing half kick p1 = p + (eps/2) g ; v1 = imm p1.  With n_steps, rows whose trajectory is complete
-  // keep their momentum (the prologue copies it through) and are skipped by the reservoir step below.
+  // closing kick p1 = p + (eps kick_coef) g (kick_coef = 1/2 for velocity Verlet) ; v1 = imm p1.  With n_steps,
+  // rows whose trajectory is complete keep their momentum (the prologue copies it through) and are skipped by
+  // the reservoir step below.
   if (matrix_stride < 0) {
     GemmArgs ga{N, D, p, g, 1, eps, eps_per_chain, p1_work, imm, v_work, nullptr, nullptr};
+    ga.kick_a = kick_coef;
     ga.b_symmetric = true;
     ga.n_steps = n_steps;
     ga.step_idx = (int32_t)step;
     if (int rc = launch_gemm(s, EPI_STORE, ga)) return rc;
   } else {
     PcArgs pa{N, D, imm, matrix_stride, p, g, 1, eps, eps_per_chain, p1_work, v_work, nullptr, nullptr};
+    pa.kick_a = kick_coef;
     pa.n_steps = n_steps;
     pa.step_idx = (int32_t)step;
     if (int rc = launch_pc(s, EPI_STORE, pa)) return rc;
@@ -1308,6 +1312,20 @@ int bjx_mhmc_step_dense_masked(void* stream, uint32_t key0, uint32_t key1, int64
                          eps, eps_per_chain, imm, matrix_stride, divergence_threshold, logp0, ke0, q, p, g,
                          logp_new, p1_work, v_work, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q,
                          prop_p, prop_g, prop_logp, prop_energy, n_steps);
+}
+
+int bjx_mhmc_step_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                             int64_t step_fold, int64_t N, int64_t D, int64_t step, float kick_coef, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                             float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                             const float* p, const float* g, const float* logp_new, float* p1_work,
+                             float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                             uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                             float* prop_logp, float* prop_energy, const int32_t* n_steps) {
+  return mhmc_step_dense("bjx_mhmc_step_dense_coef", stream, key0, key1, chain_offset, step_fold, N, D, step,
+                         eps, eps_per_chain, imm, matrix_stride, divergence_threshold, logp0, ke0, q, p, g,
+                         logp_new, p1_work, v_work, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q,
+                         prop_p, prop_g, prop_logp, prop_energy, n_steps, kick_coef);
 }
 
 }  // extern "C"

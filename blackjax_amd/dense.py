@@ -90,9 +90,10 @@ def finish_coef(stream, metric, k0, k1, off, fold, n, d, kick_coef, eps, eps_pc,
 
 
 def mhmc_step(stream, metric, k0, k1, off, fold, n, d, step, eps, eps_pc, thr, logp0, ke0, q, p, g, logp,
-              weight, slpa, any_div, ever, pq, pp, pg, plogp, penergy, n_steps=None):
+              weight, slpa, any_div, ever, pq, pp, pg, plogp, penergy, n_steps=None, kick_coef=None):
     """Closing half kick + reservoir step of multinomial HMC; returns the fully kicked momentum.
-    ``n_steps``: per-chain trajectory lengths (dmhmc) -- chains with ``step >= n_steps`` are left alone."""
+    ``n_steps``: per-chain trajectory lengths (dmhmc) -- chains with ``step >= n_steps`` are left alone.
+    ``kick_coef``: closing-kick coefficient b1 of a general palindromic integrator (None: velocity Verlet)."""
     p1 = torch.empty_like(p)
     v = torch.empty_like(p)
     args = (stream, k0, k1, off, fold, n, d, step, eps, _lib.ptr(eps_pc),
@@ -100,7 +101,9 @@ def mhmc_step(stream, metric, k0, k1, off, fold, n, d, step, eps, eps_pc, thr, l
             q.data_ptr(), p.data_ptr(), g.data_ptr(), logp.data_ptr(), p1.data_ptr(), v.data_ptr(),
             weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(),
             pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr())
-    if n_steps is None:
+    if kick_coef is not None:  # any palindromic integrator: closing kick (eps * b1) g (round 4)
+        _lib.call("bjx_mhmc_step_dense_coef", *args[:9], float(kick_coef), *args[9:], _lib.ptr(n_steps))
+    elif n_steps is None:
         _lib.call("bjx_mhmc_step_dense", *args)
     else:
         _lib.call("bjx_mhmc_step_dense_masked", *args, n_steps.data_ptr())

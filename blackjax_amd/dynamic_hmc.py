@@ -238,8 +238,8 @@ def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integrat
     """blackjax.dmhmc (blackjax/__init__.py:155-163): every chain draws its own trajectory length and one
     state of ITS trajectory proportionally to exp(-H) (hmc.py:181-248 over dynamic_hmc.py:85-118).  The
     per-chain lengths mask the fused step kernel of ``blackjax_amd.mhmc`` (diagonal metric) or, with a dense
-    metric (one shared matrix: MFMA GEMMs; one per chain: fp64 matrix-vector kernels; velocity Verlet), the
-    masked dense leapfrog and ``bjx_mhmc_step_dense_masked``."""
+    metric (one shared matrix: MFMA GEMMs; one per chain: fp64 matrix-vector kernels), the
+    masked dense leapfrog and ``bjx_mhmc_step_dense_masked`` / ``_coef`` (any palindromic integrator since round 4)."""
 
     def kernel(rng_key, state: DynamicHMCState, logdensity_fn: Callable, step_size,
                inverse_mass_matrix, integration_steps_params: tuple = (), *, chain_offset: int = 0):
@@ -252,8 +252,6 @@ def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integrat
         vg = value_and_grad(logdensity_fn)
         metric = metrics.default_metric(inverse_mass_matrix, N, D, dev)
         is_diag = metric.kind == "diag"
-        if not is_diag and (tuple(kick_c) != (0.5, 0.5) or tuple(drift_c) != (1.0,)):
-            raise NotImplementedError("dmhmc with a dense metric is implemented for velocity_verlet")
         eps, eps_pc = step_size_args(step_size, N, dev)
         stream = _lib.current_stream()
         off = int(chain_offset)
@@ -284,15 +282,21 @@ def _build_multinomial_kernel(thr: float, next_random_arg_fn: Callable, integrat
             # opening kick + drift, callable, closing kick + reservoir step; the next leapfrog starts from
             # the fully kicked momentum with its own opening kick (blackjax_amd.hmc, dense branch) -- every
             # launch masked by the chain's own length
-            p_half = dense.leapfrog_coef(stream, metric, N, D, 1, 0.5, 0.0, 1.0, eps, eps_pc, q0, p0, g0, q, p)
+            # (any palindromic integrator since round 4: opening (b1, a1), stages in between, closing kick b1)
+            general = tuple(kick_c) != (0.5, 0.5) or tuple(drift_c) != (1.0,)
+            p_half = dense.leapfrog_coef(stream, metric, N, D, 1, b1, 0.0, a1, eps, eps_pc, q0, p0, g0, q, p)
             for i in range(hi):
                 logp, g = eval_logdensity(vg, q)  # finished chains keep their q: same (logp, g) again, unused
+                for si in range(1, len(drift_c)):  # stages 2 .. K, masked by the chain's own length
+                    p_half = dense.leapfrog_coef(stream, metric, N, D, 1, float(kick_c[si]), 0.0, float(drift_c[si]),
+                                                 eps, eps_pc, q, p_half, g, q, torch.empty_like(q0), n_steps, i)
+                    logp, g = eval_logdensity(vg, q)
                 p1 = dense.mhmc_step(stream, metric, k0, k1, off, fold, N, D, i, eps, eps_pc, thr, logp0, ke0,
                                      q, p_half, g, logp, weight, slpa, any_div, ever, pq, pp, pg, plogp,
-                                     penergy, n_steps=n_steps)
+                                     penergy, n_steps=n_steps, kick_coef=b1 if general else None)
                 if i + 1 < hi:
-                    p_half = dense.leapfrog_coef(stream, metric, N, D, 1, 0.5, 0.0, 1.0, eps, eps_pc, q, p1, g,
-                                                 q, p_half, n_steps, i + 1)
+                    p_half = dense.leapfrog_coef(stream, metric, N, D, 1, b1, 0.0, a1, eps, eps_pc, q, p1, g,
+                                                 q, torch.empty_like(q0) if general else p_half, n_steps, i + 1)
         else:
             _lib.call("bjx_leapfrog_diag_coef", stream, N, D, 1, b1, 0.0, a1, eps, _lib.ptr(eps_pc), imm_p, imm_s,
                       q0.data_ptr(), p0.data_ptr(), g0.data_ptr(), q.data_ptr(), p.data_ptr(), None, 0)

@@ -155,8 +155,26 @@ def _build_mhmc_kernel(thr: float, kick_c=(0.5, 0.5), drift_c=(1.0,)):
                           ever.data_ptr(), pq.data_ptr(), pp.data_ptr(), pg.data_ptr(),
                           plogp.data_ptr(), penergy.data_ptr(), None, b1, a1)
         elif L > 0 and general:
-            raise NotImplementedError("mhmc with a dense metric is implemented for velocity_verlet "
-                                      "(mclachlan / yoshida / omelyan: diagonal metrics)")
+            # dense metric x any palindromic integrator (round 4): opening (b1, a1), the stages in between and the
+            # re-opening of the next step are bjx_leapfrog_dense_coef launches (kick prologue + GEMM / mat-vec +
+            # drift epilogue), the closing kick b1 + reservoir step is bjx_mhmc_step_dense_coef
+            from . import dense
+
+            b1, a1 = float(kick_c[0]), float(drift_c[0])
+            q, p_half = torch.empty_like(q0), torch.empty_like(q0)
+            p_half = dense.leapfrog_coef(stream, metric, N, D, 1, b1, 0.0, a1, eps, eps_pc, q0, p0, g0, q, p_half)
+            for i in range(L):
+                logp, g = eval_logdensity(vg, q)
+                for si in range(1, len(drift_c)):
+                    p_half = dense.leapfrog_coef(stream, metric, N, D, 1, float(kick_c[si]), 0.0, float(drift_c[si]),
+                                                 eps, eps_pc, q, p_half, g, q, torch.empty_like(q0))
+                    logp, g = eval_logdensity(vg, q)
+                p1 = dense.mhmc_step(stream, metric, k0, k1, off, fold, N, D, i, eps, eps_pc, thr, logp0,
+                                     ke0, q, p_half, g, logp, weight, slpa, any_div, ever, pq, pp, pg,
+                                     plogp, penergy, kick_coef=b1)
+                if i + 1 < L:
+                    p_half = dense.leapfrog_coef(stream, metric, N, D, 1, b1, 0.0, a1, eps, eps_pc, q, p1, g, q,
+                                                 torch.empty_like(q0))
         elif L > 0 and is_diag:
             q, p = torch.empty_like(q0), torch.empty_like(q0)
             _lib.call("bjx_leapfrog_diag", stream, N, D, 1, eps, _lib.ptr(eps_pc), imm_p, imm_s,

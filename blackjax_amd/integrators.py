@@ -4,8 +4,8 @@ An integrator is its coefficient list ``[b1, a1, b2, a2, ..., b1]`` (momentum / 
 alternating, ``generalized_two_stage_integrator`` 62-152).  ``velocity_verlet`` is implemented for
 every sampler and metric; ``mclachlan``, ``yoshida`` and ``omelyan`` (any palindromic list) run through
 the general-coefficient kernels: ``hmc`` and ``dynamic_hmc`` with diagonal and dense metrics
-(``bjx_leapfrog_*_coef`` / ``bjx_hmc_finish_*_coef``), ``mhmc`` / ``dmhmc`` with diagonal metrics
-(``bjx_mhmc_step_diag_coef``), and ``nuts`` -- lockstep ``step`` with diagonal and dense metrics
+(``bjx_leapfrog_*_coef`` / ``bjx_hmc_finish_*_coef``), ``mhmc`` / ``dmhmc`` with diagonal
+(``bjx_mhmc_step_diag_coef``) and -- round 4 -- dense metrics (``bjx_mhmc_step_dense_coef``), and ``nuts`` -- lockstep ``step`` with diagonal and dense metrics
 (``bjx_nuts_t.int_kick / int_drift`` + ``bjx_nuts_mid``) and, round 4, ``run`` on the FREE-RUNNING tick kernels
 for a diagonal metric with 16-byte rows of at most 512 floats (a leaf lasts K ticks,
 ``bjx_nuts_async_t.int_stages``; other shapes run the same transitions as lockstep steps);

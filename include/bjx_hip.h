@@ -316,6 +316,19 @@ int bjx_mhmc_step_dense_masked(void* stream, uint32_t key0, uint32_t key1, int64
                                uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
                                float* prop_logp, float* prop_energy, const int32_t* n_steps);
 
+/* bjx_mhmc_step_dense[_masked] for any palindromic integrator [b1, a1, ..., b1] (integrators.py:104-150, 335-369):
+ * the closing kick of a leapfrog is p1 = p + (eps kick_coef) g with kick_coef = b1 (1/2 = velocity Verlet);
+ * n_steps may be NULL (all chains take part: blackjax.mhmc) or per-chain trajectory lengths (blackjax.dmhmc).
+ * The opening stage and the stages in between are bjx_leapfrog_dense_coef launches (round 4). */
+int bjx_mhmc_step_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,
+                             int64_t step_fold, int64_t N, int64_t D, int64_t step, float kick_coef, float eps,
+                             const float* eps_per_chain, const float* imm, int64_t matrix_stride,
+                             float divergence_threshold, const float* logp0, const float* ke0, const float* q,
+                             const float* p, const float* g, const float* logp_new, float* p1_work,
+                             float* v_work, float* weight, float* sum_log_p_accept, uint8_t* any_divergent,
+                             uint8_t* ever_accepted, float* prop_q, float* prop_p, float* prop_g,
+                             float* prop_logp, float* prop_energy, const int32_t* n_steps);
+
 /* Closing half kick + energies + Metropolis accept + select with a dense metric (same contract as
  * bjx_hmc_finish_diag).  p1_work, v_work: (N, D) scratch (p1_work must not alias p). */
 int bjx_hmc_finish_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

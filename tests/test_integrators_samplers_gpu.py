@@ -240,8 +240,19 @@ def test_nuts_free_running_with_a_multi_stage_integrator(dev, name, N, D, key_la
 def test_where_general_integrators_are_not_available():
     with pytest.raises(NotImplementedError):
         bjx.hmc.build_kernel(object())
-    alg = bjx.mhmc(bjx.targets.AR1Gaussian(0.5, 4), 0.1, torch.eye(4, device="cuda"), 2,
-                   integrator=bjx.integrators.mclachlan)
-    st = alg.init(torch.zeros(3, 4, device="cuda"))
+    # (mhmc / dmhmc with dense metrics take them since round 4: tests/test_frows_dense_gpu.py)
+    # free-running NUTS ticks: diagonal metric, 16-byte rows of at most 512 floats -- a wider row is refused by
+    # run_free itself (nuts(...).run then takes lockstep steps instead)
+    from blackjax_amd.nuts import free_running_supports, run_free
+
+    assert not free_running_supports(bjx.integrators.mclachlan, "diag", 516)
+    assert not free_running_supports(bjx.integrators.mclachlan, "dense", 64)
+    D = 516
+    alg = bjx.nuts(bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), integrator=bjx.integrators.mclachlan,
+                   max_num_doublings=3)
+    st = alg.init(0.1 * torch.ones(5, D, device="cuda"))
     with pytest.raises(NotImplementedError):
-        alg.step(bjx.random.key(0), st)
+        run_free(bjx.random.key(0), st, bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), 2, 3,
+                 integrator=bjx.integrators.mclachlan)
+    final, pos, info = alg.run(bjx.random.key(0), st, 2)  # falls back to lockstep steps
+    assert pos.shape == (2, 5, D)
