@@ -9,9 +9,11 @@ parallel" (ghmc.py:246-249), and the sampler the MEADS warm-up tunes (``blackjax
 The chain axis is native; chain ``i`` of ``step(rng_key, state)`` reproduces the reference's
 single-chain ``step(jax.random.split(rng_key, N)[i], state_i)``.  ``step_size``, ``alpha`` and ``delta``
 may be per-chain ``(N,)`` tensors, ``momentum_inverse_scale`` a scalar, ``(D,)`` or per-chain ``(N, D)``
-tensor (MEADS hands every fold its own values).  Only the per-dimension inverse-SCALE form of the
-momentum metric is built (ghmc.py:67-86, legacy branch: inverse mass matrix = scale ** 2); dense and
-low-rank momentum metrics (blackjax#950) are outside SURVEY.md section 8 and raise.
+tensor (MEADS hands every fold its own values) -- the per-dimension inverse-SCALE form of the momentum
+metric (ghmc.py:67-86, legacy branch: inverse mass matrix = scale ** 2) -- or, round 4, ONE dense ``(D, D)``
+INVERSE MASS MATRIX shared by all chains (the "rich metric" branch of ghmc.py:67-86: a 2-d array passes
+straight to ``default_metric``): momentum draw, velocity and kinetic energies on the fp32 MFMA GEMMs of
+``bjx_dense.hip``, the scalar tail as plain torch ops.  Low-rank metrics and callables raise.
 
 The arithmetic runs in libbjxhip (include/bjx_ghmc.h, include/bjx_hip.h); this module sequences
 refresh + kick + drift (one launch) -> user callable -> finish.
@@ -89,9 +91,7 @@ def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, dev
     if t.shape == (dim, dim) and not tagged:
         # the reference reads ANY 2-d argument as a dense inverse mass matrix (ghmc.py:67-86): a square
         # array is never silently taken for per-chain scales, whatever the number of chains
-        raise NotImplementedError("ghmc: a dense (d, d) momentum metric is outside the built scope "
-                                  "(per-dimension inverse scales: scalar, (D,), or per-chain (N, D) -- "
-                                  "wrapped in metrics.PerChainDiag when N == D)")
+        return t.contiguous(), -1  # stride -1: dense inverse mass matrix (not squared), _dense_step
     if t.shape not in ((dim,), (n_chains, dim)):
         raise ValueError(f"momentum_inverse_scale must be a scalar, ({dim},) or ({n_chains}, {dim}); got {tuple(t.shape)}")
     t = t.contiguous()
@@ -106,6 +106,58 @@ def _per_chain_or_scalar(x, n_chains: int, device, name: str):
             raise ValueError(f"per-chain {name} must have shape ({n_chains},), got {tuple(t.shape)}")
         return 0.0, t
     return float(x), None
+
+
+def _dense_step(k0, k1, fold, off, vg, thr, q0, p_prev, logp0, g0, sl_prev, imm_dense, eps, eps_pc, a_s, a_pc,
+                d_s, d_pc):
+    """One GHMC transition with ONE dense inverse mass matrix for all chains (ghmc.py:67-86 rich-metric branch,
+    116-198; proposal.py:243-264).  The O(N D^2) work -- fresh momentum p = L^-T z, velocities M^-1 p, the
+    leapfrog's kick + GEMM + drift, the closing kick and both kinetic energies -- are the dense-HMC entry
+    points (``bjx_hmc_momentum_dense``, ``bjx_dense_apply_imm``, ``bjx_leapfrog_dense``,
+    ``bjx_hmc_finish_dense``: fp32 MFMA GEMMs, the oracle's f32-chain arithmetic); the per-element mixing of
+    the momentum and the per-chain slice arithmetic are single-rounding torch ops in the reference's order."""
+    from . import dense
+
+    N, D = q0.shape
+    dev = q0.device
+    f32 = torch.float32
+    stream = _lib.current_stream()
+    metric = metrics.default_metric(imm_dense, N, D, dev)
+    fresh, ke_tmp = torch.empty_like(q0), torch.empty_like(logp0)
+    dense.momentum(stream, metric, k0, k1, off, fold, N, D, fresh, ke_tmp)  # key_momentum = split(chain key)[0]
+    alpha = a_pc[:, None] if a_pc is not None else torch.tensor(a_s, dtype=f32, device=dev)
+    delta = d_pc if d_pc is not None else torch.tensor(d_s, dtype=f32, device=dev)
+    s1, s2 = torch.sqrt(1.0 - alpha), torch.sqrt(alpha)
+    p = (p_prev * s1) + (s2 * fresh)  # update_momentum, ghmc.py:216-221: two products, one sum
+    t = ((sl_prev + 1.0) + delta) + 0.0  # ghmc.py:176 (noise_fn = 0)
+    sl = torch.remainder(t, 2.0) - 1.0
+    v0 = torch.empty_like(q0)
+    _lib.call("bjx_dense_apply_imm", stream, N, D, p.data_ptr(), metric.imm.data_ptr(), v0.data_ptr())
+    ke0 = (v0.double() * p.double()).sum(-1).to(f32) * 0.5  # metrics.py:263-270, fp64-accumulated, rounded once
+    q1, p_half = torch.empty_like(q0), torch.empty_like(q0)
+    p_half = dense.leapfrog(stream, metric, N, D, 1, eps, eps_pc, q0, p, g0, q1, p_half)
+    logp1, g1 = eval_logdensity(vg, q1)
+    # closing kick, K(p1), energies, p_accept, divergence: the dense-HMC tail (its uniform accept is not used)
+    scratch = [torch.empty_like(q0) for _ in range(2)]
+    p_end = torch.empty_like(q0)
+    lp_scr, acc_rate, energy = torch.empty_like(logp0), torch.empty_like(logp0), torch.empty_like(logp0)
+    is_acc_u = torch.empty(N, dtype=torch.bool, device=dev)
+    is_div = torch.empty(N, dtype=torch.bool, device=dev)
+    dense.finish(stream, metric, k0, k1, off, fold, N, D, eps, eps_pc, thr, q0, logp0, g0, ke0, q1, logp1, g1,
+                 p_half, p_end, scratch[0], lp_scr, scratch[1], acc_rate, is_acc_u, is_div, energy)
+    # nonreversible_slice_sampling (proposal.py:253-256) on dE = H0 - H1 (proposal.py:45-48: NaN -> -inf)
+    dE = (-logp0 + ke0) - energy
+    dE = torch.where(torch.isnan(dE), torch.full_like(dE, float("-inf")), dE)
+    acc = sl.abs().double().log().to(f32) <= dE
+    accf = acc.to(f32)
+    factor = ((-dE).double().exp().to(f32) * accf) + (1.0 - accf)
+    sl_next = sl * factor
+    am = acc[:, None]
+    p1 = -1.0 * p_end  # hmc.flip_momentum once more (ghmc.py:188): accepted -> +p1, rejected -> -p
+    state = GHMCState(torch.where(am, q1, q0), torch.where(am, p1, -1.0 * p), torch.where(acc, logp1, logp0),
+                      torch.where(am, g1, g0), sl_next)
+    info = HMCInfo(p, acc_rate, acc, is_div, energy, IntegratorState(q1, p_end, logp1, g1), 1)
+    return state, info
 
 
 def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
@@ -142,6 +194,11 @@ def build_kernel(noise_fn=None, divergence_threshold: float = 1000):
         a_s, a_pc = _per_chain_or_scalar(alpha, N, dev, "alpha")
         d_s, d_pc = _per_chain_or_scalar(delta, N, dev, "delta")
         stream = _lib.current_stream()
+        if imm_stride < 0:
+            if skip_chains is not None:
+                raise NotImplementedError("ghmc: skip_chains (MEADS) with a dense momentum metric")
+            return _dense_step(k0, k1, fold, int(chain_offset), vg, thr, q0, p_prev, logp0, g0, sl_prev, imm, eps,
+                               eps_pc, a_s, a_pc, d_s, d_pc)
         p = torch.empty_like(q0)
         sl = torch.empty_like(sl_prev)
         ke0 = torch.empty_like(logp0)

@@ -14,8 +14,9 @@ Reference lines followed
 * nonreversible_slice_sampling         blackjax/mcmc/proposal.py:243-264
 * flip_momentum                        blackjax/mcmc/hmc.py:95-112
 
-Only the per-dimension inverse-scale form of ``momentum_inverse_scale`` is restated (what MEADS
-passes); dense / low-rank momentum metrics are outside SURVEY.md section 8.
+The per-dimension inverse-scale form of ``momentum_inverse_scale`` (what MEADS passes) and -- ``metric=`` --
+any Gaussian-Euclidean metric of oracle/hmc.py, e.g. a dense inverse mass matrix (the reference's rich-metric
+branch, ghmc.py:67-86: a 2-d array passes straight to ``default_metric``).  Low-rank metrics are not restated.
 """
 from __future__ import annotations
 
@@ -59,17 +60,18 @@ def _per_chain(x, n):
 
 
 def kernel(rng_key, state: GHMCState, logdensity_fn, step_size, momentum_inverse_scale, alpha, delta,
-           divergence_threshold: float = 1000.0, chain_offset: int = 0, chain_keys_override=None):
+           divergence_threshold: float = 1000.0, chain_offset: int = 0, chain_keys_override=None, metric=None):
     """ghmc.py:116-198.  ``step_size``, ``alpha``, ``delta``: scalars or (N,);
     ``momentum_inverse_scale``: scalar, (D,) or (N, D) inverse scale (squared into the inverse
     mass matrix, ghmc.py:86)."""
     q, p_prev, logp, g, sl = state
     N, D = q.shape
-    scale = np.asarray(momentum_inverse_scale, dtype=f32)
-    imm = (scale * scale).astype(f32)
-    if imm.ndim == 0:
-        imm = np.full(D, imm, f32)
-    metric = ohmc.default_metric(imm, n_chains=N, per_chain_diag=imm.ndim == 2)
+    if metric is None:
+        scale = np.asarray(momentum_inverse_scale, dtype=f32)
+        imm = (scale * scale).astype(f32)
+        if imm.ndim == 0:
+            imm = np.full(D, imm, f32)
+        metric = ohmc.default_metric(imm, n_chains=N, per_chain_diag=imm.ndim == 2)
     keys = _chain_keys(rng_key, N, chain_offset, chain_keys_override)
     kk = prng.split(keys, 2)  # key_momentum, key_noise (noise_fn = 0, ghmc.py:89-91)
     a = _per_chain(alpha, N)[:, None]
