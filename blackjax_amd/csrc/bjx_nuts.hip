@@ -2978,6 +2978,7 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
         if (leaf3 >= 128) {  /* 128 + w: one chain per wave, transition ends deferred into the next launch */ \
           const dim3 g1((unsigned)run->n_rows);                                            \
           if (leaf3 == 128 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 3, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
+          else if (leaf3 == 128 + 6) hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 6, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
           else hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 4, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                  \
           deferred_ends = true;                                                            \
         } else if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
