@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Stage-by-stage timing of the multi-tick NUTS leaf (build-time instrumentation).
-Needs a library built with `make -C blackjax_amd/csrc CXXFLAGS="... -DBJX_TICK_PROBE"` (tools/r3_call18.sh does
+Needs a library built with `make -C blackjax_amd/csrc CXXFLAGS="... -DBJX_TICK_PROBE"` (a tools/gpu_call.sh command does
 that into a scratch copy of the tree); prints the 100-MHz-tick sums of compact row 0's wave per stage."""
 import ctypes
 import json
