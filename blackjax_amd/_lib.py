@@ -190,6 +190,8 @@ class NutsAsync(ctypes.Structure):
         ("target_kind", ctypes.c_int32), ("ticks_per_launch", ctypes.c_int32), ("target_vec", c_void_p),
         ("int_stages", ctypes.c_int32), ("reserved3", ctypes.c_int32),
         ("int_mid_kick", c_float * 6), ("int_mid_drift", c_float * 6),  # BJX_NUTS_MAX_MID
+        ("gemm_pc", c_void_p), ("gemm_vc", c_void_p), ("gemm_z", c_void_p), ("gemm_pm", c_void_p),
+        ("gemm_vm", c_void_p), ("gemm_cap", ctypes.c_int64),
     ]
 
 

@@ -2537,6 +2537,163 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
     ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
   }
 }
+
+// ------------------------------------------------------------------------------------ free-running chains, shared dense metric on the GEMM
+// (round 4)  One dense inverse mass matrix shared by all chains: every product v = M^{-1} p
+// a tick needs is ONE fp32 MFMA GEMM over the compact rows (bjx_dense_apply_imm), exactly the arithmetic the
+// lockstep `step` uses for this metric (nuts.py: dense_gemm; the oracle's "f32chain" mode) -- instead of D^2
+// fp64-accumulated words per chain and product in k_nuts_async_fused<.., true>.  A tick is then a fixed
+// sequence of launches on one stream (bjx_nuts_async_tick, GEMM mode), built from the SAME per-chain device
+// functions as the lockstep kernels (nuts_post_chain / nuts_merge_chain / nuts_init_chain / nuts_open_half with
+// bjx_nuts_t.v_pre), with the lane <-> element mapping each of them has there:
+//   kick(1)   pc[b] = p_end + (dir eps b1) gf[b]            chains with a leaf in flight (phase 1)
+//   GEMM      vc = pc M^{-1}
+//   leaf      closing kick, energy, sampling, U-turn; subtree complete: merge -> next doubling (phase 4)
+//             | transition complete: record, accept; then (also phase 0) z = normal(km) into a slot of the
+//             momentum list (phase 5) -- at most `cap` chains per tick, the others stay in phase 0 and
+//             try again in the next tick (chains are independent: a chain's results do not depend on when
+//             it runs)
+//   GEMM x 2  pm = z L^{-1} ; vm = pm M^{-1}                 (metrics.py:260-270 as bjx_hmc_momentum_dense)
+//   start     p0, v0, K(p0) -> tree init, doubling 0 (phase 4)
+//   kick(4)   pc[b] = p_end + (dir eps b1) g_end             chains that open a leaf
+//   GEMM      vc = pc M^{-1}
+//   pre       q += (dir eps a1) vc[b], p += (dir eps b1) g_end -> qf[b]  (phase 1)
+// Velocity Verlet / one-gradient integrators only (multi-stage integrators use lockstep steps for this metric).
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_gemm_kick(bjx_nuts_t nt, bjx_nuts_async_t ax, const float* __restrict__ gf, int want_phase) {
+  if (want_phase == 1 && blockIdx.x == 0 && threadIdx.x == 0) *ax.end_count = 0;  // this tick's momentum list
+  async_for_each_chain<false>(ax, want_phase, want_phase, [&](int64_t c, int64_t b, int) {
+    const int dir = IS(BJX_NUTS_I_DIR, c);
+    const float h = ((float)dir * chain_eps(nt, c)) * int_kick(nt);
+    const int64_t base = c * nt.D;
+    const float* p = (dir > 0 ? nt.Rp : nt.Lp) + base;
+    const float* g = want_phase == 1 ? gf + b * nt.D : (dir > 0 ? nt.Rg : nt.Lg) + base;
+    float* out = ax.gemm_pc + b * nt.D;
+    BJX_ROW_SWEEP(j0) {
+      const Row<VEC> gg = ldr<VEC>(g + j0);
+      Row<VEC> pp = ldr<VEC>(p + j0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pp.v[e] = fmaf(h, gg.v[e], pp.v[e]);
+      str<VEC>(out + j0, pp);
+    }
+  });
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_FUSED_WAVES)))
+k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
+                 const float* __restrict__ gf, int32_t cap) {
+  async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
+    const int lane = threadIdx.x & 63;
+    int32_t t = ax.t[c];
+    if (phase == 1) {
+      const StepCtx cx = async_ctx(nt, ax, t);
+      const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
+      const int32_t s = IS(BJX_NUTS_I_SUBN, c);
+      const bool last = (s + 1) >= (1 << depth);
+      const bool stop = nuts_post_chain<VEC, true>(nt, cx, c, b, depth, s, qf, logp_f, gf, false);
+      if (!(stop || last)) {  // the subtree keeps integrating: the next leaf opens after this tick's second GEMM
+        if (lane == 0) ax.phase[c] = 4;
+        return;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const bool grow = nuts_merge_chain<1, true>(nt, cx, c, depth);  // <1, true>: the lockstep merge kernel's mapping
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (grow) {
+        nuts_begin_doubling(nt, cx, c, depth + 1);
+        if (lane == 0) ax.phase[c] = 4;
+        return;
+      }
+      // transition t is complete: record it and make the proposal the chain's state (as async_boundary_chain)
+      const int64_t base = c * nt.D;
+      const int64_t row = (int64_t)t * nt.N + c;
+      for (int64_t j = lane; j < nt.D; j += 64) {
+        const float q = nt.Pq[base + j];
+        ax.q[base + j] = q;
+        ax.g[base + j] = nt.Pg[base + j];
+        if (ax.out_position) ax.out_position[row * nt.D + j] = q;
+      }
+      if (lane == 0) {
+        const float lp = FS(BJX_NUTS_F_PLOGP, c);
+        ax.logp[c] = lp;
+        if (ax.out_logdensity) ax.out_logdensity[row] = lp;
+        if (ax.out_acceptance_rate) ax.out_acceptance_rate[row] = FS(BJX_NUTS_F_ACC, c);
+        if (ax.out_energy) ax.out_energy[row] = FS(BJX_NUTS_F_PENERGY, c);
+        if (ax.out_num_integration_steps) ax.out_num_integration_steps[row] = IS(BJX_NUTS_I_NSTATES, c);
+        if (ax.out_num_trajectory_expansions) ax.out_num_trajectory_expansions[row] = IS(BJX_NUTS_I_DEPTH, c);
+        if (ax.out_is_divergent) ax.out_is_divergent[row] = (uint8_t)(IS(BJX_NUTS_I_DIV, c) != 0);
+        if (ax.out_is_turning) ax.out_is_turning[row] = (uint8_t)(IS(BJX_NUTS_I_TURN, c) != 0);
+      }
+      t += 1;
+      if (lane == 0) ax.t[c] = t;
+      if (t >= ax.n_steps) {
+        if (lane == 0) {
+          ax.phase[c] = 2;
+          atomicAdd(ax.n_done, 1);
+        }
+        return;
+      }
+    }
+    // start transition t: a slot of this tick's momentum list, or wait for the next tick
+    int e = 0;
+    if (lane == 0) e = atomicAdd(ax.end_count, 1);
+    e = __builtin_amdgcn_readfirstlane(e);
+    if (e >= cap) {
+      if (lane == 0) ax.phase[c] = 0;
+      return;
+    }
+    const StepCtx cx = async_ctx(nt, ax, t);
+    const Key km = key_child(chain_key(cx.key, (uint64_t)(c + cx.off), cx.fold), 0);  // split(kc, 2)[0]
+    float* z = ax.gemm_z + (int64_t)e * nt.D;
+    for (int64_t j = lane; j < nt.D; j += 64) z[j] = normal_from_bits(key_bits32(km, (uint64_t)j));
+    if (lane == 0) {
+      ax.end_list[e] = (int32_t)c;
+      ax.phase[c] = 5;
+    }
+  });
+}
+
+// momentum list -> tree start: p0 = pm[e], v0 = vm[e], K = v0.p0 / 2 with the accumulation of k_rowdot_half
+__global__ void __launch_bounds__(kBlock)
+k_nuts_gemm_start(bjx_nuts_t nt, bjx_nuts_async_t ax, int32_t cap) {
+  const int lane = threadIdx.x & 63;
+  int64_t n = (int64_t)__builtin_amdgcn_readfirstlane(*ax.end_count);
+  if (n > cap) n = cap;
+  for (int64_t e = wave_row0(); e < n; e += wave_row_stride()) {
+    const int64_t c = (int64_t)__builtin_amdgcn_readfirstlane(ax.end_list[e]);
+    const int64_t base = c * nt.D;
+    const float* pm = ax.gemm_pm + e * nt.D;
+    const float* vm = ax.gemm_vm + e * nt.D;
+    double acc = 0.0;
+    for (int64_t j = lane; j < nt.D; j += 64) {
+      const float p = pm[j], v = vm[j];
+      ax.p[base + j] = p;
+      ax.v0[base + j] = v;
+      acc += (double)v * (double)p;
+    }
+    acc = wave_sum(acc);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // p0 / v0: read back by nuts_init_chain
+    nuts_init_chain<1, true>(nt, c, ax.logp[c], 0.5f * (float)acc);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
+    nuts_begin_doubling(nt, cx, c, 0);
+    if (lane == 0) ax.phase[c] = 4;
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_nuts_gemm_pre(bjx_nuts_t nt, bjx_nuts_async_t ax, float* __restrict__ qf) {
+  async_for_each_chain<false>(ax, 4, 4, [&](int64_t c, int64_t b, int) {
+    const int dir = IS(BJX_NUTS_I_DIR, c);
+    const float deps = (float)dir * chain_eps(nt, c);
+    const float h = deps * int_kick(nt);
+    const float* fg = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
+    nuts_open_half<VEC, true>(nt, c, dir, deps * int_drift(nt), h, fg, qf + b * nt.D, nt.v_pre + b * nt.D);
+    if ((threadIdx.x & 63) == 0) ax.phase[c] = 1;
+  });
+}
 #endif  // !__HIPCC_RTC__
 
 // Compaction of the free-running rows: keep, in order, the rows whose chain is not finished.
@@ -2884,6 +3041,38 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   BJX_CHECK_ARG(run->ticks_per_launch <= 1 || run->target_kind != BJX_TARGET_NONE,
                 "bjx_nuts_async_tick: ticks_per_launch > 1 needs an engine-resident target (target_kind)");
   if (run->n_rows == 0 || run->n_steps == 0) return 0;
+  if (nuts->Mdense && run->gemm_pc) {
+    // ONE shared dense matrix, products on the MFMA GEMM (see "free-running chains, shared dense metric on the GEMM")
+    BJX_CHECK_ARG(nuts->Mdense_stride == 0 && nuts->v_pre && nuts->v_pre == run->gemm_vc && run->gemm_z &&
+                      run->gemm_pm && run->gemm_vm && run->gemm_cap >= 1 && run->end_list && run->end_count &&
+                      run->int_stages <= 1 && run->target_kind == BJX_TARGET_NONE,
+                  "bjx_nuts_async_tick: GEMM mode needs one shared dense matrix (Mdense_stride == 0), nuts->v_pre == "
+                  "run->gemm_vc, gemm_z / gemm_pm / gemm_vm with gemm_cap >= 1, end_list / end_count, a one-gradient "
+                  "integrator and no engine-resident target");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = run->n_rows, D = nuts->D;
+    const int32_t cap = (int32_t)(run->gemm_cap < n ? run->gemm_cap : n);
+    const dim3 rgrid(bjx_row_grid(n, kWavesPerBlock)), cgrid(bjx_row_grid(cap, kWavesPerBlock)), blk(kBlock);
+    const bool v4 = nuts_vec4_dense(nuts, qf, gf, run->gemm_pc);
+#define BJX_GEMM_K(KERNEL, ...)                                                          \
+  do {                                                                                   \
+    if (v4) hipLaunchKernelGGL(KERNEL<4>, rgrid, blk, 0, st, *nuts, *run, __VA_ARGS__);  \
+    else hipLaunchKernelGGL(KERNEL<1>, rgrid, blk, 0, st, *nuts, *run, __VA_ARGS__);     \
+    if (int rc = bjx_check_launch("bjx_nuts_async_tick(gemm)")) return rc;               \
+  } while (0)
+    BJX_GEMM_K(k_nuts_gemm_kick, gf, 1);
+    if (int rc = bjx_dense_apply_imm(stream, n, D, run->gemm_pc, nuts->Mdense, run->gemm_vc)) return rc;
+    BJX_GEMM_K(k_nuts_gemm_leaf, qf, logp_f, gf, cap);
+    if (int rc = bjx_dense_matmul(stream, cap, D, run->gemm_z, run->mass_sqrt_t, run->gemm_pm)) return rc;
+    if (int rc = bjx_dense_apply_imm(stream, cap, D, run->gemm_pm, nuts->Mdense, run->gemm_vm)) return rc;
+    hipLaunchKernelGGL(k_nuts_gemm_start, cgrid, blk, 0, st, *nuts, *run, cap);
+    if (int rc = bjx_check_launch("bjx_nuts_async_tick(gemm start)")) return rc;
+    BJX_GEMM_K(k_nuts_gemm_kick, gf, 4);
+    if (int rc = bjx_dense_apply_imm(stream, n, D, run->gemm_pc, nuts->Mdense, run->gemm_vc)) return rc;
+    BJX_GEMM_K(k_nuts_gemm_pre, qf);
+#undef BJX_GEMM_K
+    return 0;
+  }
   if (nuts->Mdense) {
     // dense metric: every leaf is a D x D matrix-vector product per chain (fp64 accumulated, the
     // arithmetic of the lockstep kernels), so one launch per tick whatever the row count

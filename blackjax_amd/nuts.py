@@ -471,7 +471,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
              sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
-             row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet):
+             row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet,
+             dense_gemm: bool = False, dense_gemm_cap=None):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -517,8 +518,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     closes the leaf and does its bookkeeping (``bjx_nuts_async_t.int_stages``) -- on the low-traffic tick
     kernels (``free_running_supports``); results equal ``num_steps`` lockstep steps with the same integrator.
 
+    ``dense_gemm=True`` (ONE shared dense inverse mass matrix, velocity Verlet): every product ``M^-1 p`` of a
+    tick is one fp32 MFMA GEMM over the live rows -- the arithmetic of the lockstep ``step`` for this metric, so
+    ``run(T)`` equals ``T`` steps bit for bit -- instead of one fp64 matrix-vector product per chain
+    (``bjx_nuts_async_t.gemm_*``); at most ``dense_gemm_cap`` chains (default: a quarter of the ensemble) start a
+    transition per tick, the others wait one tick.
+
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
-    ``store_positions=False``), ``info`` a ``NUTSRunInfo``.  Diagonal metric only."""
+    ``store_positions=False``), ``info`` a ``NUTSRunInfo``."""
     import numpy as np
 
     from . import random as bjx_random
@@ -573,6 +580,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             "lockstep steps for other shapes)")
     if metric.kind != "diag" and adaptation is not None:
         raise NotImplementedError("free-running per-chain adaptation is implemented for the diagonal metric")
+    gemm = bool(dense_gemm)
+    if gemm and (metric.kind != "dense" or general or fuse_target):
+        raise NotImplementedError("dense_gemm=True: one shared dense inverse mass matrix, velocity Verlet, no fuse_target")
     eps, eps_pc = step_size_args(step_size, N, dev)
     if adaptation is not None and (eps_pc is None or eps_pc.data_ptr() != adaptation["step_size"].data_ptr()
                                    or metric.imm.data_ptr() != adaptation["imm"].data_ptr()
@@ -617,6 +627,15 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if metric.kind != "diag":  # the tick kernel draws p = L^{-T} z and v0 = M^{-1} p per chain
         v0 = torch.empty_like(q)
         dense_f["fields"]["v0"] = v0.data_ptr()
+    gemm_bufs = None
+    if gemm:
+        # compact kicked momenta / their velocities (one GEMM per product), and the momentum list of a tick
+        cap = dense_gemm_cap if dense_gemm_cap is not None else int(_os_environ().get("BJX_NUTS_GEMM_CAP", "0"))
+        cap = int(cap) if cap and int(cap) > 0 else max(128, -(-N // 4))
+        cap = min(N, -(-cap // 128) * 128)
+        gemm_bufs = (torch.zeros_like(q), torch.zeros_like(q), torch.zeros((cap, D), **f32),
+                     torch.zeros((cap, D), **f32), torch.zeros((cap, D), **f32), cap)
+        dense_f["fields"]["v_pre"] = gemm_bufs[1].data_ptr()
     rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32) if v0 is None else None
     front_p = torch.empty_like(q) if v0 is None else None
     end_list = torch.empty((2, N), **i32)
@@ -642,6 +661,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         rec=_lib.ptr(rec), front_p=_lib.ptr(front_p), end_list=end_list.data_ptr(),
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
+    if gemm_bufs is not None:
+        (run.gemm_pc, run.gemm_vc, run.gemm_z, run.gemm_pm, run.gemm_vm) = (b.data_ptr() for b in gemm_bufs[:5])
+        run.gemm_cap = gemm_bufs[5]
     if general and len(drift_c) > 1:  # middle stages (b_2, a_2), ..., (b_K, a_K); the closing kick b_1 is int_kick
         run.int_stages = len(drift_c)
         for i in range(1, len(drift_c)):
@@ -677,6 +699,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # K ticks per leaf; + one tick per transition: the busy-phase leaf kernel finishes a transition in the
     # tick AFTER the one that completed its tree (deferred transition ends, k_nuts_async_tick3<.., DEFER>)
     max_ticks = T * (((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 1) + 4
+    if gemm_bufs is not None:  # a chain may wait for a slot of the momentum list: at most ceil(N / cap) - 1 ticks per start
+        max_ticks += T * (-(-N // gemm_bufs[5]))
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
@@ -1060,7 +1084,14 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             # ONE shared dense matrix on the GEMM path (the arithmetic `step` uses for this metric: every
             # product v = M^-1 p is an fp32 MFMA GEMM over the live rows): the free-running tick kernels apply
             # a dense metric per chain in fp64 -- other roundings, and 20 x slower at 16 384 x 512 -- so the
-            # run is made of lockstep steps: same keys, run(T) == T x step bit for bit
+            # run is made of lockstep steps: same keys, run(T) == T x step bit for bit.  BJX_NUTS_FREE_GEMM=1
+            # (velocity Verlet): free-running ticks with every product on the GEMM instead (bjx_nuts_async_t.gemm_*:
+            # the same arithmetic, so the same results)
+            if not general and _os_environ().get("BJX_NUTS_FREE_GEMM", "0") != "0":
+                return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
+                                max_num_doublings, divergence_threshold=divergence_threshold,
+                                chain_offset=chain_offset, key_layout=key_layout, store_positions=store_positions,
+                                use_graph=True if use_graph is True else run_use_graph, dense_gemm=True)
             return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
         if general:
             # multi-stage integrators run free on the low-traffic tick kernels (diagonal metric, D % 4 == 0,

@@ -37,8 +37,9 @@
 extern "C" {
 #endif
 
-#define BJX_ABI_VERSION 3 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
-                             int_mid_kick / int_mid_drift, bjx_rng_key_probe added (round 4) */
+#define BJX_ABI_VERSION 4 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
+                             int_mid_kick / int_mid_drift, bjx_rng_key_probe added (round 4); 4: bjx_nuts_async_t gained
+                             gemm_pc .. gemm_cap (round 4) */
 
 const char* bjx_last_error(void);
 int bjx_abi_version(void);

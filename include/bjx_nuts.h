@@ -301,6 +301,23 @@ typedef struct {
   int32_t reserved3;
   float int_mid_kick[BJX_NUTS_MAX_MID];
   float int_mid_drift[BJX_NUTS_MAX_MID];
+  /* ONE shared dense inverse mass matrix on the MFMA GEMM (round 4; nuts->Mdense with Mdense_stride == 0,
+   * velocity Verlet / one-gradient integrators, no per-chain adaptation, no engine-resident target): gemm_pc != NULL
+   * makes every product v = M^{-1} p of a tick one GEMM over the compact rows (bjx_dense_apply_imm) -- the arithmetic
+   * of the lockstep step for this metric (bjx_nuts_dense_kick -> bjx_dense_apply_imm -> kernels reading
+   * nuts->v_pre; blackjax/mcmc/metrics.py:263-304 with util.py:58-61) -- instead of one fp64-accumulated
+   * matrix-vector product per chain.  A tick is then a fixed sequence of launches on `stream` (kick, GEMM, leaf,
+   * two GEMMs for the momenta of the chains that start a transition, tree start, kick, GEMM, opening half).
+   * gemm_pc, gemm_vc: (n_rows capacity, D) kicked momenta of the compact rows and their velocities; gemm_vc must
+   * be nuts->v_pre.  gemm_z, gemm_pm, gemm_vm: (gemm_cap, D) normal draws, momenta p = L^{-T} z and velocities of
+   * the chains that start a transition in this tick: at most gemm_cap per tick, the others wait a tick (which
+   * changes no result: chains are independent).  Needs end_list (>= gemm_cap entries) and end_count (int32[1]). */
+  float* gemm_pc;
+  float* gemm_vc;
+  float* gemm_z;
+  float* gemm_pm;
+  float* gemm_vm;
+  int64_t gemm_cap;
 } bjx_nuts_async_t;
 
 enum {

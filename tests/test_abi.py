@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
     assert lib.bjx_pool_workspace_bytes(0, 8) == 0
     assert lib.bjx_pool_workspace_bytes(65536, 1024) == 512 * 4 * 1024 * 8  # 512 slabs x K=4 x D doubles
-    assert lib.bjx_abi_version() == 3  # 3: bjx_nuts_async_t gained int_stages / int_mid_* (round 4)
+    assert lib.bjx_abi_version() == 4  # 4: bjx_nuts_async_t gained gemm_pc .. gemm_cap (round 4)
 
 
 def test_error_reporting_without_gpu():
@@ -90,7 +90,7 @@ def test_nuts_descriptor_and_slots_match_header():
     max_mid = int(re.search(r"#define BJX_NUTS_MAX_MID (\d+)", text_nc).group(1))
     assert max_mid == _lib.NUTS_MAX_MID == len(_lib.NutsAsync().int_mid_kick) == len(_lib.NutsAsync().int_mid_drift)
     assert ctypes.sizeof(_lib.NutsAsync) == (8 + 4 * 2 + 8 * 7 + 8 * 2 + 8 * 8 + 8 + 4 * 2 + 8 * 9 + 8 * 4 + 4 * 2 + 8
-                                             + 8 * 2 + 4 * 2 + 8 + 4 * 2 + 4 * 2 * max_mid)
+                                             + 8 * 2 + 4 * 2 + 8 + 4 * 2 + 4 * 2 * max_mid + 8 * 6)
     for name, i in _lib.NUTS_AT.items():
         assert enums["BJX_NUTS_AT_" + name] == i
     assert enums["BJX_NUTS_ADAPT_COLS"] == _lib.NUTS_ADAPT_COLS
