@@ -61,6 +61,8 @@ SIGNATURES = {
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_dense_matmul": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
     "bjx_dense_apply_imm": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p],
+    "bjx_dense_matmul_bt": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p],
+    "bjx_dense_apply_imm_t": [c_void_p, c_int64, c_int64, _f32p, _f32p, _f32p, _f32p],
     "bjx_hmc_momentum_dense": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64,
                                _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "bjx_leapfrog_dense": [c_void_p, c_int64, c_int64, c_int, c_float, _f32p, _f32p, _f32p, _f32p,
@@ -191,7 +193,8 @@ class NutsAsync(ctypes.Structure):
         ("int_stages", ctypes.c_int32), ("reserved3", ctypes.c_int32),
         ("int_mid_kick", c_float * 6), ("int_mid_drift", c_float * 6),  # BJX_NUTS_MAX_MID
         ("gemm_pc", c_void_p), ("gemm_vc", c_void_p), ("gemm_z", c_void_p), ("gemm_pm", c_void_p),
-        ("gemm_vm", c_void_p), ("gemm_cap", ctypes.c_int64),
+        ("gemm_vm", c_void_p), ("gemm_cap", ctypes.c_int64), ("gemm_mass_sqrt", c_void_p),
+        ("gemm_imm_t", c_void_p),
     ]
 
 

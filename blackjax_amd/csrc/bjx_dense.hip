@@ -933,6 +933,93 @@ k_welford_final_dense(int64_t total, int64_t D, float nm1, float beta_data, floa
   }
 }
 
+// Skinny product for FEW rows (the deep doublings of a NUTS transition, the tail of a free-running run):
+// C[r][i] = the fp32 fma chain over k of A[r][k] * Bkn[k][i] in the k order of the MFMA kernels (tiles of
+// 16, inside a tile k = u, 8 + u for u = 0 .. 7 -- oracle/fp.py::mfma_k_order), starting from +0: bit for
+// bit the MFMA kernels' result.  Those kernels walk K in dependent LDS-staged steps of one workgroup per
+// 128 x 128 tile -- 18-28 us however few rows there are; here a wave owns 64 columns x kSkinnyRows rows, reads
+// the matrix rows coalesced (Bkn[k][i .. i + 63]) with the next tile's 16 rows in flight while it works on
+// the current one, and the A values as wave-uniform (scalar) loads: 7 / 11 / 21 us at D = 128 / 256 / 512 for up to
+// ~1 000 rows against 11 / 19 / 34 us.  (A variant with both operands staged through LDS, all loads of a 256-wide K
+// chunk in flight at once, measured the same within 1 us -- the chain of D dependent fmas and the launch are what is
+// left -- and was not kept.)
+constexpr int kSkinnyRows = 4;
+__global__ void __launch_bounds__(256)
+k_dense_skinny(int64_t M, int64_t D, const float* __restrict__ A, const float* __restrict__ Bkn, float* __restrict__ C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t r0 = ((int64_t)blockIdx.y * 4 + wave) * kSkinnyRows;
+  if (r0 >= M) return;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ic = i < D ? i : D - 1;  // out-of-range lanes compute column D - 1 again and store nothing
+  const float* a[kSkinnyRows];
+#pragma unroll
+  for (int r = 0; r < kSkinnyRows; ++r) a[r] = A + (r0 + r < M ? r0 + r : M - 1) * D;
+  float acc[kSkinnyRows];
+#pragma unroll
+  for (int r = 0; r < kSkinnyRows; ++r) acc[r] = 0.0f;
+  const int64_t n_full = D / 16;
+  float b[16], bn[16];
+  if (n_full > 0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) b[u] = Bkn[(int64_t)u * D + ic];
+  }
+  for (int64_t t = 0; t < n_full; ++t) {
+    const int64_t k0 = t * 16;
+    if (t + 1 < n_full) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) bn[u] = Bkn[(k0 + 16 + u) * D + ic];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int r = 0; r < kSkinnyRows; ++r) {
+        acc[r] = fmaf(a[r][k0 + u], b[u], acc[r]);
+        acc[r] = fmaf(a[r][k0 + 8 + u], b[8 + u], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) b[u] = bn[u];
+  }
+  const int64_t k0 = n_full * 16;  // the zero-padded last tile: indices >= D are dropped (fma(0, b, acc) == acc)
+  if (k0 < D) {
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t k = k0 + 8 * h + u;
+        if (k < D) {
+          const float bk = Bkn[k * D + ic];
+#pragma unroll
+          for (int r = 0; r < kSkinnyRows; ++r) acc[r] = fmaf(a[r][k], bk, acc[r]);
+        }
+      }
+    }
+  }
+  if (i < D) {
+#pragma unroll
+    for (int r = 0; r < kSkinnyRows; ++r)
+      if (r0 + r < M) C[(r0 + r) * D + i] = acc[r];
+  }
+}
+
+// rows x D up to which the skinny kernel is used (BJX_DENSE_SKINNY_MAX; 0 = never)
+static int64_t skinny_max() {
+  static const int64_t v = [] {
+    const char* e = getenv("BJX_DENSE_SKINNY_MAX");
+    // measured on MI355X (tools/bench_skinny.py, profiles/r04/dense_skinny.json): the crossover with the MFMA kernels
+    // sits at 4 096 / 2 048 / 1 024 / 512 rows for D = 128 / 256 / 512 / 1 024
+    return e ? atoll(e) : (int64_t)1 << 19;
+  }();
+  return v;
+}
+static bool use_skinny(int64_t M, int64_t D) { return M * D <= skinny_max(); }
+
+int launch_skinny(hipStream_t s, int64_t M, int64_t D, const float* A, const float* Bkn, float* C) {
+  const dim3 grid((unsigned)((D + 63) / 64), (unsigned)((M + 4 * kSkinnyRows - 1) / (4 * kSkinnyRows)));
+  hipLaunchKernelGGL(k_dense_skinny, grid, dim3(256), 0, s, M, D, A, Bkn, C);
+  return bjx_check_launch("bjx_dense skinny");
+}
+
 int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
   const dim3 grid(bjx_row_grid(pa.N, kWavesPerBlock)), block(kBlock);
   const size_t lds = (size_t)kWavesPerBlock * pa.D * sizeof(float);
@@ -1012,12 +1099,38 @@ int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const f
   return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
 }
 
+int bjx_dense_matmul_bt(void* stream, int64_t N, int64_t D, const float* A, const float* B, const float* Bt,
+                        float* C) {
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(N >= 0 && D > 0 && A && B && Bt && C, "bjx_dense_matmul_bt: bad arguments");
+  if (use_skinny(N, D)) return launch_skinny((hipStream_t)stream, N, D, A, B, C);
+  GemmArgs ga{N, D, A, nullptr, 0, 0.0f, nullptr, nullptr, B, C, nullptr, nullptr};
+  // the kernel that reads its matrix as stored (rows of Bt = columns of B) exists for whole, 16-byte aligned tiles
+  if ((N % BM == 0) && (D % BN == 0) && bjx_vec4_ok(D, A, Bt, C)) {
+    ga.B = Bt;
+    ga.b_symmetric = true;
+  }
+  return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
+}
+
 int bjx_dense_apply_imm(void* stream, int64_t N, int64_t D, const float* P, const float* imm, float* V) {
   if (N == 0) return 0;
   BJX_CHECK_ARG(N >= 0 && D > 0 && P && imm && V, "bjx_dense_apply_imm: bad arguments");
   GemmArgs ga{N, D, P, nullptr, 0, 0.0f, nullptr, nullptr, imm, V, nullptr, nullptr};
   ga.b_symmetric = true;  // B is an inverse mass matrix: the TN kernel reads it as stored
   return launch_gemm((hipStream_t)stream, EPI_STORE, ga);
+}
+
+int bjx_dense_apply_imm_t(void* stream, int64_t N, int64_t D, const float* P, const float* imm, const float* imm_t,
+                          float* V) {
+  if (N == 0) return 0;
+  BJX_CHECK_ARG(N >= 0 && D > 0 && P && imm && imm_t && V, "bjx_dense_apply_imm_t: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (use_skinny(N, D)) return launch_skinny(s, N, D, P, imm_t, V);
+  GemmArgs ga{N, D, P, nullptr, 0, 0.0f, nullptr, nullptr, imm, V, nullptr, nullptr};
+  if ((N % BM == 0) && (D % BN == 0) && bjx_vec4_ok(D, P, imm, V)) ga.b_symmetric = true;  // reads imm as stored
+  else ga.B = imm_t;  // the general kernel walks B[k][n]: the transposed copy is what "as stored" means there
+  return launch_gemm(s, EPI_STORE, ga);
 }
 
 int bjx_hmc_momentum_dense(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

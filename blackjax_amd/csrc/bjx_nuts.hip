@@ -2548,14 +2548,14 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
 // bjx_nuts_t.v_pre), with the lane <-> element mapping each of them has there:
 //   kick(1)   pc[b] = p_end + (dir eps b1) gf[b]            chains with a leaf in flight (phase 1)
 //   GEMM      vc = pc M^{-1}
-//   leaf      closing kick, energy, sampling, U-turn; subtree complete: merge -> next doubling (phase 4)
+//   leaf      closing kick, energy, sampling, U-turn (-> phase 4); subtree complete: merge -> next doubling (phase 4)
 //             | transition complete: record, accept; then (also phase 0) z = normal(km) into a slot of the
 //             momentum list (phase 5) -- at most `cap` chains per tick, the others stay in phase 0 and
 //             try again in the next tick (chains are independent: a chain's results do not depend on when
 //             it runs)
 //   GEMM x 2  pm = z L^{-1} ; vm = pm M^{-1}                 (metrics.py:260-270 as bjx_hmc_momentum_dense)
 //   start     p0, v0, K(p0) -> tree init, doubling 0 (phase 4)
-//   kick(4)   pc[b] = p_end + (dir eps b1) g_end             chains that open a leaf
+//             (leaf and start also write pc[b] = p_end + (dir eps b1) g_end for the chains that open a leaf)
 //   GEMM      vc = pc M^{-1}
 //   pre       q += (dir eps a1) vc[b], p += (dir eps b1) g_end -> qf[b]  (phase 1)
 // Velocity Verlet / one-gradient integrators only (multi-stage integrators use lockstep steps for this metric).
@@ -2580,8 +2580,23 @@ k_nuts_gemm_kick(bjx_nuts_t nt, bjx_nuts_async_t ax, const float* __restrict__ g
   });
 }
 
+// pc[b] = p_end + (dir eps b1) g_end for a chain that opens a leaf on its end `dir` (the expression of k_nuts_gemm_kick)
 template <int VEC>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_FUSED_WAVES)))
+__device__ __forceinline__ void gemm_open_kick(const bjx_nuts_t& nt, int64_t c, int dir, float* __restrict__ out) {
+  const float h = ((float)dir * chain_eps(nt, c)) * int_kick(nt);
+  const float* p = (dir > 0 ? nt.Rp : nt.Lp) + c * nt.D;
+  const float* g = (dir > 0 ? nt.Rg : nt.Lg) + c * nt.D;
+  BJX_ROW_SWEEP(j0) {
+    const Row<VEC> gg = ldr<VEC>(g + j0);
+    Row<VEC> pp = ldr<VEC>(p + j0);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) pp.v[e] = fmaf(h, gg.v[e], pp.v[e]);
+    str<VEC>(out + j0, pp);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))  // 124 VGPRs
 k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                  const float* __restrict__ gf, int32_t cap) {
   async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
@@ -2594,6 +2609,7 @@ k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __r
       const bool last = (s + 1) >= (1 << depth);
       const bool stop = nuts_post_chain<VEC, true>(nt, cx, c, b, depth, s, qf, logp_f, gf, false);
       if (!(stop || last)) {  // the subtree keeps integrating: the next leaf opens after this tick's second GEMM
+        gemm_open_kick<VEC>(nt, c, IS(BJX_NUTS_I_DIR, c), ax.gemm_pc + b * nt.D);  // rows this wave's lanes just wrote
         if (lane == 0) ax.phase[c] = 4;
         return;
       }
@@ -2601,7 +2617,8 @@ k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __r
       const bool grow = nuts_merge_chain<1, true>(nt, cx, c, depth);  // <1, true>: the lockstep merge kernel's mapping
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (grow) {
-        nuts_begin_doubling(nt, cx, c, depth + 1);
+        const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
+        gemm_open_kick<VEC>(nt, c, dir, ax.gemm_pc + b * nt.D);
         if (lane == 0) ax.phase[c] = 4;
         return;
       }
@@ -2649,6 +2666,7 @@ k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __r
     for (int64_t j = lane; j < nt.D; j += 64) z[j] = normal_from_bits(key_bits32(km, (uint64_t)j));
     if (lane == 0) {
       ax.end_list[e] = (int32_t)c;
+      ax.end_list[nt.N + e] = (int32_t)b;  // its compact row: k_nuts_gemm_start writes the opening kick there
       ax.phase[c] = 5;
     }
   });
@@ -2677,7 +2695,9 @@ k_nuts_gemm_start(bjx_nuts_t nt, bjx_nuts_async_t ax, int32_t cap) {
     nuts_init_chain<1, true>(nt, c, ax.logp[c], 0.5f * (float)acc);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
-    nuts_begin_doubling(nt, cx, c, 0);
+    const int dir = nuts_begin_doubling(nt, cx, c, 0);
+    const int64_t b = (int64_t)__builtin_amdgcn_readfirstlane(ax.end_list[nt.N + e]);
+    gemm_open_kick<1>(nt, c, dir, ax.gemm_pc + b * nt.D);  // rows nuts_init_chain<1> just wrote, same lanes
     if (lane == 0) ax.phase[c] = 4;
   }
 }
@@ -3060,15 +3080,22 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
     else hipLaunchKernelGGL(KERNEL<1>, rgrid, blk, 0, st, *nuts, *run, __VA_ARGS__);     \
     if (int rc = bjx_check_launch("bjx_nuts_async_tick(gemm)")) return rc;               \
   } while (0)
+    auto apply_imm = [&](int64_t rows, const float* p_in, float* v_out) {
+      return run->gemm_imm_t ? bjx_dense_apply_imm_t(stream, rows, D, p_in, nuts->Mdense, run->gemm_imm_t, v_out)
+                             : bjx_dense_apply_imm(stream, rows, D, p_in, nuts->Mdense, v_out);
+    };
     BJX_GEMM_K(k_nuts_gemm_kick, gf, 1);
-    if (int rc = bjx_dense_apply_imm(stream, n, D, run->gemm_pc, nuts->Mdense, run->gemm_vc)) return rc;
+    if (int rc = apply_imm(n, run->gemm_pc, run->gemm_vc)) return rc;
     BJX_GEMM_K(k_nuts_gemm_leaf, qf, logp_f, gf, cap);
-    if (int rc = bjx_dense_matmul(stream, cap, D, run->gemm_z, run->mass_sqrt_t, run->gemm_pm)) return rc;
-    if (int rc = bjx_dense_apply_imm(stream, cap, D, run->gemm_pm, nuts->Mdense, run->gemm_vm)) return rc;
+    if (run->gemm_mass_sqrt) {  // p = L^{-T} z with the matrix read as stored where that kernel applies (faster)
+      if (int rc = bjx_dense_matmul_bt(stream, cap, D, run->gemm_z, run->mass_sqrt_t, run->gemm_mass_sqrt, run->gemm_pm))
+        return rc;
+    } else if (int rc = bjx_dense_matmul(stream, cap, D, run->gemm_z, run->mass_sqrt_t, run->gemm_pm)) return rc;
+    if (int rc = apply_imm(cap, run->gemm_pm, run->gemm_vm)) return rc;
     hipLaunchKernelGGL(k_nuts_gemm_start, cgrid, blk, 0, st, *nuts, *run, cap);
     if (int rc = bjx_check_launch("bjx_nuts_async_tick(gemm start)")) return rc;
-    BJX_GEMM_K(k_nuts_gemm_kick, gf, 4);
-    if (int rc = bjx_dense_apply_imm(stream, n, D, run->gemm_pc, nuts->Mdense, run->gemm_vc)) return rc;
+    // (the opening kicks pc[b] = p_end + (dir eps b1) g_end were written by the leaf / start kernels)
+    if (int rc = apply_imm(n, run->gemm_pc, run->gemm_vc)) return rc;
     BJX_GEMM_K(k_nuts_gemm_pre, qf);
 #undef BJX_GEMM_K
     return 0;

@@ -16,6 +16,7 @@ class Metric(NamedTuple):
     imm: torch.Tensor  # (D,), (N, D) [diag]  or (D, D) [dense]
     imm_stride: int  # diag: 0 shared, D per chain
     mass_sqrt_t: Optional[torch.Tensor]  # dense: (L^{-T})^T = L^{-1}, row-major (D, D)
+    imm_t: Optional[torch.Tensor] = None  # shared dense: the transpose of imm, row-major (bjx_dense_apply_imm_t)
 
 
 _DENSE_CACHE: dict = {}
@@ -105,7 +106,8 @@ def _dense_metric(imm: torch.Tensor) -> Metric:
         eye = eye.expand(imm.shape).contiguous()
     Linv = torch.linalg.solve_triangular(L, eye, upper=False)  # L^{-1} = (L^{-T})^T
     # "dense": one matrix shared by all chains (MFMA GEMMs); "dense_pc": one matrix per chain
-    m = Metric("dense" if imm.ndim == 2 else "dense_pc", imm, 0, Linv.float().contiguous())
+    m = Metric("dense" if imm.ndim == 2 else "dense_pc", imm, 0, Linv.float().contiguous(),
+               imm.t().contiguous() if imm.ndim == 2 else None)
     if len(_DENSE_CACHE) > 8:
         _DENSE_CACHE.clear()
     _DENSE_CACHE[key] = m

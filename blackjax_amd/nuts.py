@@ -111,6 +111,7 @@ class _GraphWorkspace:
         self.dense = _dense_fields("dense" if self.gemm else kind, self.imm, N, D, max_depth, device)
         if self.gemm:
             self.pc, self.vc = torch.empty((N, D), **f32), torch.empty((N, D), **f32)
+            self.imm_t = torch.ones(imm_shape, **f32)  # static copy of the transposed matrix (bjx_dense_apply_imm_t)
             self.dense["fields"]["v_pre"] = self.vc.data_ptr()
         self.desc = _lib.NutsDesc(
             N=N, D=D, max_depth=max_depth, reserved=0, imm=self.imm.data_ptr(),
@@ -140,8 +141,8 @@ class _GraphWorkspace:
             the chunk's row capacity"""
             _lib.call("bjx_nuts_dense_kick", stream, dref, 0, s_off, n_cap, idx_p, ctl_p, _lib.ptr(gf_t), kick,
                       self.pc.data_ptr())
-            _lib.call("bjx_dense_apply_imm", stream, n_cap, self.D, self.pc.data_ptr(), self.imm.data_ptr(),
-                      self.vc.data_ptr())
+            _lib.call("bjx_dense_apply_imm_t", stream, n_cap, self.D, self.pc.data_ptr(), self.imm.data_ptr(),
+                      self.imm_t.data_ptr(), self.vc.data_ptr())
 
         if self.gemm:
             velocities(0, None, self.kick_c[0])
@@ -311,8 +312,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
                     """GEMM mode: vc[b] = M^{-1} (p_end + (dir eps kick) g) for the live rows"""
                     _lib.call("bjx_nuts_dense_kick", stream, dref, depth, s, n_step, _lib.ptr(idx_step), None,
                               _lib.ptr(gf_t), kick, pc.data_ptr())
-                    _lib.call("bjx_dense_apply_imm", stream, n_step, D, pc.data_ptr(), metric.imm.data_ptr(),
-                              vc.data_ptr())
+                    _lib.call("bjx_dense_apply_imm_t", stream, n_step, D, pc.data_ptr(), metric.imm.data_ptr(),
+                              metric.imm_t.data_ptr(), vc.data_ptr())
 
                 if need_pre:
                     if gemm:
@@ -355,6 +356,8 @@ def build_kernel(integrator=integrators.velocity_verlet, divergence_threshold: i
         else:
             ws.eps.copy_(eps_pc)
         ws.imm.copy_(metric.imm)
+        if ws.gemm:
+            ws.imm_t.copy_(metric.imm_t)
         d = ws.desc
         d.key0, d.key1, d.chain_offset, d.step_fold = k0, k1, off, fold
         d.q0, d.g0, d.p0 = q0.data_ptr(), g0.data_ptr(), p0.data_ptr()
@@ -634,7 +637,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         cap = int(cap) if cap and int(cap) > 0 else max(128, -(-N // 4))
         cap = min(N, -(-cap // 128) * 128)
         gemm_bufs = (torch.zeros_like(q), torch.zeros_like(q), torch.zeros((cap, D), **f32),
-                     torch.zeros((cap, D), **f32), torch.zeros((cap, D), **f32), cap)
+                     torch.zeros((cap, D), **f32), torch.zeros((cap, D), **f32), cap,
+                     metric.mass_sqrt_t.t().contiguous())  # L^{-T} row-major: read as stored by the TN GEMM kernel
         dense_f["fields"]["v_pre"] = gemm_bufs[1].data_ptr()
     rec = torch.zeros((N, _lib.NUTS_REC_WORDS), **i32) if v0 is None else None
     front_p = torch.empty_like(q) if v0 is None else None
@@ -664,6 +668,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if gemm_bufs is not None:
         (run.gemm_pc, run.gemm_vc, run.gemm_z, run.gemm_pm, run.gemm_vm) = (b.data_ptr() for b in gemm_bufs[:5])
         run.gemm_cap = gemm_bufs[5]
+        if _os_environ().get("BJX_NUTS_GEMM_TN", "1") != "0":
+            run.gemm_mass_sqrt = gemm_bufs[6].data_ptr()
+            run.gemm_imm_t = metric.imm_t.data_ptr()
     if general and len(drift_c) > 1:  # middle stages (b_2, a_2), ..., (b_K, a_K); the closing kick b_1 is int_kick
         run.int_stages = len(drift_c)
         for i in range(1, len(drift_c)):

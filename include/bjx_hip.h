@@ -231,6 +231,23 @@ int bjx_mhmc_finish_masked(void* stream, int64_t N, int64_t D, const int32_t* n_
  * C = A @ B with A (N, D), B (D, D): the building block, exported for parity tests. */
 int bjx_dense_matmul(void* stream, int64_t N, int64_t D, const float* A, const float* B, float* C);
 
+/* V = P imm^T -- v_r = imm p_r for every row, the matrix read AS STORED (v[i] = sum_k imm[i][k] p[k],
+ * blackjax/mcmc/metrics.py:263-304 `linear_map`) -- given imm AND its transpose imm_t (both (D, D) row-major).
+ * bjx_dense_apply_imm with three differences: few rows (N D <= BJX_DENSE_SKINNY_MAX, default 2^19) run on a
+ * latency-oriented kernel (a few microseconds instead of 18-28), ragged shapes use imm_t on the general kernel --
+ * so a matrix that is symmetric only up to rounding (a Welford covariance) gives the same product at every batch
+ * size -- and whole aligned tiles run on the kernel bjx_dense_apply_imm uses.  One ascending-k fp32 fma chain per
+ * output element in the k order of the MFMA kernels everywhere: identical results.  (round 4) */
+int bjx_dense_apply_imm_t(void* stream, int64_t N, int64_t D, const float* P, const float* imm, const float* imm_t,
+                          float* V);
+
+/* C = A B like bjx_dense_matmul, given B AND its transpose Bt (both (D, D) row-major): whole 128-row / 128-column
+ * tiles of 16-byte aligned buffers run on the kernel that reads its matrix as stored (the one bjx_dense_apply_imm uses
+ * for a symmetric matrix, faster), few rows (N D <= BJX_DENSE_SKINNY_MAX) on the latency-oriented kernel of
+ * bjx_dense_apply_imm_t, anything else on bjx_dense_matmul's kernel.  Same ascending-k fp32 fma chain per
+ * output element either way: identical results.  (round 4) */
+int bjx_dense_matmul_bt(void* stream, int64_t N, int64_t D, const float* A, const float* B, const float* Bt, float* C);
+
 /* V = P @ imm^T for N rows: v_i = imm p_i (linear_map(inverse_mass_matrix, p), util.py:58-61;
  * metrics.py:263-304) on the fp32 MFMA GEMM, imm read as the reference stores it (row n = output n).
  * Complete 128 x 128 tiles take the k-contiguous "TN" kernel.  Used by dense-metric NUTS, where the

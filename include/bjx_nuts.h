@@ -311,13 +311,20 @@ typedef struct {
    * gemm_pc, gemm_vc: (n_rows capacity, D) kicked momenta of the compact rows and their velocities; gemm_vc must
    * be nuts->v_pre.  gemm_z, gemm_pm, gemm_vm: (gemm_cap, D) normal draws, momenta p = L^{-T} z and velocities of
    * the chains that start a transition in this tick: at most gemm_cap per tick, the others wait a tick (which
-   * changes no result: chains are independent).  Needs end_list (>= gemm_cap entries) and end_count (int32[1]). */
+   * changes no result: chains are independent).  Needs end_list ((2, N): chain and compact row of every list slot)
+   * and end_count (int32[1]). */
   float* gemm_pc;
   float* gemm_vc;
   float* gemm_z;
   float* gemm_pm;
   float* gemm_vm;
   int64_t gemm_cap;
+  const float* gemm_mass_sqrt; /* optional (D, D): L^{-T} = transpose of mass_sqrt_t, row-major.  Given, p = L^{-T} z runs on
+                                  the GEMM kernel that reads its matrix as stored (the one bjx_dense_apply_imm uses); NULL:
+                                  bjx_dense_matmul with mass_sqrt_t.  Same k order, same results. */
+  const float* gemm_imm_t;     /* optional (D, D): transpose of nuts->Mdense, row-major.  Given, the products run through
+                                  bjx_dense_apply_imm_t (few live rows -- the tail of a run -- on its latency-oriented
+                                  kernel); NULL: bjx_dense_apply_imm.  Same results. */
 } bjx_nuts_async_t;
 
 enum {

@@ -90,7 +90,7 @@ def test_nuts_descriptor_and_slots_match_header():
     max_mid = int(re.search(r"#define BJX_NUTS_MAX_MID (\d+)", text_nc).group(1))
     assert max_mid == _lib.NUTS_MAX_MID == len(_lib.NutsAsync().int_mid_kick) == len(_lib.NutsAsync().int_mid_drift)
     assert ctypes.sizeof(_lib.NutsAsync) == (8 + 4 * 2 + 8 * 7 + 8 * 2 + 8 * 8 + 8 + 4 * 2 + 8 * 9 + 8 * 4 + 4 * 2 + 8
-                                             + 8 * 2 + 4 * 2 + 8 + 4 * 2 + 4 * 2 * max_mid + 8 * 6)
+                                             + 8 * 2 + 4 * 2 + 8 + 4 * 2 + 4 * 2 * max_mid + 8 * 8)
     for name, i in _lib.NUTS_AT.items():
         assert enums["BJX_NUTS_AT_" + name] == i
     assert enums["BJX_NUTS_ADAPT_COLS"] == _lib.NUTS_ADAPT_COLS

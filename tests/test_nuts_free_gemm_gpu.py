@@ -130,3 +130,48 @@ def test_gemm_mode_refuses_what_it_does_not_implement(dev):
     with pytest.raises(NotImplementedError):  # multi-stage integrator
         nuts_mod.run_free(prng.key(0), st, tgt, 0.1, torch.eye(D, device=dev), 1, 3, dense_gemm=True,
                           integrator=bjx.integrators.mclachlan)
+
+
+@pytest.mark.parametrize("N,D", [(256, 128), (4096, 512), (40, 128), (300, 72)])
+def test_matmul_bt_equals_matmul(dev, N, D):
+    """bjx_dense_matmul_bt (the matrix also given transposed -> the kernel that reads it as stored, for whole aligned
+    tiles) returns bjx_dense_matmul's product bit for bit, for a NON-symmetric (triangular) matrix."""
+    from blackjax_amd import _lib
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    a = torch.randn(N, D, device=dev, generator=g)
+    b = torch.tril(torch.randn(D, D, device=dev, generator=g)).contiguous()
+    bt = b.t().contiguous()
+    c1, c2 = torch.empty_like(a), torch.empty_like(a)
+    s = _lib.current_stream()
+    _lib.call("bjx_dense_matmul", s, N, D, a.data_ptr(), b.data_ptr(), c1.data_ptr())
+    _lib.call("bjx_dense_matmul_bt", s, N, D, a.data_ptr(), b.data_ptr(), bt.data_ptr(), c2.data_ptr())
+    assert torch.equal(c1, c2)
+    np.testing.assert_allclose(t2n(c1), t2n(a.double() @ b.double()), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,D", [(1, 128), (7, 72), (32, 256), (130, 128), (1000, 256), (4096, 512), (16384, 128),
+                                 (300, 72), (5000, 200)])
+def test_apply_imm_t_is_the_same_chain_on_every_kernel(dev, N, D):
+    """bjx_dense_apply_imm_t: V = P imm^T (the matrix read as stored, metrics.py:263-304) for a matrix that is NOT
+    bitwise symmetric.  Few rows run on the latency-oriented kernel, whole aligned tiles on the MFMA kernel that reads
+    the matrix as stored, ragged shapes on the general MFMA kernel over the transposed copy: all three are one
+    ascending-k fp32 fma chain per element in the MFMA k order -- compared here with bjx_dense_matmul(P, imm_t)
+    (always the general MFMA kernel) bit for bit, and with the oracle's restatement of that chain."""
+    from blackjax_amd import _lib
+    from oracle import fp
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    p = torch.randn(N, D, device=dev, generator=g)
+    imm = torch.randn(D, D, device=dev, generator=g).contiguous()  # no symmetry at all
+    imm_t = imm.t().contiguous()
+    v1, v2 = torch.empty_like(p), torch.empty_like(p)
+    s = _lib.current_stream()
+    _lib.call("bjx_dense_apply_imm_t", s, N, D, p.data_ptr(), imm.data_ptr(), imm_t.data_ptr(), v1.data_ptr())
+    _lib.call("bjx_dense_matmul", s, N, D, p.data_ptr(), imm_t.data_ptr(), v2.data_ptr())
+    assert torch.equal(v1, v2)
+    rows = slice(0, min(N, 64))
+    ref = fp.gemm_f32chain(t2n(p[rows]), t2n(imm_t))
+    assert np.array_equal(t2n(v1[rows]), ref)
