@@ -132,7 +132,8 @@ def _dense_step(k0, k1, fold, off, vg, thr, q0, p_prev, logp0, g0, sl_prev, imm_
     t = ((sl_prev + 1.0) + delta) + 0.0  # ghmc.py:176 (noise_fn = 0)
     sl = torch.remainder(t, 2.0) - 1.0
     v0 = torch.empty_like(q0)
-    _lib.call("bjx_dense_apply_imm", stream, N, D, p.data_ptr(), metric.imm.data_ptr(), v0.data_ptr())
+    _lib.call("bjx_dense_apply_imm_t", stream, N, D, p.data_ptr(), metric.imm.data_ptr(), metric.imm_t.data_ptr(),
+              v0.data_ptr())
     ke0 = (v0.double() * p.double()).sum(-1).to(f32) * 0.5  # metrics.py:263-270, fp64-accumulated, rounded once
     q1, p_half = torch.empty_like(q0), torch.empty_like(q0)
     p_half = dense.leapfrog(stream, metric, N, D, 1, eps, eps_pc, q0, p, g0, q1, p_half)

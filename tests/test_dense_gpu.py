@@ -297,3 +297,31 @@ def test_dense_full_size_properties(dev):
     qb, pb, _, _ = integrate(qa, -pa, ga, L)
     assert (qb - q0).abs().max().item() < 5e-4
     assert (pb + p0).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("N,D,L", [(100, 64, 4), (256, 128, 3), (200, 128, 3)])
+def test_dense_hmc_reads_a_not_quite_symmetric_matrix_as_stored(dev, N, D, L):
+    """A dense inverse mass matrix that is symmetric only up to rounding (what a dense Welford window produces):
+    ``v = imm p`` must read it AS STORED, ``v[i] = sum_k imm[i][k] p[k]`` (metrics.py:263-304 ``linear_map``), on the
+    whole-tile GEMM kernel AND on the general one (ragged N or D; round 4: they get the transposed copy) -- so a chain's
+    arithmetic does not depend on the size of the batch it runs in.  Bit for bit against the oracle's f32-chain mode,
+    which reads rows."""
+    rho = 0.9
+    fn_o = otargets.ar1_gaussian(rho, D)
+    cov = otargets.ar1_covariance(rho, D).copy()
+    rng = np.random.default_rng(3)
+    cov = (cov * (1.0 + 1e-6 * np.triu(rng.standard_normal((D, D)), 1))).astype(np.float32)
+    assert not np.array_equal(cov, cov.T)
+    tgt = bjx.targets.AR1Gaussian(rho, D)
+    q0 = prng.normal(prng.key(1), (N, D)).astype(np.float32)
+    st_o = ohmc.init(q0, fn_o)
+    alg = bjx.hmc(tgt, 0.5, dev_t(cov, dev), L)
+    st_g = alg.init(dev_t(q0, dev))
+    metric = _shared_factor(dev, cov, N, D)
+    for kk in prng.split(prng.key(0), 3):
+        st_o, info_o = ohmc.kernel(kk, st_o, fn_o, np.float32(0.5), cov, L, metric=metric)
+        st_g, info_g = alg.step(kk, st_g)
+        assert np.array_equal(t2n(info_g.proposal.position), info_o.proposal.position)
+        assert np.array_equal(t2n(info_g.proposal.momentum), info_o.proposal.momentum)
+        assert np.array_equal(t2n(info_g.energy), info_o.energy)
+        assert np.array_equal(t2n(st_g.position), st_o.position)
