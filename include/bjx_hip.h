@@ -250,8 +250,12 @@ int bjx_dense_matmul_bt(void* stream, int64_t N, int64_t D, const float* A, cons
 
 /* V = P @ imm^T for N rows: v_i = imm p_i (linear_map(inverse_mass_matrix, p), util.py:58-61;
  * metrics.py:263-304) on the fp32 MFMA GEMM, imm read as the reference stores it (row n = output n).
- * Complete 128 x 128 tiles take the k-contiguous "TN" kernel.  Used by dense-metric NUTS, where the
- * kick and the consumers of v are separate kernels (bjx_nuts.h, v_pre). */
+ * Complete 128 x 128 tiles take the k-contiguous "TN" kernel, which reads imm[i][k]; ragged shapes run on the general
+ * kernel, which walks imm[k][i] -- the same product for an EXACTLY symmetric matrix only.  For a matrix that is
+ * symmetric up to rounding (a dense Welford estimate) use bjx_dense_apply_imm_t, which takes the transposed copy too
+ * and reads the matrix as stored at every shape (what dense-metric NUTS and the Python layer do since round 4; the
+ * fused entry points -- bjx_leapfrog_dense, bjx_hmc_finish_dense, ... -- follow the same rule, so their callers pass
+ * the transposed copy as `imm` for ragged shapes: blackjax_amd/dense.py::_imm_ptr). */
 int bjx_dense_apply_imm(void* stream, int64_t N, int64_t D, const float* P, const float* imm, float* V);
 
 /* Momentum draw: z = normal(km, (D,)) ; p = L^{-T} z = z @ mass_sqrt_t with mass_sqrt_t = L^{-1}
