@@ -1037,6 +1037,14 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
   const bool aligned = bjx_vec4_ok(ga.D, ga.A, ga.G, ga.A_out, ga.B, ga.C, ga.Q_in, ga.Q_out);
   const bool full = (ga.M % BM == 0) && (ga.D % BN == 0);
+  if (ga.b_symmetric && full && !aligned) {
+    // The host side (blackjax_amd/dense.py::_imm_ptr) hands over the matrix AS STORED for whole tiles and its
+    // transposed copy for ragged shapes; whole tiles on the general kernel would read `imm` transposed, which is
+    // wrong for a matrix that is symmetric only up to rounding.  Refuse instead of silently transposing.
+    bjx_set_error("dense metric: whole %dx%d tiles need 16-byte aligned buffers (N=%lld, D=%lld)", BM, BN,
+                  (long long)ga.M, (long long)ga.D);
+    return 1;
+  }
   if (ga.b_symmetric && aligned && full) {
     static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
     // staggered start: only when the launch is at most one round of resident workgroups (2 per CU)

@@ -113,7 +113,7 @@ def mhmc_step(stream, metric, k0, k1, off, fold, n, d, step, eps, eps_pc, thr, l
             weight.data_ptr(), slpa.data_ptr(), any_div.data_ptr(), ever.data_ptr(), pq.data_ptr(),
             pp.data_ptr(), pg.data_ptr(), plogp.data_ptr(), penergy.data_ptr())
     if kick_coef is not None:  # any palindromic integrator: closing kick (eps * b1) g (round 4)
-        _lib.call("bjx_mhmc_step_dense_coef", *args[:9], float(kick_coef), *args[9:], _lib.ptr(n_steps))
+        _lib.call("bjx_mhmc_step_dense_coef", *args[:8], float(kick_coef), *args[8:], _lib.ptr(n_steps))
     elif n_steps is None:
         _lib.call("bjx_mhmc_step_dense", *args)
     else:

@@ -162,19 +162,24 @@ def test_mhmc_dense_window_adaptation_smoke(dev):
 
 
 @pytest.mark.parametrize("name", ["mclachlan", "yoshida", "omelyan"])
+@pytest.mark.parametrize("eps_pc", [False, True])
 @pytest.mark.parametrize("N,D,L,per_chain", [(128, 128, 3, False), (20, 24, 4, True)])
-def test_mhmc_dense_general_integrator_parity(dev, name, N, D, L, per_chain):
+def test_mhmc_dense_general_integrator_parity(dev, name, N, D, L, per_chain, eps_pc):
     """Round 4 (VERDICT r3 "missing" #4): blackjax.mhmc with a DENSE metric and a multi-stage integrator
     (hmc.py:181-248 over integrators.py:335-369) -- every stage a masked-free bjx_leapfrog_dense_coef launch, the
     closing kick b1 + reservoir step bjx_mhmc_step_dense_coef.  Reservoir picks (exact positions and momenta)
     and divergence flags follow the oracle (shared matrix: its f32-chain mode; per chain: fp64 mat-vec)."""
     fn_o, tgt, imm, metric, q0 = _setup(dev, N, D, per_chain, seed=3)
     st_o = ohmc.init(q0, fn_o)
-    alg = bjx.mhmc(tgt, 0.3, dev_t(imm, dev), L, chain_offset=2, integrator=getattr(bjx.integrators, name))
+    # eps_pc: one step size PER CHAIN (the closing kick must use eps[chain] * b1: ADVICE r4 found the scalar and the
+    # per-chain step size swapped with the coefficient in this call, invisible with a scalar step size)
+    eps = np.random.default_rng(11).uniform(0.15, 0.4, N).astype(f32) if eps_pc else f32(0.3)
+    alg = bjx.mhmc(tgt, dev_t(eps, dev) if eps_pc else 0.3, dev_t(imm, dev), L, chain_offset=2,
+                   integrator=getattr(bjx.integrators, name))
     st_g = alg.init(dev_t(q0, dev))
     moved = 0
     for kk in prng.split(prng.key(0), 3):
-        st_n, info_o = ohmc.mhmc_kernel(kk, st_o, fn_o, f32(0.3), imm, L, chain_offset=2, metric=metric,
+        st_n, info_o = ohmc.mhmc_kernel(kk, st_o, fn_o, eps, imm, L, chain_offset=2, metric=metric,
                                         coefficients=getattr(oint, name))
         st_g, info_g = alg.step(kk, st_g)
         assert np.array_equal(t2n(st_g.position), st_n.position)
@@ -188,18 +193,21 @@ def test_mhmc_dense_general_integrator_parity(dev, name, N, D, L, per_chain):
 
 
 @pytest.mark.parametrize("name", ["mclachlan", "omelyan"])
+@pytest.mark.parametrize("eps_pc", [False, True])
 @pytest.mark.parametrize("N,D,per_chain", [(40, 36, False), (14, 12, True)])
-def test_dmhmc_dense_general_integrator_parity(dev, name, N, D, per_chain):
+def test_dmhmc_dense_general_integrator_parity(dev, name, N, D, per_chain, eps_pc):
     """blackjax.dmhmc (per-chain random trajectory lengths + progressive sampling) with a dense metric and a
     multi-stage integrator: all launches masked by the chain's own length."""
     fn_o, tgt, imm, metric, q0 = _setup(dev, N, D, per_chain, seed=9)
     st = ohmc.init(q0, fn_o)
     st_o = ohmc.DynamicHMCState(st.position, st.logdensity, st.logdensity_grad, prng.split(prng.key(77), N))
-    alg = bjx.dmhmc(tgt, 0.3, dev_t(imm, dev), integrator=getattr(bjx.integrators, name))
+    eps = np.random.default_rng(13).uniform(0.15, 0.4, N).astype(f32) if eps_pc else f32(0.3)
+    alg = bjx.dmhmc(tgt, dev_t(eps, dev) if eps_pc else 0.3, dev_t(imm, dev),
+                    integrator=getattr(bjx.integrators, name))
     st_g = alg.init(dev_t(q0, dev), prng.key(77))
     lengths = set()
     for kk in prng.split(prng.key(0), 3):
-        st_n, info_o = ohmc.dynamic_hmc_kernel(kk, st_o, fn_o, f32(0.3), imm, metric=metric, multinomial=True,
+        st_n, info_o = ohmc.dynamic_hmc_kernel(kk, st_o, fn_o, eps, imm, metric=metric, multinomial=True,
                                                coefficients=getattr(oint, name))
         st_g, info_g = alg.step(kk, st_g)
         assert np.array_equal(t2n(info_g.num_integration_steps), info_o.num_integration_steps)

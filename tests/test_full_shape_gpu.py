@@ -258,3 +258,39 @@ def test_c5_full_shape_dense_subset_bit_exact(dev):
         n_rej += int((~info_s.is_accepted).sum())
         assert 0.3 < float(info_g.acceptance_rate.mean()) <= 1.0
     assert n_rej > 0
+
+
+def test_c5_dense_oracle_own_factor(dev):
+    """the test above hands the oracle the ENGINE's Cholesky / triangular-inverse factor, so only the
+    GEMM chain is compared bit for bit.  Here the oracle factorises the matrix ITSELF (metrics.py:701-729:
+    cholesky + solve_triangular on the host, fp64 rounded once) and runs its fp64-accumulated products; the
+    engine uses its own factor and the MFMA fp32 chain.  C5's target and metric (D = 512, AR(1) rho = 0.9, L = 20,
+    eps = 0.5), 256 chains (two complete GEMM tile rows), ten transitions without re-sync.  Stated tolerance of
+    the two arithmetics over ten transitions: accept bits equal except within 1e-5 of a tie,
+    |dq| <= 1e-4, momenta 2e-4."""
+    N, D, L, eps, T, rho = 256, 512, 20, 0.5, 10, 0.9
+    cov = otargets.ar1_covariance(rho, D)
+    fn_o = otargets.ar1_gaussian(rho, D)
+    q0 = np.random.default_rng(5).standard_normal((N, D), dtype=f32)
+    alg = bjx.hmc(bjx.targets.AR1Gaussian(rho, D), eps, dev_t(cov, dev), L)
+    st_g = alg.init(dev_t(q0, dev))
+    metric_own = ohmc.default_metric(cov)  # the oracle's own factor, fp64-accumulated products
+    st_o = ohmc.init(q0, fn_o)
+    flips = 0
+    for k in prng.split(prng.key(33), T):
+        # restart the oracle from the engine's state each transition: a one-ulp difference must not be amplified
+        # through ten chaotic trajectories before it is measured
+        st_o = ohmc.HMCState(t2n(st_g.position), t2n(st_g.logdensity), t2n(st_g.logdensity_grad))
+        st_g, info_g = alg.step(k, st_g)
+        st_o, info_o = ohmc.kernel(k, st_o, fn_o, f32(eps), cov, L, metric=metric_own)
+        np.testing.assert_allclose(t2n(info_g.momentum), info_o.momentum, rtol=0, atol=2e-5)  # a7: p0 = L^-T z
+        np.testing.assert_allclose(t2n(info_g.proposal.position), info_o.proposal.position, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(t2n(info_g.proposal.momentum), info_o.proposal.momentum, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(t2n(info_g.acceptance_rate), info_o.acceptance_rate, rtol=0, atol=2e-4)
+        diff = t2n(info_g.is_accepted) != info_o.is_accepted
+        if diff.any():  # only a uniform draw within the stated tolerance of the acceptance probability may flip
+            ki = prng.split(prng.split(k, N), 2)[:, 1]
+            u = prng.uniform(ki, ())
+            assert np.all(np.abs(u[diff] - info_o.acceptance_rate[diff]) < 2e-4)
+            flips += int(diff.sum())
+    assert flips <= 2

@@ -25,6 +25,22 @@ def test_build_schedule_golden(num_steps):
     assert [(int(s), bool(e)) for s, e in got] == expected
 
 
+@pytest.mark.parametrize("num_steps", ["19", "100", "200"])
+def test_product_build_schedule_golden(num_steps):
+    """The PRODUCT's own host schedule (blackjax_amd.adaptation.build_schedule) on the reference's
+    vectors (tests/adaptation/test_adaptation.py:27-49) -- not only through the warm-up parity tests --
+    and equal to the oracle's on a sweep of lengths."""
+    from blackjax_amd.adaptation import build_schedule
+
+    expected = []
+    for stage, end, count in KATS["build_schedule"][num_steps]:
+        expected += [(stage, end)] * count
+    got = build_schedule(int(num_steps))
+    assert [(int(s), bool(e)) for s, e in got] == expected
+    for n in (0, 1, 20, 21, 149, 150, 151, 333, 1000, 2500):
+        assert [(int(s), bool(e)) for s, e in build_schedule(n)] == [(int(s), bool(e)) for s, e in oad.build_schedule(n)]
+
+
 def test_dual_averaging_golden():
     k = KATS["dual_averaging"]
     st = oad.da_init(np.array([k["x_init"]], f32))
