@@ -39,6 +39,9 @@ JSON extras (contract in the task statement):
   ess / ess_nonresonant   min-ESS per second on the contract parameters (eps*L = 12.5 ~ 4 pi: a
                 resonant trajectory length, every transition returns near its start) and on
                 eps = 0.21 (same cost per transition, non-resonant).
+  parity        BASELINE.md section 3's parity columns, per config (top level = C2; c3_nuts.parity, c5_dense.parity): one
+                more transition AFTER the timed regions, engine over all chains vs the oracle on a spread subset --
+                accept_mismatches, max_abs_dpos, max_abs_dmean, max_abs_dvar, chains_checked.
   cpu_baseline  BlackJAX on JAX-CPU when ``import jax, blackjax`` works on this box ("reference"),
                 else the oracle's C/OpenMP port ("port"); bounded sample, rank 0, N = 1 only.
 """
@@ -173,6 +176,161 @@ def cpu_baseline(D, L, eps, target_seconds=15.0):
 
 
 # ------------------------------------------------------------------------------------ launching
+# ------------------------------------------------------------------------------------ parity (checker leg)
+# BASELINE.md section 3 asks for "accept-index mismatches vs oracle, max |d mean|, |d var|" NEXT TO the throughput.
+# After the timed regions (never inside them) one more transition of the benchmarked state is taken by the engine
+# over all chains and recomputed for a spread subset of chains by the oracle (oracle/: the CPU restatement of the
+# reference's arithmetic, test infrastructure -- here the CHECKER, never the thing measured).  The subset's
+# per-chain keys are the rows of split(key, N_total) at the chains' global indices, so the subset run IS those chains.
+def _spread_chains(N, blocks, n_total, seed):
+    """First / last chains, both sides of every boundary of each block size, random fill up to n_total chains."""
+    idx = {0, 1, 2, 3, 63, 64, N - 2, N - 1}
+    for b in blocks:
+        if b and b < N:
+            for m in range(b, N, b):
+                idx.update((m - 1, m))
+    idx = {i for i in idx if 0 <= i < N}
+    rng = np.random.default_rng(seed)
+    pool = np.setdiff1d(np.arange(N), np.fromiter(idx, dtype=np.int64))
+    if n_total > len(idx):
+        idx.update(int(i) for i in rng.choice(pool, min(n_total - len(idx), len(pool)), replace=False))
+    return np.array(sorted(idx), dtype=np.int64)
+
+
+def _moment_deltas(a, b):
+    """max over dimensions of |mean_a - mean_b| and |var_a - var_b| across the checked chains (fp64 moments)."""
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    return (float(np.max(np.abs(a64.mean(0) - b64.mean(0)))), float(np.max(np.abs(a64.var(0) - b64.var(0)))))
+
+
+def parity_c2(bjx, dev, rank, state, target, imm, inv_var, N, D, L, eps, sched):
+    """One more C2 transition from the benchmarked state: engine (all chains, the headline's scheduling) vs the
+    oracle's C port on >= 512 chains spread over every chain block."""
+    from oracle import cport, prng
+
+    t0 = time.perf_counter()
+    cb, gr, ns = sched
+    idx = _spread_chains(N, (cb, 4096), 512, seed=17)
+    t = torch.as_tensor(idx, device=dev)
+    q = state.position[t].cpu().numpy().copy()
+    lp = state.logdensity[t].cpu().numpy().copy()
+    g = state.logdensity_grad[t].cpu().numpy().copy()
+    alg = bjx.hmc(target, eps, imm, L, chain_offset=rank * N, chain_block=cb, use_graph=gr, streams=ns)
+    key = bjx.random.key(424242)
+    st1, info = alg.step(key, state)
+    acc_o, ia_o, idv_o = cport.hmc_diag_gaussian_step_pc(
+        prng.split_at(np.asarray(key), idx + rank * N), q, lp, g, eps,
+        imm.cpu().numpy(), inv_var.cpu().numpy(), L)
+    pos_g = st1.position[t].cpu().numpy()
+    dmean, dvar = _moment_deltas(pos_g, q)
+    ia_g = info.is_accepted[t].cpu().numpy().astype(bool)
+    return {"checked_against": "oracle/c (C port of the oracle, bit-identical to oracle/hmc.py: tests/test_oracle_c.py)",
+            "transition": "one transition after the timed region, from the benchmarked state, fresh key",
+            "chains_checked": int(len(idx)), "chain_blocks_covered": int(len(np.unique(idx // cb))),
+            "chain_blocks_total": int((N + cb - 1) // cb),
+            "accept_mismatches": int(np.sum(ia_g != ia_o)),
+            "divergence_mismatches": int(np.sum(info.is_divergent[t].cpu().numpy().astype(bool) != idv_o)),
+            "max_abs_dacceptance_rate": float(np.max(np.abs(info.acceptance_rate[t].cpu().numpy() - acc_o))),
+            "max_abs_dpos": float(np.max(np.abs(pos_g - q))),
+            "max_abs_dgrad": float(np.max(np.abs(st1.logdensity_grad[t].cpu().numpy() - g))),
+            "max_abs_dmean": dmean, "max_abs_dvar": dvar,
+            "rejected_among_checked": int(np.sum(~ia_o)), "seconds": time.perf_counter() - t0}
+
+
+def parity_c5(bjx, dev, rank, alg, state, N, D, L, eps, rho):
+    """One more C5 transition: engine (MFMA GEMM chain) vs oracle/hmc.py in its f32-chain mode (the stated k order of
+    v_mfma_f32_32x32x2_f32, oracle/fp.py) on >= 256 chains, at least one in every 128-row GEMM tile.  The oracle runs
+    with the engine's fp32 factor L^-T (so the GEMM chain is compared bit for bit); the factor itself is compared
+    with the oracle's own fp64 Cholesky / triangular inverse and the difference reported."""
+    from oracle import hmc as ohmc
+    from oracle import prng
+    from oracle import targets as otargets
+
+    t0 = time.perf_counter()
+    f32 = np.float32
+    rng = np.random.default_rng(23)
+    idx = np.unique(np.concatenate([_spread_chains(N, (4096,), 128, seed=29),
+                                    np.arange(0, N, 128) + rng.integers(0, 128, (N + 127) // 128)]))
+    idx = idx[idx < N]
+    t = torch.as_tensor(idx, device=dev)
+    cov = otargets.ar1_covariance(rho, D)
+    fn_o = otargets.ar1_gaussian(rho, D)
+    m = bjx.metrics.default_metric(torch.as_tensor(cov, device=dev), N, D, dev)
+    mass_sqrt = np.ascontiguousarray(m.mass_sqrt_t.cpu().numpy().T)
+    own = ohmc.default_metric(cov).mass_matrix_sqrt
+    factor_rel = float(np.max(np.abs(mass_sqrt - own) / np.maximum(np.abs(own), 1e-30)))
+    metric = ohmc.default_metric(cov, dense_accum="f32chain", mass_matrix_sqrt=mass_sqrt)
+    st_s = ohmc.HMCState(state.position[t].cpu().numpy().copy(), state.logdensity[t].cpu().numpy().copy(),
+                         state.logdensity_grad[t].cpu().numpy().copy())
+    key = bjx.random.key(515151)
+    st1, info = alg.step(key, state)
+    key_np = np.asarray(key)
+    st_s, info_s = ohmc.kernel(None, st_s, fn_o, f32(eps), cov, L, metric=metric,
+                               chain_keys_override=prng.split_at(key_np, idx + rank * N))
+    pos_g = st1.position[t].cpu().numpy()
+    dmean, dvar = _moment_deltas(pos_g, st_s.position)
+    return {"checked_against": "oracle/hmc.py, dense_accum='f32chain' (fp32 fma chain in the MFMA's k order), engine's fp32 factor",
+            "transition": "one transition after the timed region, from the benchmarked state, fresh key",
+            "chains_checked": int(len(idx)), "gemm_tiles_covered": int(len(np.unique(idx // 128))),
+            "gemm_tiles_total": int((N + 127) // 128),
+            "accept_mismatches": int(np.sum(info.is_accepted[t].cpu().numpy().astype(bool) != info_s.is_accepted)),
+            "divergence_mismatches": int(np.sum(info.is_divergent[t].cpu().numpy().astype(bool) != info_s.is_divergent)),
+            "max_abs_dacceptance_rate": float(np.max(np.abs(info.acceptance_rate[t].cpu().numpy() - info_s.acceptance_rate))),
+            "max_abs_dmomentum_draw": float(np.max(np.abs(info.momentum[t].cpu().numpy() - info_s.momentum))),
+            "max_abs_dpos": float(np.max(np.abs(pos_g - st_s.position))),
+            "max_abs_dmean": dmean, "max_abs_dvar": dvar,
+            "factor_max_rel_diff_vs_oracle_own_cholesky": factor_rel,
+            "rejected_among_checked": int(np.sum(~info_s.is_accepted)), "seconds": time.perf_counter() - t0}
+
+
+def parity_c3(bjx, dev, rank, alg, state, N, D, eps, max_depth):
+    """One more lockstep NUTS transition: engine (all chains) vs oracle/nuts.py on 120+ chains spread over the batch
+    plus the chains that built the deepest trees of this transition (chosen from the engine's record; the oracle
+    recomputes them from scratch)."""
+    from oracle import hmc as ohmc
+    from oracle import nuts as onuts
+    from oracle import prng
+    from oracle import targets as otargets
+
+    t0 = time.perf_counter()
+    f32 = np.float32
+    key = bjx.random.key(313131)
+    st1, info = alg.step(key, state)
+    deepest = torch.topk(info.num_integration_steps, 8).indices.cpu().numpy()
+    idx = np.unique(np.concatenate([_spread_chains(N, (8192,), 120, seed=31), deepest]))
+    t = torch.as_tensor(idx, device=dev)
+    st_s = ohmc.HMCState(state.position[t].cpu().numpy().copy(), state.logdensity[t].cpu().numpy().copy(),
+                         state.logdensity_grad[t].cpu().numpy().copy())
+    key_np = np.asarray(key)
+    st_s, info_s = onuts.kernel(None, st_s, otargets.neal_funnel(), f32(eps), np.ones(D, f32), max_depth,
+                                chain_keys_override=prng.split_at(key_np, idx + rank * N))
+    pos_g = st1.position[t].cpu().numpy()
+    dmean, dvar = _moment_deltas(pos_g, st_s.position)
+    mism = {name: int(np.sum(getattr(info, name)[t].cpu().numpy() != getattr(info_s, name)))
+            for name in ("num_integration_steps", "num_trajectory_expansions", "is_turning", "is_divergent")}
+    return {"checked_against": "oracle/nuts.py (NumPy restatement of nuts.py / trajectory.py / termination.py)",
+            "transition": "one lockstep transition after the timed regions, from the benchmarked state, fresh key",
+            "chains_checked": int(len(idx)),
+            "accept_mismatches": int(np.sum(np.any(pos_g != st_s.position, axis=1) & (np.max(np.abs(pos_g - st_s.position), axis=1) > 1e-5))),
+            "accept_note": "NUTS has no accept bit: a chain counts as a mismatch when its selected proposal differs from the oracle's by more than 1e-5 anywhere",
+            "tree_size_mismatches": mism["num_integration_steps"], "tree_depth_mismatches": mism["num_trajectory_expansions"],
+            "turning_flag_mismatches": mism["is_turning"], "divergence_mismatches": mism["is_divergent"],
+            "max_abs_dpos": float(np.max(np.abs(pos_g - st_s.position))),
+            "frac_position_elements_not_bit_equal": float(np.mean(pos_g != st_s.position)),
+            "max_abs_dacceptance_rate": float(np.max(np.abs(info.acceptance_rate[t].cpu().numpy() - info_s.acceptance_rate))),
+            "max_abs_dmean": dmean, "max_abs_dvar": dvar,
+            "largest_tree_checked": int(np.max(info_s.num_integration_steps)),
+            "tree_depths_checked": sorted(set(int(d) for d in info_s.num_trajectory_expansions)),
+            "seconds": time.perf_counter() - t0}
+
+
+def _try_parity(fn, *a):
+    try:
+        return fn(*a)
+    except Exception as e:  # the parity block is a reported extra; it must never fail the throughput line
+        return {"error": repr(e)[:400]}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -665,6 +823,10 @@ def bench_c2(args, ctx):
                            "note": "same kernels and cost per transition with eps = 0.21: trajectory phase "
                                    "50 * 2*asin(0.105) = 10.5 rad, not a multiple of 2*pi"})
 
+    parity = None
+    if rank == 0 and not args.no_parity and not args.only_mode and not args.headline_only:
+        parity = _try_parity(parity_c2, bjx, dev, rank, head["state"], target, imm, inv_var, N, D, L, args.eps,
+                             (head["chain_block"], head["hip_graph"], head["streams"]))
     if rank != 0:
         return None
     value = head["value"]
@@ -699,6 +861,7 @@ def bench_c2(args, ctx):
         "torch_pair_mode": torch_pair_mode,
         "engine_resident_target_mode": resident_mode,
         "roofline": roofline,
+        "parity": parity,
     }
     return out
 
@@ -875,6 +1038,9 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
             _lib.set_timer(None)
             tick_us = None
             print(f"bench.py: c3 tick bracket failed: {e!r}", file=sys.stderr)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = _try_parity(parity_c3, bjx, dev, rank, alg, st_box["state"], N, D, eps, max_depth)
     if rank != 0:
         return None
     peak_rate = HBM_PEAK_GBS * 1e9 / (52.0 * D)  # chain-leapfrogs/s per GPU at 52 B per element
@@ -892,6 +1058,27 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
                                    "the callable's launch is outside this bracket) over all chains, first 24 bracketed "
                                    "ticks of a plain-launch run",
     }
+    # MEASURED traffic of one busy-phase tick (tick kernel + callable, every chain live): committed PMC passes
+    # (tools/pmc_nuts_traffic.sh -> profiles/nuts_traffic_latest.json; FETCH_SIZE doubled per the guide's gfx950 note)
+    tpath = os.path.join(ROOT, "profiles", "nuts_traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("chains") == N and tj.get("dim") == D:
+                both = tj["tick_plus_callable"]
+                per_leap = both["measured_bytes"] / N  # bytes per chain-leapfrog, callable included
+                roofline.update({
+                    "traffic": both["measured_bytes"],
+                    "traffic_unit": "bytes per full-ensemble tick (tick kernel + callable launch), L2 memory-side counters",
+                    "traffic_bytes_per_chain_leapfrog": per_leap, "traffic_bytes_per_element": per_leap / D,
+                    "traffic_over_algorithmic": per_leap / (52.0 * D),
+                    "frac_at_measured_bytes": value / world * per_leap / 1e9 / HBM_PEAK_GBS,
+                    "busy_phase_tick_GBps_measured": both.get("GBps_measured"),
+                    "busy_phase_tick_frac_measured": both.get("frac_of_8TBps_measured"),
+                    "traffic_source": "profiles/nuts_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                      "earlier run, committed; NOT measured in this run; Infinity-Cache hits are counted)"})
+        except Exception:
+            pass
     return {
         "metric": "NUTS useful chain-leapfrog-steps/sec (whole node), 32 768 chains x 256-dim funnel",
         "value": value, "unit": "chain-leapfrog-steps/s", "n_gpus": world, "steps": T, "warmup": n_warm,
@@ -918,6 +1105,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
             "note": "alg.step (the reference's kernel API: all chains in lockstep, HIP-graph driver); a transition lasts "
                     "as long as the deepest tree of the ensemble"},
         "roofline": roofline,
+        "parity": parity,
     }
 
 
@@ -956,6 +1144,9 @@ def bench_c5(args, ctx, steps=None):
 
     dt, per, _ = timed_region(ctx, one, K)
     _lib.set_timer(None)
+    parity = None
+    if rank == 0 and not args.no_parity and D == 512:
+        parity = _try_parity(parity_c5, bjx, dev, rank, alg, box["state"], N, D, L, 0.5, 0.9)
     if rank != 0:
         return None
     flops = 2.0 * N * D * D
@@ -984,6 +1175,7 @@ def bench_c5(args, ctx, steps=None):
         "mean_acceptance": float(acc) / K,
         "end_to_end_TFLOPs": value / world * 2.0 * D * D / 1e12,
         "roofline": roofline,
+        "parity": parity,
     }
 
 
@@ -1051,6 +1243,9 @@ def main():
     ap.add_argument("--no-ess-nonresonant", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity block (one extra transition per config recomputed by the oracle for a spread "
+                         "subset of chains, after the timed regions)")
     ap.add_argument("--no-rng-pin", action="store_true",
                     help="skip the jax.random self-check (it only does anything where `import jax` works)")
     ap.add_argument("--only-mode", choices=["torch_autograd", "torch_pair"], default=None,

@@ -50,15 +50,11 @@ struct GemmArgs {
   // otherwise its momentum and position are copied through untouched.  NULL = every row advances.
   const int32_t* n_steps = nullptr;
   int32_t step_idx = 0;
-  // Staggered start (k_dense_gemm_tn8): workgroups of the second half of the grid (stagger_mode 0) or
-  // of every other group of eight (mode 1) wait this many ticks of the 100 MHz wall clock before
-  // they load anything.  When a launch is exactly one round of resident workgroups (C5: 512 tiles on
-  // 256 CUs x 2) all of them reach the drift epilogue -- 67 MB of q / q' -- at the same moment and the
-  // matrix pipes idle while HBM drains it; a late workgroup lets its CU neighbour run at the full pipe
-  // rate first, so the two finish their main loops a stagger apart and one epilogue hides under the
-  // other's MFMAs.  0 = off.  Pure scheduling: results are unchanged.
-  int32_t stagger_ticks = 0;
-  int32_t stagger_mode = 0;
+#ifdef BJX_DENSE_PROBE
+  // PROBE builds only (tools/dense_timeline.py): four wall-clock stamps per workgroup -- entry, first K-tile staged,
+  // end of the main loop, end of the epilogue.  The shipped library has no such field.
+  unsigned long long* probe = nullptr;
+#endif
 };
 
 __device__ __forceinline__ bool gemm_row_active(const GemmArgs& a, int64_t row) {
@@ -534,13 +530,9 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   const int64_t row0 = row_blk * BM, col0 = col_blk * BN, D = a.D;
   float* As0 = smem;
   float* Bs0 = smem + 2 * BM * LDK;
-  if (a.stagger_ticks > 0) {
-    const bool late = a.stagger_mode == 0 ? (blockIdx.x >= gridDim.x / 2) : (((blockIdx.x >> 3) & 1) != 0);
-    if (late) {
-      const uint64_t t0 = wall_clock64();
-      while (wall_clock64() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-    }
-  }
+#ifdef BJX_DENSE_PROBE
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 0] = wall_clock64();
+#endif
 
   // staging: thread -> (tile row tid/4, 4 consecutive k starting at (tid&3)*4) of A and of Bt
   const int s_row = tid >> 2, s_k = (tid & 3) * 4;
@@ -574,10 +566,16 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
         kick(r.a, r.g, ha);
         if constexpr (KICKS == 2) kick(r.a, r.g, hb);
       }
-      if (a_out && k0 / BN == col_blk) st4(a_out + k0, r.a);
     }
     st4(As0 + buf * BM * LDK + s_row * LDK + s_k, r.a);
     st4(Bs0 + buf * BN * LDK + s_row * LDK + s_k, r.b);
+    // The store of the kicked momentum goes LAST (round 5): vmcnt counts loads and stores in issue order, so with
+    // the store ahead of the B-tile's LDS write the `s_waitcnt vmcnt(0)` for r.b also waited for the store's
+    // acknowledgement -- a full memory round trip in front of the K-tile barrier in 8 of 32 K-tiles.  Issued here,
+    // nothing waits for it before the next K-tile's staging (whose loads were requested a K-tile earlier).
+    if constexpr (KICKS > 0) {
+      if (a_out && k0 / BN == col_blk) st4(a_out + k0, r.a);
+    }
   };
 
   f32x16 acc[2];
@@ -591,6 +589,9 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   load_tiles(R1, BK);
   store_tiles(R0, 0, 0);
   __syncthreads();
+#ifdef BJX_DENSE_PROBE
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 1] = wall_clock64();
+#endif
   const int lm = lane & 31, lk = lane >> 5;
   const int a_off = (wm * 64 + lm) * LDK + lk * 8;
   const int b_off = (wn * 32 + lm) * LDK + lk * 8;
@@ -627,10 +628,35 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
     tile(t, R1, R0);
     tile(t + 1, R0, R1);
   }
+#ifdef BJX_DENSE_PROBE
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 2] = wall_clock64();
+#endif
 
   // epilogue: each wave transposes its two 32 x 32 accumulator tiles through its private 4 KiB slice
-  // of the (now idle) tile buffers so that global accesses are 16-byte row segments
+  // of the (now idle) tile buffers so that global accesses are 16-byte row segments.
+  // Round 5: (1) all eight q segments of a lane are requested up front, in one batch -- before, every segment was
+  // load -> s_waitcnt vmcnt(0) -> fma -> store, and since vmcnt counts stores too each wait also covered the
+  // PREVIOUS segment's store: eight dependent memory round trips per wave at the end of the launch, when every
+  // workgroup of the one-round grid is in its epilogue; (2) per-row step sizes / trajectory masks are read once per
+  // row, ahead of the transposes; (3) a masked row is a select on the result, not a branch, so every segment is one
+  // 16-byte store.  Arithmetic unchanged: q' = fma(eps * drift, v, q).
   float* stage = smem + wave * (32 * 32);
+  const int c4 = (lane & 7) * 4;
+  const int64_t col = col0 + wn * 32 + c4;
+  [[maybe_unused]] F4 qv[2][4];
+  [[maybe_unused]] float ev[2][4];
+  [[maybe_unused]] int32_t nsv[2][4];  // the row's trajectory length (dynamic HMC), INT32_MAX = every row advances
+  if constexpr (EPI == EPI_DRIFT) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t row = row0 + wm * 64 + i * 32 + (lane >> 3) + 8 * it;
+        qv[i][it] = ld4(a.Q_in + row * D + col);
+        ev[i][it] = a.eps_pc ? a.eps_pc[row] : a.eps;
+        nsv[i][it] = a.n_steps ? a.n_steps[row] : INT32_MAX;
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -640,8 +666,6 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int c4 = (lane & 7) * 4;
-    const int64_t col = col0 + wn * 32 + c4;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int rl = (lane >> 3) + 8 * it;
@@ -650,19 +674,22 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
       if constexpr (EPI == EPI_STORE) {
         st4(a.C + row * D + col, c);
       } else {
-        const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
-        const F4 q = ld4(a.Q_in + row * D + col);
-        if (gemm_row_active(a, row))
-          st4(a.Q_out + row * D + col,
-              F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
-        else
-          st4(a.Q_out + row * D + col, q);
+        const float e = ev[i][it] * a.drift;
+        const F4 q = qv[i][it];
+        const bool act = a.step_idx < nsv[i][it];  // gemm_row_active
+        const F4 r{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)};
+        st4(a.Q_out + row * D + col, F4{act ? r.x : q.x, act ? r.y : q.y, act ? r.z : q.z, act ? r.w : q.w});
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+#ifdef BJX_DENSE_PROBE
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stamp follows the last store's acknowledgement
+  __syncthreads();
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 3] = wall_clock64();
+#endif
 }
 
 constexpr int kBlock = 256;
@@ -826,15 +853,6 @@ struct PcArgs {
   float kick_a = 0.5f, kick_b = 0.5f, drift = 1.0f;  // as in GemmArgs
   const int32_t* n_steps = nullptr;
   int32_t step_idx = 0;
-  // Staggered start (k_dense_gemm_tn8): workgroups of the second half of the grid (stagger_mode 0) or
-  // of every other group of eight (mode 1) wait this many ticks of the 100 MHz wall clock before
-  // they load anything.  When a launch is exactly one round of resident workgroups (C5: 512 tiles on
-  // 256 CUs x 2) all of them reach the drift epilogue -- 67 MB of q / q' -- at the same moment and the
-  // matrix pipes idle while HBM drains it; a late workgroup lets its CU neighbour run at the full pipe
-  // rate first, so the two finish their main loops a stagger apart and one epilogue hides under the
-  // other's MFMAs.  0 = off.  Pure scheduling: results are unchanged.
-  int32_t stagger_ticks = 0;
-  int32_t stagger_mode = 0;
 };
 
 template <int EPI>
@@ -1032,6 +1050,10 @@ int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
   return bjx_check_launch("bjx_dense_pc gemv");
 }
 
+#ifdef BJX_DENSE_PROBE
+static unsigned long long* g_probe_buf = nullptr;
+#endif
+
 int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
   GemmArgs ga = ga_in;
   const dim3 grid((unsigned)(((ga.D + BN - 1) / BN) * ((ga.M + BM - 1) / BM)));
@@ -1047,14 +1069,8 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
   }
   if (ga.b_symmetric && aligned && full) {
     static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
-    // staggered start: only when the launch is at most one round of resident workgroups (2 per CU)
 #ifdef BJX_DENSE_PROBE
-    static const double stagger_us = [] { const char* e = getenv("BJX_DENSE_STAGGER_US"); return e ? atof(e) : 0.0; }();
-    static const int stagger_mode = [] { const char* e = getenv("BJX_DENSE_STAGGER_MODE"); return e ? atoi(e) : 0; }();
-    if (stagger_us > 0.0 && grid.x <= 512u && grid.x >= 2u) {
-      ga.stagger_ticks = (int32_t)(stagger_us * 100.0);
-      ga.stagger_mode = stagger_mode;
-    }
+    ga.probe = g_probe_buf;
 #endif
 #define BJX_LAUNCH_TN(E, K)                                                                   \
   do {                                                                                        \
@@ -1448,5 +1464,13 @@ int bjx_mhmc_step_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                          logp_new, p1_work, v_work, weight, sum_log_p_accept, any_divergent, ever_accepted, prop_q,
                          prop_p, prop_g, prop_logp, prop_energy, n_steps, kick_coef);
 }
+
+#ifdef BJX_DENSE_PROBE
+/* PROBE builds only: device buffer of 4 x (number of workgroups) 64-bit stamps, or NULL. */
+int bjx_dense_probe_set(void* buf) {
+  g_probe_buf = (unsigned long long*)buf;
+  return 0;
+}
+#endif
 
 }  // extern "C"
