@@ -531,7 +531,13 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   float* As0 = smem;
   float* Bs0 = smem + 2 * BM * LDK;
 #ifdef BJX_DENSE_PROBE
-  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 0] = wall_clock64();
+  if (a.probe && tid == 0) {
+    a.probe[blockIdx.x * 8 + 0] = wall_clock64();
+    // HW_REG_LDS_ALLOC (hwreg 6): LDS_BASE in its low bits -- non-zero = this workgroup's LDS block sits above
+    // another one's, i.e. it was placed second on its CU
+    a.probe[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    a.probe[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+  }
 #endif
 
   // staging: thread -> (tile row tid/4, 4 consecutive k starting at (tid&3)*4) of A and of Bt
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   store_tiles(R0, 0, 0);
   __syncthreads();
 #ifdef BJX_DENSE_PROBE
-  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 1] = wall_clock64();
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 1] = wall_clock64();
 #endif
   const int lm = lane & 31, lk = lane >> 5;
   const int a_off = (wm * 64 + lm) * LDK + lk * 8;
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
     tile(t + 1, R0, R1);
   }
 #ifdef BJX_DENSE_PROBE
-  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 2] = wall_clock64();
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 2] = wall_clock64();
 #endif
 
   // epilogue: each wave transposes its two 32 x 32 accumulator tiles through its private 4 KiB slice
@@ -688,7 +694,7 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
 #ifdef BJX_DENSE_PROBE
   __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stamp follows the last store's acknowledgement
   __syncthreads();
-  if (a.probe && tid == 0) a.probe[blockIdx.x * 4 + 3] = wall_clock64();
+  if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 3] = wall_clock64();
 #endif
 }
 

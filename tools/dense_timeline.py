@@ -21,7 +21,7 @@ cov = (0.9 ** (idx[:, None] - idx[None, :]).abs().float()).contiguous()
 q, p, gr = (torch.randn(N, D, device=dev, generator=g) for _ in range(3))
 q2, p2, v = torch.empty_like(q), torch.empty_like(p), torch.empty_like(p)
 n_wg = (N // 128) * (D // 128)
-stamps = torch.zeros(n_wg * 4, dtype=torch.int64, device=dev)
+stamps = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 lib.bjx_dense_probe_set.argtypes = [ctypes.c_void_p]
@@ -44,7 +44,8 @@ def stats(x):
             "p90": float(np.percentile(x, 90)), "max": float(x.max())}
 
 
-out = {"clock": "wall_clock64 (100 MHz); all figures in microseconds; 512 workgroups, two per CU, one round",
+import os
+out = {"BJX_DENSE_FAIR": os.environ.get("BJX_DENSE_FAIR", "unset"), "clock": "wall_clock64 (100 MHz); all figures in microseconds; 512 workgroups, two per CU, one round",
        "stamps": ["entry", "first K-tile staged (after the first barrier)", "end of main loop", "end (stores acknowledged)"]}
 for name, fn in (("fused_tn8<EPI_DRIFT,2>", fused), ("plain_tn8<EPI_STORE,0>", plain)):
     runs = []
@@ -59,14 +60,20 @@ for name, fn in (("fused_tn8<EPI_DRIFT,2>", fused), ("plain_tn8<EPI_STORE,0>", p
         fn()
         e1.record()
         torch.cuda.synchronize()
-        t = stamps.cpu().numpy().reshape(n_wg, 4)
+        raw = stamps.cpu().numpy().reshape(n_wg, 8)
+        t = raw[:, :4]
+        second = (raw[:, 4] & 0xFFF) != 0
         t0 = t[:, 0].min()
         runs.append({"event_us": e0.elapsed_time(e1) * 1e3,
                      "span_first_entry_to_last_end": float(t[:, 3].max() - t0) / 100.0,
                      "entry_skew": stats(t[:, 0] - t0), "prologue": stats(t[:, 1] - t[:, 0]),
                      "main_loop": stats(t[:, 2] - t[:, 1]), "epilogue": stats(t[:, 3] - t[:, 2]),
                      "main_loop_end_skew": stats(t[:, 2] - t[:, 2].min()),
-                     "end_skew": stats(t[:, 3].max() - t[:, 3])})
+                     "end_skew": stats(t[:, 3].max() - t[:, 3]),
+                     "placed_second_workgroups": int(second.sum()),
+                     "lds_alloc_values": sorted(set(int(x) for x in raw[:, 4]))[:8],
+                     "main_loop_placed_first": stats((t[:, 2] - t[:, 1])[~second]) if (~second).any() else None,
+                     "main_loop_placed_second": stats((t[:, 2] - t[:, 1])[second]) if second.any() else None})
     lib.bjx_dense_probe_set(None)
     runs.sort(key=lambda r: r["span_first_entry_to_last_end"])
     out[name] = {"median_run": runs[len(runs) // 2], "spans_us": [r["span_first_entry_to_last_end"] for r in runs]}
