@@ -591,6 +591,9 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
   const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
+  const int lm = lane & 31, lk = lane >> 5;
+  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
+  const int b_off = (wn * 32 + lm) * LDK + lk * 8;
   load_tiles(R0, 0);
   load_tiles(R1, BK);
   store_tiles(R0, 0, 0);
@@ -598,9 +601,6 @@ __global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
 #ifdef BJX_DENSE_PROBE
   if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 1] = wall_clock64();
 #endif
-  const int lm = lane & 31, lk = lane >> 5;
-  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
-  const int b_off = (wn * 32 + lm) * LDK + lk * 8;
   auto tile = [&](int64_t t, Regs& stage, Regs& refill) {
     const int buf = (int)(t & 1);
     const float* as = As0 + buf * BM * LDK + a_off;

@@ -3135,10 +3135,10 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
   const bool all_vec4 = nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm);
   const int ni2 = all_vec4 ? nuts_resident_ni(nuts, qf, gf) : 0;
   if (use_v2 && ni2 == 0 && all_vec4 && nuts->D <= 1024 && leaf3_env >= 128 &&
-      run->target_kind == BJX_TARGET_NONE && run->rec && run->front_p && run->int_stages <= 1) {
+      run->target_kind == BJX_TARGET_NONE && run->rec && run->front_p) {
     // rows of 513 .. 1 024 floats (three / four 16-byte pieces per lane): only the lean tick kernel with deferred
     // transition ends exists for them -- one launch per tick at every batch size (round 4; before: the round-1
-    // general sweeps).  Velocity Verlet only.
+    // general sweeps).  Multi-stage integrators too (round 5: a leaf lasts K ticks, as for narrower rows).
     const dim3 g1((unsigned)run->n_rows);
     if (nuts->D <= 768) hipLaunchKernelGGL((k_nuts_async_tick3<64, 3, 2, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
     else hipLaunchKernelGGL((k_nuts_async_tick3<64, 4, 2, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);

@@ -193,7 +193,8 @@ def test_dynamic_hmc_general_integrator_dense_metric(dev):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("N,D,key_layout", [(40, 64, "step_major"), (300, 256, "chain_major"), (25, 132, "step_major")])
+@pytest.mark.parametrize("N,D,key_layout", [(40, 64, "step_major"), (300, 256, "chain_major"), (25, 132, "step_major"),
+                                            (36, 1024, "step_major"), (70, 640, "chain_major")])
 def test_nuts_free_running_with_a_multi_stage_integrator(dev, name, N, D, key_layout):
     """Round 4: ``run`` with mclachlan / yoshida / omelyan stays on the FREE-RUNNING tick kernels (a leaf lasts
     K ticks: K - 1 middle stages + the closing tick, ``bjx_nuts_async_t.int_stages``) instead of degrading to
@@ -241,18 +242,20 @@ def test_where_general_integrators_are_not_available():
     with pytest.raises(NotImplementedError):
         bjx.hmc.build_kernel(object())
     # (mhmc / dmhmc with dense metrics take them since round 4: tests/test_frows_dense_gpu.py)
-    # free-running NUTS ticks: diagonal metric, 16-byte rows of at most 512 floats -- a wider row is refused by
-    # run_free itself (nuts(...).run then takes lockstep steps instead)
+    # free-running NUTS ticks: diagonal metric, 16-byte rows of at most 1 024 floats (round 5; 512 before) -- a wider
+    # row is refused by run_free itself (nuts(...).run then takes lockstep steps instead, with a warning)
     from blackjax_amd.nuts import free_running_supports, run_free
 
-    assert not free_running_supports(bjx.integrators.mclachlan, "diag", 516)
+    assert not free_running_supports(bjx.integrators.mclachlan, "diag", 1028)
+    assert free_running_supports(bjx.integrators.yoshida, "diag", 1024)
     assert not free_running_supports(bjx.integrators.mclachlan, "dense", 64)
-    D = 516
+    D = 1028
     alg = bjx.nuts(bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), integrator=bjx.integrators.mclachlan,
                    max_num_doublings=3)
     st = alg.init(0.1 * torch.ones(5, D, device="cuda"))
     with pytest.raises(NotImplementedError):
         run_free(bjx.random.key(0), st, bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), 2, 3,
                  integrator=bjx.integrators.mclachlan)
-    final, pos, info = alg.run(bjx.random.key(0), st, 2)  # falls back to lockstep steps
+    with pytest.warns(RuntimeWarning, match="lockstep"):  # never degrade silently
+        final, pos, info = alg.run(bjx.random.key(0), st, 2)  # falls back to lockstep steps
     assert pos.shape == (2, 5, D)
