@@ -767,6 +767,47 @@ def bench_c2(args, ctx):
         torch_pair_mode = torch_line(mp, k_t, "torch_pair",
                                      "g = -(q * inv_var); lp = 0.5 * (q * g).sum(-1); return lp, g  (no autograd)", 32)
 
+    # ---- the same plain-PyTorch log-density, (a) traced by blackjax_amd.targets.from_elementwise (torch.fx ->
+    # forward-mode derivative -> ONE hiprtc-compiled value-and-gradient kernel, an external callable: 8 B per element),
+    # (b) wrapped in torch.compile (Inductor, if it works on this image) -- what a PyTorch user can do about the
+    # autograd line above without writing HIP
+    torch_elementwise_mode = torch_compile_mode = None
+    if extras and not args.no_torch_callable:
+        k_t = max(2, args.steps // 4)
+        try:
+            t_c = time.perf_counter()
+            ew_fn = bjx.targets.from_elementwise(torch_logdensity, D, device=dev)
+            lp_e, g_e = ew_fn(q_init[:256])
+            qa = q_init[:256].detach().clone().requires_grad_(True)
+            lp_a = torch_logdensity(qa)
+            (g_a,) = torch.autograd.grad(lp_a.sum(), qa)
+            t_c = time.perf_counter() - t_c
+            me = measure(blk_auto, False, False, steps=k_t, fn=ew_fn, timing=False)
+            torch_elementwise_mode = torch_line(
+                me, k_t, "torch_elementwise",
+                "blackjax_amd.targets.from_elementwise(lambda q: -0.5 * (q * q * inv_var).sum(-1), D): the SAME "
+                "PyTorch function, traced with torch.fx into one generated HIP value-and-gradient kernel (hiprtc), "
+                "called as an external callable between two leapfrogs", 8)
+            torch_elementwise_mode.update({
+                "generated": ew_fn.elementwise.description, "trace_compile_first_call_s": t_c,
+                "max_rel_dgrad_vs_autograd": float(((g_e - g_a).abs() / g_a.abs().clamp_min(1e-30)).max()),
+                "max_rel_dlogp_vs_autograd": float(((lp_e - lp_a.detach()).abs() / lp_a.detach().abs().clamp_min(1e-30)).max())})
+        except Exception as e:
+            torch_elementwise_mode = {"value": None, "error": repr(e)[:300]}
+        try:
+            t_c = time.perf_counter()
+            compiled_pair = torch.compile(torch_pair, dynamic=False)
+            bjx.returns_pair(compiled_pair)
+            compiled_pair(q_init[:blk_auto])  # compile for the block shape the engine will call it with
+            torch.cuda.synchronize()
+            t_c = time.perf_counter() - t_c
+            mc = measure(blk_auto, False, False, steps=k_t, fn=compiled_pair, timing=False)
+            torch_compile_mode = torch_line(mc, k_t, "torch_compile",
+                                            "torch.compile(pair) with pair = the torch_pair_mode function (Inductor)", 12)
+            torch_compile_mode["compile_s"] = t_c
+        except Exception as e:  # Inductor needs a working Triton for gfx950 on this image: report, do not fail
+            torch_compile_mode = {"value": None, "error": repr(e)[:300]}
+
     # ---- what the external-callable contract costs: the same C2 transition with the built-in Gaussian evaluated
     # INSIDE one launch per transition (hmc(..., fuse_target="lean"): engine-resident target, results bit for bit
     # those of the headline path, tests/test_hmc_traj_gpu.py).  NOT the contract, NOT `value`: a labelled line.
@@ -859,6 +900,8 @@ def bench_c2(args, ctx):
         "torch_callable_mode": torch_mode,
         "torch_callable_graph_mode": torch_graph_mode,
         "torch_pair_mode": torch_pair_mode,
+        "torch_elementwise_mode": torch_elementwise_mode,
+        "torch_compile_mode": torch_compile_mode,
         "engine_resident_target_mode": resident_mode,
         "roofline": roofline,
         "parity": parity,

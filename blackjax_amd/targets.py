@@ -171,3 +171,13 @@ class DeviceTarget(_Target):
                              ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(logp.data_ptr()),
                              ctypes.c_void_p(g.data_ptr()))
         return logp, g
+
+
+def from_elementwise(fn, dim: int, device="cuda") -> DeviceTarget:
+    """A plain PyTorch log-density of the element-wise + row-sum shape -> ONE generated HIP value-and-gradient kernel
+    (``blackjax_amd.elementwise``: torch.fx trace, forward-mode derivative, hiprtc), returned as a ``DeviceTarget``:
+    an ordinary external callable ``f(q) -> (logp, grad)`` that moves 8 bytes per element instead of autograd's 50-80.
+    The reference gets this fusion from ``jax.value_and_grad`` under XLA (mcmc/integrators.py:189,204)."""
+    from .elementwise import from_elementwise as _f
+
+    return _f(fn, dim, device)

@@ -143,3 +143,27 @@ def test_staged_adaptation_engine_entry_and_schedule_fn(dev):
     np.testing.assert_allclose(t2n(p_c["inverse_mass_matrix"]), par_o["inverse_mass_matrix"], rtol=1e-6)
     np.testing.assert_allclose(t2n(s_c.position), st_o.position, rtol=1e-6, atol=1e-6)
     assert not torch.equal(p_c["inverse_mass_matrix"], p_w["inverse_mass_matrix"])  # the schedule mattered
+
+
+def test_default_info_keeps_scalars_at_scale_and_in_place_welford_is_bit_identical(dev):
+    """at 2 048 x 4 096 one step of ``return_all_adapt_info`` would hold ~0.34 GiB, so the
+    DEFAULT adaptation_info_fn keeps the per-chain scalars only (one-time RuntimeWarning) and the Welford buffers are
+    updated in place; the adapted parameters and final state are bit for bit those of a run that keeps everything
+    explicitly (fresh Welford tensors every slow step).  Mirrors staged_adaptation.py:731-754 / adaptation/base.py:32-36."""
+    N, D, T = 2048, 4096, 24  # the 24-step schedule has a slow window and its end
+    sig = torch.as_tensor((10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32), device=dev)
+    tgt = bjx.targets.DiagGaussian((1.0 / (sig * sig)).contiguous())
+    q0 = torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    bad._WARNED_INFO[0] = False
+    with pytest.warns(RuntimeWarning, match="per-chain scalars"):
+        (st_a, par_a), hist_a = bjx.window_adaptation(bjx.hmc, tgt, num_integration_steps=3).run(bjx.random.key(3), q0, T)
+    assert hist_a.state.position is None and hist_a.info.momentum is None
+    assert hist_a.adaptation_state.imm_state is None or hist_a.adaptation_state.imm_state.wc_state.mean is None
+    assert tuple(hist_a.info.acceptance_rate.shape) == (T, N) and tuple(hist_a.adaptation_state.step_size.shape) == (T, N)
+    keep_all = bjx.window_adaptation(bjx.hmc, tgt, num_integration_steps=3,
+                                     adaptation_info_fn=bad.get_filter_adapt_info_fn(adapt_state_keys={"imm_state"}))
+    (st_b, par_b), hist_b = keep_all.run(bjx.random.key(3), q0, T)  # retains the Welford state: NOT in place
+    assert torch.equal(par_a["step_size"], par_b["step_size"])
+    assert torch.equal(torch.as_tensor(par_a["inverse_mass_matrix"]), torch.as_tensor(par_b["inverse_mass_matrix"]))
+    assert torch.equal(st_a.position, st_b.position)
+    assert float(torch.as_tensor(par_a["inverse_mass_matrix"]).std()) > 0  # the window end did update the metric
