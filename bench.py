@@ -258,7 +258,7 @@ def parity_c5(bjx, dev, rank, alg, state, N, D, L, eps, rho):
     m = bjx.metrics.default_metric(torch.as_tensor(cov, device=dev), N, D, dev)
     mass_sqrt = np.ascontiguousarray(m.mass_sqrt_t.cpu().numpy().T)
     own = ohmc.default_metric(cov).mass_matrix_sqrt
-    factor_rel = float(np.max(np.abs(mass_sqrt - own) / np.maximum(np.abs(own), 1e-30)))
+    factor_abs = float(np.max(np.abs(mass_sqrt - own)))  # (relative to the largest entry: the factor is banded, most entries ~ 0)
     metric = ohmc.default_metric(cov, dense_accum="f32chain", mass_matrix_sqrt=mass_sqrt)
     st_s = ohmc.HMCState(state.position[t].cpu().numpy().copy(), state.logdensity[t].cpu().numpy().copy(),
                          state.logdensity_grad[t].cpu().numpy().copy())
@@ -279,7 +279,7 @@ def parity_c5(bjx, dev, rank, alg, state, N, D, L, eps, rho):
             "max_abs_dmomentum_draw": float(np.max(np.abs(info.momentum[t].cpu().numpy() - info_s.momentum))),
             "max_abs_dpos": float(np.max(np.abs(pos_g - st_s.position))),
             "max_abs_dmean": dmean, "max_abs_dvar": dvar,
-            "factor_max_rel_diff_vs_oracle_own_cholesky": factor_rel,
+            "factor_max_abs_diff_vs_oracle_own_cholesky": factor_abs, "factor_max_abs_entry": float(np.max(np.abs(own))),
             "rejected_among_checked": int(np.sum(~info_s.is_accepted)), "seconds": time.perf_counter() - t0}
 
 
@@ -1088,7 +1088,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         return None
     peak_rate = HBM_PEAK_GBS * 1e9 / (52.0 * D)  # chain-leapfrogs/s per GPU at 52 B per element
     roofline = {
-        "bound": "hbm", "kernel": "k_nuts_async_tick3<64,1,W,DEFER> (leaf + deferred transition ends, one launch per tick) + funnel callable, whole run",
+        "bound": "hbm", "kernel": "k_nuts_async_tick3<NI=1, W=4> (leaf + deferred transition ends, one launch per tick) + funnel callable, whole run",
         "achieved": value / world * 52.0 * D / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": value / world / peak_rate, "traffic": None,
         "algorithmic_bytes_per_chain_leapfrog": 52.0 * D,

@@ -62,8 +62,12 @@ def _scalars_only_adapt_info(state, info, adaptation_state):
     ``state.logdensity``, the (N,) fields of ``info`` (acceptance rate, accept / divergence flags, energy, step
     counts), the dual-averaging state and the step size -- and none of the (N, D) tensors."""
 
-    def small(t):
-        return t if not (isinstance(t, torch.Tensor) and t.ndim >= 2) else None
+    n = state.position.shape[0]
+
+    def small(t):  # per-chain scalars: (N,) tensors (and Python scalars); the shared (D,) initial metric is dropped too
+        if isinstance(t, torch.Tensor):
+            return t if (t.ndim == 0 or (t.ndim == 1 and t.shape[0] == n)) else None
+        return t
 
     def filt(tup):
         if tup is None:
@@ -245,7 +249,7 @@ def _stack_history(history):
         if first is None:
             return None
         if isinstance(first, torch.Tensor):
-            if any(it.shape != first.shape for it in items):
+            if any(not isinstance(it, torch.Tensor) or it.shape != first.shape for it in items):
                 return items  # e.g. the shared (D,) initial imm vs the per-chain (N, D) adapted ones
             return torch.stack(items)
         if isinstance(first, tuple) and hasattr(first, "_fields"):

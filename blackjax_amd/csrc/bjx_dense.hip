@@ -327,181 +327,13 @@ __global__ void __launch_bounds__(kThreads) k_dense_gemm(GemmArgs a) {
 // free at stride 20) instead of eight ds_read_b32.  Per K-tile and wave: 8 LDS reads feed 32 MFMAs.
 constexpr int LDK = BK + 4;
 
-template <int EPI, int KICKS>
-__global__ void __launch_bounds__(kThreads) k_dense_gemm_tn(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
-  static_assert(2 * BM * LDK + 2 * BN * LDK >= 4 * 32 * 64, "epilogue staging needs 32 KiB");
-  static_assert(BK == 16, "the k pairing below assumes two 8-wide halves");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t n_col = a.D / BN, n_row = a.M / BM;
-  const int64_t lin = blockIdx.x;
-  int64_t row_blk, col_blk;
-  {  // XCD-aware tile order, as in k_dense_gemm
-    const int64_t full = (n_row / 8) * 8 * n_col;
-    if (lin < full) {
-      const int64_t xcd = lin % 8, slot = lin / 8;
-      col_blk = slot % n_col;
-      row_blk = (slot / n_col) * 8 + xcd;
-    } else {
-      const int64_t r = lin - full;
-      row_blk = (n_row / 8) * 8 + r / n_col;
-      col_blk = r % n_col;
-    }
-  }
-  const int64_t row0 = row_blk * BM, col0 = col_blk * BN, D = a.D;
-  float* As0 = smem;
-  float* Bs0 = smem + 2 * BM * LDK;
-
-  // staging: thread -> (tile row tid/2, 8 consecutive k starting at (tid&1)*8) of A and of Bt
-  const int s_row = tid >> 1, s_k = (tid & 1) * 8;
-  const float* a_src = a.A + (row0 + s_row) * D + s_k;
-  const float* g_src = KICKS > 0 ? a.G + (row0 + s_row) * D + s_k : nullptr;
-  const float* b_src = a.B + (col0 + s_row) * D + s_k;
-  // The kicked operand p' is an output (A_out).  Every column block of a row block stages the same
-  // A rows, so the store is shared out: column block c writes the k range [c*BN, (c+1)*BN) -- one
-  // quarter of the K-tiles each at D = 512 instead of all of them in column block 0, whose
-  // store drains then made its row's slowest workgroup.
-  float* a_out = (KICKS > 0 && a.A_out) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
-  float ha = 0.0f, hb = 0.0f;
-  bool kick_row = true;
-  if (KICKS > 0) {
-    const float e = a.eps_pc ? a.eps_pc[row0 + s_row] : a.eps;
-    ha = e * a.kick_a;
-    hb = e * a.kick_b;
-    kick_row = gemm_row_active(a, row0 + s_row);
-  }
-  // Software pipeline over K-tiles with two register sets (loop unrolled by two so the set index
-  // is static).  In iteration t, in program order:
-  //   LDS operand reads of tile t, first half of its MFMAs           (matrix pipe now busy)
-  //   staging of tile t+1 from set (t+1)&1: kick, A_out store, LDS store   (in the MFMA shadow;
-  //       its global loads were issued one iteration ago)
-  //   issue the global loads of tile t+2 into set t&1 (whose A_out store is one iteration old)
-  //   second half of the MFMAs, workgroup barrier
-  // Loads and stores share one in-order counter that the compiler must drain completely once
-  // stores are in flight, so the loads are issued AFTER the stores of the same iteration and the
-  // only full drain sits where everything outstanding is a full iteration old.
-  struct Regs {
-    F4 a[2], g[2], b[2];
-  };
-  Regs R0, R1;
-  auto load_tiles = [&](Regs& r, int64_t k0) {
-    r.a[0] = ld4(a_src + k0); r.a[1] = ld4(a_src + k0 + 4);
-    if constexpr (KICKS > 0) { r.g[0] = ld4(g_src + k0); r.g[1] = ld4(g_src + k0 + 4); }
-    r.b[0] = ld4(b_src + k0); r.b[1] = ld4(b_src + k0 + 4);
-  };
-  auto kick = [&](F4& x, const F4& g, float h) {
-    x.x = fmaf(h, g.x, x.x); x.y = fmaf(h, g.y, x.y); x.z = fmaf(h, g.z, x.z); x.w = fmaf(h, g.w, x.w);
-  };
-  auto store_tiles = [&](Regs& r, int buf, int64_t k0) {
-    if constexpr (KICKS > 0) {
-      if (kick_row) {
-        kick(r.a[0], r.g[0], ha); kick(r.a[1], r.g[1], ha);
-        if constexpr (KICKS == 2) { kick(r.a[0], r.g[0], hb); kick(r.a[1], r.g[1], hb); }
-      }
-      if (a_out && k0 / BN == col_blk) { st4(a_out + k0, r.a[0]); st4(a_out + k0 + 4, r.a[1]); }
-    }
-    float* as = As0 + buf * BM * LDK + s_row * LDK + s_k;
-    float* bs = Bs0 + buf * BN * LDK + s_row * LDK + s_k;
-    st4(as, r.a[0]); st4(as + 4, r.a[1]);
-    st4(bs, r.b[0]); st4(bs + 4, r.b[1]);
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
-  load_tiles(R0, 0);
-  load_tiles(R1, BK);
-  store_tiles(R0, 0, 0);
-  __syncthreads();
-  const int lm = lane & 31, lk = lane >> 5;
-  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
-  const int b_off = (wn * 64 + lm) * LDK + lk * 8;
-  auto mfma4 = [&](float x0, float x1, float y0, float y1) {
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
-  };
-  // tile t: `stage` holds tile t+1 (in flight), `refill` is the set whose contents (tile t) are
-  // already in LDS and which receives tile t+2
-  auto tile = [&](int64_t t, Regs& stage, Regs& refill) {
-    const int buf = (int)(t & 1);
-    const float* as = As0 + buf * BM * LDK + a_off;
-    const float* bs = Bs0 + buf * BN * LDK + b_off;
-    float fa0[8], fa1[8], fb0[8], fb1[8];
-    *reinterpret_cast<F4*>(fa0) = ld4(as);                 *reinterpret_cast<F4*>(fa0 + 4) = ld4(as + 4);
-    *reinterpret_cast<F4*>(fb0) = ld4(bs);                 *reinterpret_cast<F4*>(fb0 + 4) = ld4(bs + 4);
-    *reinterpret_cast<F4*>(fa1) = ld4(as + 32 * LDK);      *reinterpret_cast<F4*>(fa1 + 4) = ld4(as + 32 * LDK + 4);
-    *reinterpret_cast<F4*>(fb1) = ld4(bs + 32 * LDK);      *reinterpret_cast<F4*>(fb1 + 4) = ld4(bs + 32 * LDK + 4);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) mfma4(fa0[u], fa1[u], fb0[u], fb1[u]);
-    __builtin_amdgcn_sched_barrier(0);  // keep the staging work here, behind 16 queued MFMAs
-    if (t + 1 < n_tiles) store_tiles(stage, buf ^ 1, (t + 1) * BK);
-    if (t + 2 < n_tiles) load_tiles(refill, (t + 2) * BK);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 4; u < 8; ++u) mfma4(fa0[u], fa1[u], fb0[u], fb1[u]);
-    __syncthreads();
-  };
-  for (int64_t t = 0; t < n_tiles; t += 2) {
-    tile(t, R1, R0);
-    tile(t + 1, R0, R1);
-  }
-
-  // epilogue: identical to the ALIGNED && FULL path of k_dense_gemm (LDS transpose, 16-byte rows)
-  float* stage = smem + wave * (32 * 64);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stage[(bq * 8 + lk * 4 + r) * 64 + j * 32 + lm] = acc[i][j][bq * 4 + r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int c4 = (lane & 15) * 4;
-    const int64_t col = col0 + wn * 64 + c4;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rl = (lane >> 4) + 4 * it;
-      const int64_t row = row0 + wm * 64 + i * 32 + rl;
-      const F4 c = *reinterpret_cast<const F4*>(stage + rl * 64 + c4);
-      if constexpr (EPI == EPI_STORE) {
-        st4(a.C + row * D + col, c);
-      } else {
-        const float e = (a.eps_pc ? a.eps_pc[row] : a.eps) * a.drift;
-        const F4 q = ld4(a.Q_in + row * D + col);
-        if (gemm_row_active(a, row))
-          st4(a.Q_out + row * D + col,
-              F4{fmaf(e, c.x, q.x), fmaf(e, c.y, q.y), fmaf(e, c.z, q.z), fmaf(e, c.w, q.w)});
-        else
-          st4(a.Q_out + row * D + col, q);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// The same "TN" tile (128 x 128 block tile, K-tile 16, row-major LDS tiles of stride 20) computed by
-// EIGHT waves (512 threads, 2 x 4 waves of 64 x 32) instead of four of 64 x 64: the global traffic,
-// the LDS footprint and the summation order are unchanged, but a CU now holds 16 waves -- four per
-// SIMD -- so the matrix pipe finds an MFMA to issue while other waves wait on LDS reads, on the
-// staging stores or at the K-tile barrier (with two waves per SIMD the pipe was busy 61 % of a
-// launch).  Per wave and K-tile: 6 ds_read_b128 feed 16 MFMAs on two independent accumulators.
+// The "TN" kernel: 128 x 128 block tile, K-tile 16, row-major LDS tiles of stride 20, computed by EIGHT waves
+// (512 threads, 2 x 4 waves of 64 x 32).  A CU holds two workgroups = 16 waves, four per SIMD, so the matrix pipe
+// finds an MFMA to issue while other waves wait on LDS reads, on the staging stores or at the K-tile barrier.
+// Per wave and K-tile: 6 ds_read_b128 feed 16 MFMAs on two independent accumulators.  (Rounds 1-4 also carried a
+// four-wave form of this tile -- 64 x 64 per wave, 172 VGPRs, two waves per SIMD, 2 % slower -- behind BJX_DENSE_TN8=0;
+// removed in round 5.)
 constexpr int kThreads8 = 512;
 
 template <int EPI, int KICKS>
@@ -1074,15 +906,10 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
     return 1;
   }
   if (ga.b_symmetric && aligned && full) {
-    static const bool tn8 = [] { const char* e = getenv("BJX_DENSE_TN8"); return e ? atoi(e) != 0 : true; }();
 #ifdef BJX_DENSE_PROBE
     ga.probe = g_probe_buf;
 #endif
-#define BJX_LAUNCH_TN(E, K)                                                                   \
-  do {                                                                                        \
-    if (tn8) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga); \
-    else hipLaunchKernelGGL((k_dense_gemm_tn<E, K>), grid, dim3(kThreads), 0, s, ga);         \
-  } while (0)
+#define BJX_LAUNCH_TN(E, K) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga)
     int kicks = ga.G ? ga.n_kicks : 0;
 #ifdef BJX_DENSE_PROBE
     // BJX_DENSE_ABLATE (measurement aid, RESULTS INVALID -- compiled only into PROBE builds, `make

@@ -905,14 +905,9 @@ __device__ __forceinline__ StepCtx async_ctx(const bjx_nuts_t& nt, const bjx_nut
   return cx;
 }
 
-// Work distribution of the free-running kernels.  Default (GROUPED = false): one wave per compact row;
-// a wave whose chain has no work in this kernel exits after two loads.  GROUPED = true
-// (BJX_NUTS_GROUPED=1, kept for comparison): a wave owns kAsyncGroup consecutive rows, finds the ones
-// with work by one coalesced load + ballot and works them off one after the other -- cheap when
-// nearly every chain is finished, but the live chains of a group are then serialised behind one wave
-// while the rest of the chip idles, which is exactly the tail of a run (C3: 87 -> 101 M/s from
-// dropping the groups in the tail alone).
-constexpr int kAsyncGroup = 8;
+// Work distribution of the general free-running kernels: one wave per compact row; a wave whose chain has no work
+// in this kernel exits after two loads.  (A grouped form -- one wave working off eight consecutive rows -- serialised
+// the live chains of a group in the tail of a run and was dropped: C3 87 -> 101 M/s, NOTEBOOK.md section 7.)
 // occupancy hint of the fused tick kernel: 3 waves per SIMD (168 VGPRs); 4 forces 140 B of spills
 // per lane and measured slower (C3: 101 vs 108 M/s)
 #ifndef BJX_FUSED_WAVES
@@ -928,35 +923,14 @@ __device__ __forceinline__ int64_t async_n_rows(const bjx_nuts_async_t& ax) {
 }
 
 // f(chain, compact row, phase) for every chain of the compact rows whose phase is want_a or want_b
-template <bool GROUPED = true, class F>
-__device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax, int want_a, int want_b,
-                                                     F f) {
-  const int lane = threadIdx.x & 63;
-  if constexpr (!GROUPED) {
-    const int64_t n_rows = async_n_rows(ax);
-    for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
-      const int chain = ax.rows ? ax.rows[b] : (int)b;
-      const int ph = ax.phase[chain];
-      if (ph == want_a || ph == want_b)
-        f((int64_t)__builtin_amdgcn_readfirstlane(chain), b, __builtin_amdgcn_readfirstlane(ph));
-    }
-    return;
-  }
-  const int64_t n_rows_g = async_n_rows(ax);
-  const int64_t n_groups = (n_rows_g + kAsyncGroup - 1) / kAsyncGroup;
-  for (int64_t grp = wave_row0(); grp < n_groups; grp += wave_row_stride()) {
-    const int64_t b0 = grp * kAsyncGroup;
-    int chain = -1, ph = -1;
-    if (lane < kAsyncGroup && b0 + lane < n_rows_g) {
-      chain = ax.rows ? ax.rows[b0 + lane] : (int)(b0 + lane);
-      ph = ax.phase[chain];
-    }
-    unsigned long long m = __ballot(ph == want_a || ph == want_b);
-    while (m) {
-      const int l = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      f((int64_t)__builtin_amdgcn_readlane(chain, l), b0 + l, __builtin_amdgcn_readlane(ph, l));
-    }
+template <class F>
+__device__ __forceinline__ void async_for_each_chain(const bjx_nuts_async_t& ax, int want_a, int want_b, F f) {
+  const int64_t n_rows = async_n_rows(ax);
+  for (int64_t b = wave_row0(); b < n_rows; b += wave_row_stride()) {
+    const int chain = ax.rows ? ax.rows[b] : (int)b;
+    const int ph = ax.phase[chain];
+    if (ph == want_a || ph == want_b)
+      f((int64_t)__builtin_amdgcn_readfirstlane(chain), b, __builtin_amdgcn_readfirstlane(ph));
   }
 }
 
@@ -980,20 +954,6 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
   else stop = nuts_post_chain<VEC, DENSE>(nt, cx, c, b, depth, s, qf, logp_f, gf, !last);
   if ((stop || last) && lane == 0) ax.phase[c] = 3;
   return stop || last;
-}
-
-// occupancy hint of the leaf kernel (122 VGPRs): A/B on one box at C3 -- 3: 111.2, 4: 110.7, 5 (84 B of
-// spills): 98.7, 6 (148 B): 88.5 M/s
-#ifndef BJX_LEAF_WAVES
-#define BJX_LEAF_WAVES 4
-#endif
-template <int VEC, int NI, bool GROUPED>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_LEAF_WAVES)))
-k_nuts_async_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
-                  const float* __restrict__ gf) {
-  async_for_each_chain<GROUPED>(ax, 1, 1, [&](int64_t c, int64_t b, int) {
-    async_leaf_chain<VEC, NI>(nt, ax, qf, logp_f, gf, c, b);
-  });
 }
 
 // Per-chain window adaptation at the end of transition t (include/bjx_nuts.h, adapt_* fields): the
@@ -1181,22 +1141,15 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
   }
 }
 
-template <int VEC, bool GROUPED>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
-k_nuts_async_boundary(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf) {
-  async_for_each_chain<GROUPED>(ax, 3, 0, [&](int64_t c, int64_t b, int phase) {
-    async_boundary_chain<VEC>(nt, ax, qf, c, b, phase);
-  });
-}
-
-// Both parts in one launch, for ticks with few live chains (the long tail of a run, where a tick is
-// bound by its dependent launches, not by the work): leaf, then -- same wave, after a fence -- the
-// boundary work the leaf may have produced.
+// The GENERAL free-running tick (every metric, every row width, 4-byte sweeps when D % 4 != 0 or a buffer is not
+// 16-byte aligned): leaf, then -- same wave, after a fence -- the transition end the leaf may have produced, in ONE
+// launch.  Diagonal metrics with 16-byte rows of at most 1 024 floats take k_nuts_async_tick3 instead.  (Round 5:
+// the round-1 two-launch form of this tick -- k_nuts_async_leaf + k_nuts_async_boundary -- is gone.)
 template <int VEC, int NI, bool DENSE = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(BJX_FUSED_WAVES)))
 k_nuts_async_fused(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
-  async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
+  async_for_each_chain(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
     if (phase == 1) {
       if (!async_leaf_chain<VEC, NI, DENSE>(nt, ax, qf, logp_f, gf, c, b)) return;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1796,95 +1749,9 @@ __device__ __forceinline__ void async_target_row(const bjx_nuts_t& nt, const bjx
   else diag_gaussian_row<NI>(nt.D, x, ax.target_vec, logp_f + b, gf + b * nt.D);
 }
 
-// One tick of one compact row.  MODE 0: leaf work only (phase 1), 1: transition ends / starts only
-// (phases 3, 0), 2: both in the same wave (one launch per tick).
-#ifndef BJX_LEAF2_WAVES
-#define BJX_LEAF2_WAVES 4
-#endif
-// Returns false when the row's chain has completed all its transitions (nothing left to do for it).
-template <int NI, int MODE, bool TGT = false>
-__device__ __forceinline__ bool async_tick2_row(const bjx_nuts_t& nt, const bjx_nuts_async_t& ax, float* qf,
-                                                const float* __restrict__ logp_f,
-                                                const float* __restrict__ gf, int64_t b) {
-  constexpr int VEC = 4;
-  const int lane = threadIdx.x & 63;
-  const int chain = ax.rows ? ax.rows[b] : (int)b;
-  const int64_t c = (int64_t)__builtin_amdgcn_readfirstlane(chain);
-  // first round trip: the phase, the record and (leaf modes) every row of a leaf, all at once
-  int phase = ax.phase[c];
-  int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
-  int w = recp[lane & (BJX_NUTS_REC_WORDS - 1)];
-  LeafRows<NI> R;
-  float lp = 0.0f;
-  if constexpr (MODE != 1) {
-    const int64_t base = c * nt.D;
-    const float* im = nt.imm + c * nt.imm_stride;
-    lp = logp_f[b];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const uint32_t j = ((uint32_t)lane + 64u * k) * VEC;
-      if (j < (uint32_t)nt.D) {
-        R.G[k] = ldr<VEC>(gf + b * nt.D + j);
-        R.M[k] = ldr<VEC>(im + j);
-        R.P[k] = ldr<VEC>(ax.front_p + base + j);
-        R.X[k] = ldr<VEC>(qf + b * nt.D + j);
-        R.S[k] = ldr<VEC>(nt.Smsum + base + j);
-      }
-    }
-  }
-  phase = __builtin_amdgcn_readfirstlane(phase);
-  const int w_in = w;
-  bool pending = false;  // a new position for the callable was written to qf[b]
-  if (MODE != 1 && phase == 1 && ax.int_stages > 1 && rec_i(w, RW_STAGE) < ax.int_stages - 1) {
-    // a middle stage of a multi-stage integrator (integrators.py:104-150): kick b_i with the gradient just
-    // evaluated, drift a_i -- the leaf's bookkeeping waits for the gradient at the leaf's LAST position
-    const int st = rec_i(w, RW_STAGE);
-    const float deps = (float)rec_i(w, RW_DIR) * rec_f(w, RW_EPS);
-    const float hk = deps * ax.int_mid_kick[st], dk = deps * ax.int_mid_drift[st];
-    const int64_t base = c * nt.D;
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const uint32_t j = ((uint32_t)lane + 64u * k) * VEC;
-      if (j < (uint32_t)nt.D) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          R.P[k].v[e] = fmaf(hk, R.G[k].v[e], R.P[k].v[e]);
-          R.X[k].v[e] = fmaf(dk, R.M[k].v[e] * R.P[k].v[e], R.X[k].v[e]);
-        }
-        str<VEC>(ax.front_p + base + j, R.P[k]);
-        str<VEC>(qf + b * nt.D + j, R.X[k]);
-      }
-    }
-    rec_set_i(w, RW_STAGE, st + 1);
-    pending = true;
-  } else if (MODE != 1 && phase == 1) {
-    rec_set_i(w, RW_STAGE, 0);
-    const int done = async_leaf2_chain<NI>(nt, ax, qf, lp, c, b, w, R);
-    pending = !done;
-    if (MODE == 2 && done) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      pending = async_end2_chain<NI>(nt, ax, qf, c, b, 3, w);
-    }
-    // two-kernel ticks: rows whose transition ended go on the work list of the second kernel
-    if (MODE == 0 && done && ax.end_list && lane == 0)
-      ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
-  } else if (MODE != 0 && (phase == 3 || phase == 0)) {
-    pending = async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
-  } else {
-    if (MODE == 0 && phase == 0 && ax.end_list && lane == 0)  // first tick of a run: every chain starts
-      ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
-    return phase != 2;
-  }
-  if (lane < BJX_NUTS_REC_WORDS && w != w_in) recp[lane] = w;
-  if constexpr (TGT) {  // engine-resident log-density (its own instantiations: the default kernels are untouched)
-    if (pending) async_target_row<NI>(nt, ax, qf, const_cast<float*>(logp_f), const_cast<float*>(gf), b);
-  }
-  return pending || MODE == 0;
-}
-
 // `k_ticks` ticks of one compact row in one launch (engine-resident target).  Only this wave touches the
 // chain during the launch.  A tick whose inputs are not in registers (the first one, the one after a
-// transition end) starts with a workgroup-scope fence and loads everything, exactly like async_tick2_row;
+// transition end) starts with a workgroup-scope fence and loads everything;
 // after a leaf that leaves a new leaf in flight, the next tick's rows are the registers this one holds and
 // its gradient / log-density come straight from the target's registers (the same values are still stored:
 // memory is what the next launch, or the host, sees).
@@ -1991,17 +1858,6 @@ __device__ __forceinline__ void async_multi_tick_row(const bjx_nuts_t& nt, const
 // all its wave slots at once, so with four chains per workgroup a CU slot group lives as long as
 // the slowest of four leaves (a merge + direction change takes several times a plain leaf); these
 // kernels use neither LDS nor barriers, so nothing is lost by launching 64-thread workgroups.
-template <int NI, int MODE, int WAVES, bool TGT = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
-k_nuts_async_tick2(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* logp_f, const float* gf) {
-  if (MODE == 0 && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
-    ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
-  const int64_t n_rows = async_n_rows(ax);
-  for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x) {
-    async_tick2_row<NI, MODE, TGT>(nt, ax, qf, logp_f, gf, b);
-  }
-}
-
 // Engine-resident target, bjx_nuts_async_t.ticks_per_launch > 1: one wave per row, that many ticks each.
 // FULL: D == 256 NI, every lane holds a piece of every row (no per-piece guards: straight-line code).
 template <int NI, int WAVES, bool FULL>
@@ -2010,22 +1866,6 @@ k_nuts_async_multi(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, float* logp_f,
   const int64_t n_rows = async_n_rows(ax);
   for (int64_t b = blockIdx.x; b < n_rows; b += gridDim.x)
     async_multi_tick_row<NI, FULL>(nt, ax, qf, logp_f, gf, b, ax.ticks_per_launch);
-}
-
-// Second kernel of a two-kernel tick over the WORK LIST the first one wrote (rows whose transition
-// ended, or -- first tick -- starts): one in eighteen chains at C3, so scanning all rows for them
-// costs more than serving them.  Two lists, used alternately (run->tick & 1): the first kernel of
-// tick k appends to list k & 1 and clears the counter of the other one, whose readers (tick k - 1)
-// are done -- no completion counting (2 048 same-address atomics with a returned value cost more
-// than the transition ends themselves: 35 us per tick measured).
-template <int NI, bool TGT = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
-k_nuts_async_end_list(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* logp_f, const float* gf) {
-  const int par = ax.tick & 1;
-  const int n = __builtin_amdgcn_readfirstlane(ax.end_count[par]);
-  const int32_t* list = ax.end_list + (int64_t)par * nt.N;
-  for (int64_t i = wave_row0(); i < n; i += wave_row_stride())
-    async_tick2_row<NI, 1, TGT>(nt, ax, qf, logp_f, gf, (int64_t)__builtin_amdgcn_readfirstlane(list[i]));
 }
 
 // ------------------------------------------------------------------------------------ free-running chains, v3
@@ -2444,27 +2284,27 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
 #undef CI
 #undef CSETF
 
-// Leaf kernel of a two-kernel tick: 64 / GL compact rows per 64-thread workgroup (one wave).
-//   <16, NI>    four chains per wave (rows of at most 64 NI floats); two waves per SIMD (252 VGPRs at NI = 4)
-//   <64, 1>     one chain per wave, the v2 leaf's layout with this function's lower register pressure
-//   DEFER       (GL = 64) no second kernel: a chain whose transition ended in tick k (phase 3) is finished and
-//               restarted by ITS wave of tick k + 1's launch (async_end2_chain) -- the work-list kernel and its
-//               launch boundary disappear from the tick, an ending chain spends one extra tick per transition
-template <int GL, int NI, int WAVES, bool DEFER = false>
+// THE free-running tick of the contract path (diagonal metric, 16-byte rows of at most 256 NI floats): one wave =
+// one 64-thread workgroup per compact row.  A chain with a leaf in flight (phase 1) does its leaf work
+// (async_leaf3_row; a middle stage of a multi-stage integrator is a kick + drift only); a chain whose transition
+// ended in tick k (phase 3), or that has not started (phase 0), is finished and restarted by ITS wave of tick
+// k + 1's launch (async_end2_chain: record, accept, adapt, momentum draw, tree start, first opening half) -- the
+// "deferred transition end": no second kernel and no work list, an ending chain spends one extra tick per
+// transition.  Rounds 2-4 also carried a four-chains-per-wave leaf (GL = 16), a work-list kernel for the ends and
+// the v2 leaf: measured slower (NOTEBOOK.md section 15) and removed in round 5; the lane-group parameter GL of the
+// device functions below is now always 64.
+template <int NI, int WAVES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES)))
 k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                    const float* __restrict__ gf) {
   constexpr int VEC = 4;
-  constexpr int CPW = 64 / GL;  // chains per wave
-  static_assert(!DEFER || GL == 64, "deferred transition ends: one chain per wave");
-  if (!DEFER && ax.end_count && blockIdx.x == 0 && threadIdx.x == 0)
-    ax.end_count[(ax.tick & 1) ^ 1] = 0;  // the other work list: its readers (previous tick) are done
+  constexpr int GL = 64;
   const int64_t n_rows = async_n_rows(ax);
-  const int g = threadIdx.x & (GL - 1);
-  const int64_t b = (int64_t)blockIdx.x * CPW + (threadIdx.x / GL);
-  if (b >= n_rows) return;  // uniform within a chain's lanes
+  const int g = threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x;
+  if (b >= n_rows) return;
   int64_t c = ax.rows ? (int64_t)ax.rows[b] : b;
-  if constexpr (GL == 64) c = (int64_t)__builtin_amdgcn_readfirstlane((int)c);
+  c = (int64_t)__builtin_amdgcn_readfirstlane((int)c);
   // first round trip: the phase, the record and every row of a leaf, all at once
   int phase = ax.phase[c];
   int* recp = ax.rec + c * BJX_NUTS_REC_WORDS;
@@ -2491,12 +2331,11 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
       R.S[k] = ldr<VEC>(nt.Smsum + base + j);
     }
   }
-  if constexpr (GL == 64) {  // wave-uniform: into SGPRs (after every load has been issued)
-    phase = __builtin_amdgcn_readfirstlane(phase);
-    lp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lp)));
+  // wave-uniform: into SGPRs (after every load has been issued)
+  phase = __builtin_amdgcn_readfirstlane(phase);
+  lp = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lp)));
 #pragma unroll
-    for (int k = 0; k < kRecHot; ++k) rw[k] = __builtin_amdgcn_readfirstlane(rw[k]);
-  }
+  for (int k = 0; k < kRecHot; ++k) rw[k] = __builtin_amdgcn_readfirstlane(rw[k]);
   stage = chain_uniform<GL>(stage);
   if (phase == 1 && ax.int_stages > 1 && stage < ax.int_stages - 1) {
     // a middle stage of a multi-stage integrator: kick b_i with the gradient just evaluated, drift a_i
@@ -2518,23 +2357,17 @@ k_nuts_async_tick3(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* _
     if (g == 0) recp[RW_STAGE] = stage + 1;
   } else if (phase == 1) {
     if (ax.int_stages > 1 && g == 0) recp[RW_STAGE] = 0;
-    const bool done = async_leaf3_row<GL, NI>(nt, ax, qf, lp, c, b, recp, rw, R);
+    async_leaf3_row<GL, NI>(nt, ax, qf, lp, c, b, recp, rw, R);
     if (g == 0) {
 #pragma unroll
       for (int k = 0; k < kRecHot / 4; ++k)
         *reinterpret_cast<int4*>(recp + 4 * k) = make_int4(rw[4 * k], rw[4 * k + 1], rw[4 * k + 2], rw[4 * k + 3]);
-      if (!DEFER && done && ax.end_list)  // rows whose transition ended go on the work list of the second kernel
-        ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
     }
-  } else if (DEFER && (phase == 3 || phase == 0)) {
-    if constexpr (GL == 64) {  // record, accept, adapt, momentum draw, tree start, first opening half
-      int w = recp[threadIdx.x & (BJX_NUTS_REC_WORDS - 1)];
-      const int w_in = w;
-      async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
-      if ((int)threadIdx.x < BJX_NUTS_REC_WORDS && w != w_in) recp[threadIdx.x] = w;
-    }
-  } else if (!DEFER && phase == 0 && ax.end_list && g == 0) {  // first tick of a run: every chain starts
-    ax.end_list[(int64_t)(ax.tick & 1) * nt.N + atomicAdd(ax.end_count + (ax.tick & 1), 1)] = (int32_t)b;
+  } else if (phase == 3 || phase == 0) {  // record, accept, adapt, momentum draw, tree start, first opening half
+    int w = recp[threadIdx.x & (BJX_NUTS_REC_WORDS - 1)];
+    const int w_in = w;
+    async_end2_chain<NI>(nt, ax, qf, c, b, phase, w);
+    if ((int)threadIdx.x < BJX_NUTS_REC_WORDS && w != w_in) recp[threadIdx.x] = w;
   }
 }
 
@@ -2563,7 +2396,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_gemm_kick(bjx_nuts_t nt, bjx_nuts_async_t ax, const float* __restrict__ gf, int want_phase) {
   if (want_phase == 1 && blockIdx.x == 0 && threadIdx.x == 0) *ax.end_count = 0;  // this tick's momentum list
-  async_for_each_chain<false>(ax, want_phase, want_phase, [&](int64_t c, int64_t b, int) {
+  async_for_each_chain(ax, want_phase, want_phase, [&](int64_t c, int64_t b, int) {
     const int dir = IS(BJX_NUTS_I_DIR, c);
     const float h = ((float)dir * chain_eps(nt, c)) * int_kick(nt);
     const int64_t base = c * nt.D;
@@ -2599,7 +2432,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))  // 124 VGPRs
 k_nuts_gemm_leaf(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, const float* __restrict__ logp_f,
                  const float* __restrict__ gf, int32_t cap) {
-  async_for_each_chain<false>(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
+  async_for_each_chain(ax, 1, 0, [&](int64_t c, int64_t b, int phase) {
     const int lane = threadIdx.x & 63;
     int32_t t = ax.t[c];
     if (phase == 1) {
@@ -2705,7 +2538,7 @@ k_nuts_gemm_start(bjx_nuts_t nt, bjx_nuts_async_t ax, int32_t cap) {
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_nuts_gemm_pre(bjx_nuts_t nt, bjx_nuts_async_t ax, float* __restrict__ qf) {
-  async_for_each_chain<false>(ax, 4, 4, [&](int64_t c, int64_t b, int) {
+  async_for_each_chain(ax, 4, 4, [&](int64_t c, int64_t b, int) {
     const int dir = IS(BJX_NUTS_I_DIR, c);
     const float deps = (float)dir * chain_eps(nt, c);
     const float h = deps * int_kick(nt);
@@ -3107,168 +2940,56 @@ int bjx_nuts_async_tick(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_asy
                        dim3(kBlock), 0, (hipStream_t)stream, *nuts, *run, qf, logp_f, gf);
     return bjx_check_launch("bjx_nuts_async_tick");
   }
-  const int64_t groups = (run->n_rows + kAsyncGroup - 1) / kAsyncGroup;
-  const dim3 grid(bjx_row_grid(groups, kWavesPerBlock) > 2048 ? 2048 : bjx_row_grid(groups, kWavesPerBlock));
   hipStream_t s = (hipStream_t)stream;
-  // largest batch whose tick is ONE launch doing leaf and transition end in the same wave (round 2: 8 192).
-  // Round 4: where the lean leaf with deferred transition ends exists (diagonal metric, rows of at most 256
-  // floats, no engine-resident target: k_nuts_async_tick3<64, 1, W, DEFER>) it is ALSO one launch per tick and
-  // faster at every batch size (C3, T = 100 / 400: 221 / 105 M/s with the round-2 threshold, 234 / 113 at 512,
-  // 251 / 136 at 0), so the default threshold there is 0; -1 = "unset".
-  static const int64_t fused_rows_env = [] {
-    const char* e = getenv("BJX_NUTS_FUSED_ROWS");
-    return e ? atoll(e) : (int64_t)-1;
-  }();
-  // One launch per tick (leaf, fence, boundary in the same wave) unless nearly all chains of a large
-  // ensemble are live: only then does the lighter leaf kernel's occupancy pay for a second launch
-  // (C3, 32 768 x 256: 105.9 M/s always fused, 100.1 / 107.8 / 111.6 M/s fused up to 2 048 / 8 192 / 16 384 rows).
-  // one launch per tick for small batches -- and always when the launch carries several ticks per chain
-  static const int leaf3_env = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 132; }();
-  const bool lean_deferred = leaf3_env >= 128 && nuts->D <= 512 && run->target_kind == BJX_TARGET_NONE &&
-                             run->end_list && run->end_count && run->rec && run->front_p;
-  const int64_t fused_rows = fused_rows_env >= 0 ? fused_rows_env : (lean_deferred ? (int64_t)0 : (int64_t)8192);
-  const bool fused = run->n_rows <= fused_rows || run->ticks_per_launch > 1;
-  static const bool use_v2 = [] {
-    const char* e = getenv("BJX_NUTS_V2");
-    return e ? atoi(e) != 0 : true;
-  }();
+  // Which kernel ticks a batch (round 5: ONE choice per shape, no environment switches -- the measured losers of
+  // rounds 1-4 are recorded in NOTEBOOK.md sections 7, 15 and no longer compiled in):
+  //   diagonal metric, 16-byte rows of at most 1 024 floats, external callable
+  //       -> k_nuts_async_tick3<NI, W>: lean leaf + the transition ends deferred from the tick before, one launch
+  //          per tick at every batch size; multi-stage integrators included
+  //   the same shapes with an engine-resident target (fuse_target, outside the callable contract, D <= 512)
+  //       -> k_nuts_async_multi: ticks_per_launch ticks of every row per launch
+  //   everything else (4-byte sweeps, rows beyond 1 024 floats; per-chain dense metrics are handled above)
+  //       -> k_nuts_async_fused: the general one-launch tick
   const bool all_vec4 = nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm);
-  const int ni2 = all_vec4 ? nuts_resident_ni(nuts, qf, gf) : 0;
-  if (use_v2 && ni2 == 0 && all_vec4 && nuts->D <= 1024 && leaf3_env >= 128 &&
-      run->target_kind == BJX_TARGET_NONE && run->rec && run->front_p) {
-    // rows of 513 .. 1 024 floats (three / four 16-byte pieces per lane): only the lean tick kernel with deferred
-    // transition ends exists for them -- one launch per tick at every batch size (round 4; before: the round-1
-    // general sweeps).  Multi-stage integrators too (round 5: a leaf lasts K ticks, as for narrower rows).
-    const dim3 g1((unsigned)run->n_rows);
-    if (nuts->D <= 768) hipLaunchKernelGGL((k_nuts_async_tick3<64, 3, 2, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
-    else hipLaunchKernelGGL((k_nuts_async_tick3<64, 4, 2, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
-    return bjx_check_launch("bjx_nuts_async_tick");
-  }
-  if (use_v2 && ni2 > 0 && run->rec && run->front_p) {  // v2 data movement (see "free-running chains, v2")
-    const dim3 rgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
-    const dim3 lgrid(rgrid.x < 512u ? rgrid.x : 512u);           // work-list kernel: at most 2 048 waves
-    const dim3 wgrid((unsigned)(run->n_rows < (int64_t)1 << 20 ? run->n_rows : (int64_t)1 << 20));  // one wave per workgroup
-    static const int leaf_waves = [] { const char* e = getenv("BJX_LEAF2_WAVES"); return e ? atoi(e) : 3; }();
-    static const int fused_waves = [] { const char* e = getenv("BJX_FUSED2_WAVES"); return e ? atoi(e) : 3; }();
-    // Few live rows (the tail of a run, small ensembles): occupancy is irrelevant, the LATENCY of one
-    // wave is everything -- the one-launch tick needs 168 VGPRs + 18 spilled ones (scratch) when capped
-    // for three waves per SIMD; uncapped (two waves, up to 256 VGPRs) it spills nothing.
-    static const int64_t lowlat_rows = [] { const char* e = getenv("BJX_NUTS_LOWLAT_ROWS"); return e ? atoll(e) : (int64_t)2048; }();
-    const bool tgt = run->target_kind != BJX_TARGET_NONE;
-    static const int multi_waves = [] { const char* e = getenv("BJX_MULTI_WAVES"); return e ? atoi(e) : 2; }();
-    // Round-4 leaf kernels of the busy phase (D <= 256), BJX_NUTS_LEAF3: 0 = the v2 leaf + work-list kernel;
-    // 16 = four chains per wave; 64 + w = one chain per wave with the lean register layout (w = waves-per-SIMD
-    // hint) + work-list kernel; 128 + w (default 132) = the same leaf with the transition ends DEFERRED into the
-    // next tick's launch -- one kernel per tick instead of two (C3: 194 -> 220 M/s at T = 100 on one box)
-    static const int leaf3 = [] { const char* e = getenv("BJX_NUTS_LEAF3"); return e ? atoi(e) : 132; }();
-    bool deferred_ends = false;
-#define BJX_TICK2_L(NI_, MODE_, W_)                                                                               \
-  do {                                                                                                            \
-    if (tgt) hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-    else hipLaunchKernelGGL((k_nuts_async_tick2<NI_, MODE_, W_, false>), wgrid, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);    \
+  const int ni2 = all_vec4 ? nuts_resident_ni(nuts, qf, gf) : 0;  // 1 / 2: rows of at most 256 / 512 floats
+  const bool lean = all_vec4 && nuts->D <= 1024 && run->rec && run->front_p;
+  if (run->target_kind != BJX_TARGET_NONE) {
+    BJX_CHECK_ARG(lean && ni2 > 0,
+                  "bjx_nuts_async_tick: target_kind is served by the low-traffic kernels only (D % 4 == 0, D <= 512, "
+                  "16-byte aligned buffers)");
+    bjx_nuts_async_t r = *run;
+    if (r.ticks_per_launch < 1) r.ticks_per_launch = 1;
+    const dim3 wgrid((unsigned)(r.n_rows < (int64_t)1 << 20 ? r.n_rows : (int64_t)1 << 20));  // one wave per workgroup
+#define BJX_MULTI(NI_)                                                                                          \
+  do {                                                                                                          \
+    if (nuts->D == 256 * NI_)                                                                                   \
+      hipLaunchKernelGGL((k_nuts_async_multi<NI_, 2, true>), wgrid, dim3(64), 0, s, *nuts, r, qf,               \
+                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                   \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_nuts_async_multi<NI_, 2, false>), wgrid, dim3(64), 0, s, *nuts, r, qf,              \
+                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                   \
   } while (0)
-#define BJX_END_LIST(NI_)                                                                                         \
-  do {                                                                                                            \
-    if (tgt) hipLaunchKernelGGL((k_nuts_async_end_list<NI_, true>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
-    else hipLaunchKernelGGL((k_nuts_async_end_list<NI_, false>), lgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);    \
-  } while (0)
-#define BJX_MULTI(NI_, W_)                                                                                        \
-  do {                                                                                                            \
-    if (nuts->D == 256 * NI_)                                                                                     \
-      hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_, true>), wgrid, dim3(64), 0, s, *nuts, *run, qf,             \
-                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                     \
-    else                                                                                                          \
-      hipLaunchKernelGGL((k_nuts_async_multi<NI_, W_, false>), wgrid, dim3(64), 0, s, *nuts, *run, qf,            \
-                         const_cast<float*>(logp_f), const_cast<float*>(gf));                                     \
-  } while (0)
-#define BJX_TICK2(NI_)                                                                     \
-  do {                                                                                     \
-    if (tgt && run->ticks_per_launch > 1) {                                                \
-      if (run->n_rows <= lowlat_rows || multi_waves <= 2) BJX_MULTI(NI_, 2);               \
-      else if (multi_waves >= 4) BJX_MULTI(NI_, 4); else BJX_MULTI(NI_, 3);                \
-    } else if (fused) {                                                                           \
-      if (run->n_rows <= lowlat_rows) BJX_TICK2_L(NI_, 2, 2);                              \
-      else if (fused_waves >= 4) BJX_TICK2_L(NI_, 2, 4); else BJX_TICK2_L(NI_, 2, 3);      \
-    } else {                                                                               \
-      if (leaf3 != 0 && (NI_ == 1 || leaf3 >= 128) && !tgt && run->end_list && run->end_count) { \
-        if (leaf3 >= 128) {  /* 128 + w: one chain per wave, transition ends deferred into the next launch */ \
-          const dim3 g1((unsigned)run->n_rows);                                            \
-          if (leaf3 == 128 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 3, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else if (leaf3 == 128 + 6) hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 6, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else hipLaunchKernelGGL((k_nuts_async_tick3<64, NI_, 4, true>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                  \
-          deferred_ends = true;                                                            \
-        } else if (leaf3 >= 64) {  /* one chain per wave, lean registers: 64 + waves per SIMD */  \
-          const dim3 g1((unsigned)run->n_rows);                                            \
-          if (leaf3 == 64 + 8) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 8>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else if (leaf3 == 64 + 7) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 7>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else if (leaf3 == 64 + 5) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 5>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
-          else if (leaf3 == 64 + 6) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 6>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else if (leaf3 == 64 + 3) hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 3>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else hipLaunchKernelGGL((k_nuts_async_tick3<64, 1, 4>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);                      \
-        } else {            /* four chains per wave */                                     \
-          const dim3 g3((unsigned)((run->n_rows + 3) / 4));                                \
-          const int ni3 = (int)((nuts->D + 63) / 64);                                      \
-          if (ni3 == 1) hipLaunchKernelGGL((k_nuts_async_tick3<16, 1, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);      \
-          else if (ni3 == 2) hipLaunchKernelGGL((k_nuts_async_tick3<16, 2, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else if (ni3 == 3) hipLaunchKernelGGL((k_nuts_async_tick3<16, 3, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf); \
-          else hipLaunchKernelGGL((k_nuts_async_tick3<16, 4, 2>), g3, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);               \
-        }                                                                                  \
-      } else if (leaf_waves >= 4) BJX_TICK2_L(NI_, 0, 4); else BJX_TICK2_L(NI_, 0, 3);     \
-      if (deferred_ends) { /* no second kernel */ }                                        \
-      else if (run->end_list && run->end_count)                                            \
-        BJX_END_LIST(NI_);                                                                 \
-      else                                                                                 \
-        BJX_TICK2_L(NI_, 1, 4);                                                            \
-    }                                                                                      \
-  } while (0)
-    if (ni2 == 1) BJX_TICK2(1);
-    else BJX_TICK2(2);
-#undef BJX_TICK2_L
-#undef BJX_END_LIST
+    if (ni2 == 1) BJX_MULTI(1);
+    else BJX_MULTI(2);
 #undef BJX_MULTI
-#undef BJX_TICK2
     return bjx_check_launch("bjx_nuts_async_tick");
   }
-  BJX_CHECK_ARG(run->target_kind == BJX_TARGET_NONE,
-                "bjx_nuts_async_tick: target_kind is served by the low-traffic kernels only (D % 4 == 0, D <= 512, "
-                "16-byte aligned buffers)");
-  if (fused) {
-    const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
-    if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {
-      const int ni = nuts_resident_ni(nuts, qf, gf);
-      if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-      else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-      else hipLaunchKernelGGL((k_nuts_async_fused<4, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    } else {
-      hipLaunchKernelGGL((k_nuts_async_fused<1, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
-    }
+  if (lean) {
+    const dim3 g1((unsigned)run->n_rows);  // one wave (= one workgroup) per compact row
+    if (ni2 == 1) hipLaunchKernelGGL((k_nuts_async_tick3<1, 4>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
+    else if (ni2 == 2) hipLaunchKernelGGL((k_nuts_async_tick3<2, 4>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
+    else if (nuts->D <= 768) hipLaunchKernelGGL((k_nuts_async_tick3<3, 2>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
+    else hipLaunchKernelGGL((k_nuts_async_tick3<4, 2>), g1, dim3(64), 0, s, *nuts, *run, qf, logp_f, gf);
+    return bjx_check_launch("bjx_nuts_async_tick");
+  }
+  const dim3 fgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));  // one wave per row
+  if (all_vec4) {
+    const int ni = nuts_resident_ni(nuts, qf, gf);
+    if (ni == 1) hipLaunchKernelGGL((k_nuts_async_fused<4, 1>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    else if (ni == 2) hipLaunchKernelGGL((k_nuts_async_fused<4, 2>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
+    else hipLaunchKernelGGL((k_nuts_async_fused<4, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
   } else {
-    static const bool grouped = [] {
-      const char* e = getenv("BJX_NUTS_GROUPED");
-      return e ? atoi(e) != 0 : false;
-    }();
-    const dim3 rgrid(bjx_row_grid(run->n_rows, kWavesPerBlock));
-#define BJX_TICK2(V, NI_, G, GR)                                                                          \
-  do {                                                                                                    \
-    hipLaunchKernelGGL((k_nuts_async_leaf<V, NI_, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf); \
-    hipLaunchKernelGGL((k_nuts_async_boundary<V, G>), GR, dim3(kBlock), 0, s, *nuts, *run, qf);            \
-  } while (0)
-    if (nuts_vec4(nuts, qf, gf, run->out_position, run->adapt_mean, run->adapt_m2, run->adapt_imm)) {
-      const int ni = nuts_resident_ni(nuts, qf, gf);
-      if (grouped) {
-        if (ni == 1) BJX_TICK2(4, 1, true, grid);
-        else if (ni == 2) BJX_TICK2(4, 2, true, grid);
-        else BJX_TICK2(4, 0, true, grid);
-      } else {
-        if (ni == 1) BJX_TICK2(4, 1, false, rgrid);
-        else if (ni == 2) BJX_TICK2(4, 2, false, rgrid);
-        else BJX_TICK2(4, 0, false, rgrid);
-      }
-    } else {
-      if (grouped) BJX_TICK2(1, 0, true, grid);
-      else BJX_TICK2(1, 0, false, rgrid);
-    }
-#undef BJX_TICK2
+    hipLaunchKernelGGL((k_nuts_async_fused<1, 0>), fgrid, dim3(kBlock), 0, s, *nuts, *run, qf, logp_f, gf);
   }
   return bjx_check_launch("bjx_nuts_async_tick");
 }

@@ -441,6 +441,7 @@ def free_running_supports(integrator, metric_kind: str, dim: int) -> bool:
             and integrator.num_gradients_per_step - 1 <= _lib.NUTS_MAX_MID)
 
 
+_DENSE_GEMM_CAP = 0  # run_free(dense_gemm=True): default size of a tick's momentum list (0 = a quarter of the ensemble)
 _WARNED_LOCKSTEP_RUN: set = set()
 
 
@@ -463,16 +464,11 @@ def _warn_lockstep_run(integrator, metric_kind: str, dim: int) -> None:
 
 def auto_row_block(n_rows: int, dim: int) -> int:
     """Rows per group of the free-running schedule.  Default: ALL rows in one group.  Ticking the
-    ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; set
-    ``BJX_NUTS_ROW_BLOCK=n`` or pass ``row_block=n``) was measured SLOWER at the C3 shape (32 768 x
+    ensemble in Infinity-Cache-sized row groups (the analogue of ``hmc.auto_chain_block``; pass
+    ``row_block=n`` to ``run_free``) was measured SLOWER at the C3 shape (32 768 x
     256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s; on the
     final kernels 184-191 vs 164 / 131): a tick moves more than the cache holds between two uses of
     a row whatever the grouping, and the smaller launches cost (NOTEBOOK.md section 7)."""
-    import os
-
-    v = os.environ.get("BJX_NUTS_ROW_BLOCK", "")
-    if v not in ("", "auto"):
-        return int(v)  # 0 = one group
     return int(n_rows)
 
 
@@ -653,7 +649,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     gemm_bufs = None
     if gemm:
         # compact kicked momenta / their velocities (one GEMM per product), and the momentum list of a tick
-        cap = dense_gemm_cap if dense_gemm_cap is not None else int(_os_environ().get("BJX_NUTS_GEMM_CAP", "0"))
+        cap = dense_gemm_cap if dense_gemm_cap is not None else _DENSE_GEMM_CAP
         cap = int(cap) if cap and int(cap) > 0 else max(128, -(-N // 4))
         cap = min(N, -(-cap // 128) * 128)
         gemm_bufs = (torch.zeros_like(q), torch.zeros_like(q), torch.zeros((cap, D), **f32),
@@ -688,20 +684,17 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if gemm_bufs is not None:
         (run.gemm_pc, run.gemm_vc, run.gemm_z, run.gemm_pm, run.gemm_vm) = (b.data_ptr() for b in gemm_bufs[:5])
         run.gemm_cap = gemm_bufs[5]
-        if _os_environ().get("BJX_NUTS_GEMM_TN", "1") != "0":
-            run.gemm_mass_sqrt = gemm_bufs[6].data_ptr()
-            run.gemm_imm_t = metric.imm_t.data_ptr()
+        run.gemm_mass_sqrt = gemm_bufs[6].data_ptr()  # both matrices read as stored (bjx_dense_matmul_bt / apply_imm_t)
+        run.gemm_imm_t = metric.imm_t.data_ptr()
     if general and len(drift_c) > 1:  # middle stages (b_2, a_2), ..., (b_K, a_K); the closing kick b_1 is int_kick
         run.int_stages = len(drift_c)
         for i in range(1, len(drift_c)):
             run.int_mid_kick[i - 1], run.int_mid_drift[i - 1] = kick_c[i], drift_c[i]
     fused = False
     rtc_module = None
-    # with an engine-resident target a whole chunk of ticks is ONE launch for batches of at most this many
-    # rows (default: always; 0 = one launch per tick).  Measured at C3 (NOTEBOOK.md section 7): every chunk as
-    # one launch 322 / 340 / 220 M/s at T = 20 / 100 / 400, only below 8 192 rows 239 / 254 / 181, one launch
-    # per tick 190 / 212 / 112, the external-callable path 172 / 200 / 99
-    multi_tick_rows = int(_os_environ().get("BJX_NUTS_MULTI_TICK_ROWS", str(N)))
+    # with an engine-resident target a whole chunk of ticks is ONE launch (k_nuts_async_multi) at every batch size:
+    # measured at C3 (NOTEBOOK.md section 7) 322 / 340 / 220 M/s at T = 20 / 100 / 400 against 190 / 212 / 112 with
+    # one launch per tick -- the one-tick target kernels were removed in round 5
     if fuse_target:
         spec = getattr(logdensity_fn, "_bjx_fused_target", None)
         spec = spec(D) if callable(spec) else None
@@ -716,7 +709,6 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             rtc_target = spec[1]
             rtc_module = rtc_target.nuts_module()
             run.target_kind, run.target_vec = _lib.NUTS_TARGET_USER, rtc_target._params_ptr(dev) or None
-            multi_tick_rows = N
         else:
             run.target_kind, run.target_vec = int(spec[0]), _lib.ptr(spec[1])
         fused_keep = spec[1]  # noqa: F841  (keeps the parameter vector / the compiled module alive for the run)
@@ -773,18 +765,17 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 
         def chunk(self, n_ticks, logp_f, gf):
             """``n_ticks`` ticks, each followed by the callable on the group's batch."""
-            if fused and self.n_rows <= multi_tick_rows:
+            if fused:
                 # engine-resident target + one-launch ticks: the whole chunk is ONE launch, every wave
                 # advancing its chain n_ticks times (bjx_nuts_async_t.ticks_per_launch)
                 self.run.tick, self.run.ticks_per_launch = 0, n_ticks
                 multi_tick(self.run, self.qf, logp_f, gf)
                 return logp_f, gf
             for i in range(n_ticks):
-                self.run.tick = i & 1  # work-list parity (include/bjx_nuts.h); chunks have an even length
+                self.run.tick = i & 1
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, self.rref, self.qf.data_ptr(),
                           logp_f.data_ptr(), gf.data_ptr())
-                if not fused:  # fuse_target: the tick wrote (logp, grad) of its new positions in place
-                    logp_f, gf = eval_logdensity(vg, self.qf)
+                logp_f, gf = eval_logdensity(vg, self.qf)
             return logp_f, gf
 
         def advance(self, n_ticks, record):
@@ -837,7 +828,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             # a recorded sequence of n_ticks ticks, replayed `reps` times per host sync: recording
             # costs ~40 us per tick, so a short sequence pays for itself within a few hundred ticks
             self.cap, self.n_ticks, self.reps = cap, n_ticks, reps
-            self.tiered = _os.environ.get("BJX_NUTS_TAIL_TIERS", "1") != "0"
+            self.tiered = True  # tail sequences follow tiers of the live-row count (cap / 512 / 128 / 32 rows)
             self.rows = [torch.zeros(cap, **i32) for _ in range(2)]
             self.qf = [q[:1].expand(cap, D).contiguous() for _ in range(2)]  # valid positions everywhere
             self.n_dev = [torch.zeros(1, **i32) for _ in range(2)]
@@ -872,7 +863,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         def chunk_ticks(self):
             """Ticks per recorded sequence: the few-row tiers are pure launch latency (two dependent
             kernels per tick), so their sequences are longer -- fewer replay boundaries per tick."""
-            mult = int(_os.environ.get("BJX_NUTS_TAIL_SEQ_MULT", "4"))
+            mult = 4
             return self.n_ticks * (mult if (self.tiered and self.view <= 128) else 1)
 
         def enter(self, groups_in, n_active):
@@ -907,13 +898,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             rref_k = ctypes.byref(self.run[k])
             if fused:
                 lp, g_ = self.lp[k][:self.view], self.g[k][:self.view]
-                if self.view <= multi_tick_rows:  # the whole sequence as one launch
-                    self.run[k].tick, self.run[k].ticks_per_launch = 0, n_ticks
-                    multi_tick(self.run[k], qf_v, lp, g_)
-                    return
+                self.run[k].tick, self.run[k].ticks_per_launch = 0, n_ticks  # the whole sequence as one launch
+                multi_tick(self.run[k], qf_v, lp, g_)
+                return
             for i in range(n_ticks):
-                if not fused:
-                    lp, g_ = eval_logdensity(vg, qf_v)
+                lp, g_ = eval_logdensity(vg, qf_v)
                 self.run[k].tick = i & 1
                 _lib.call("bjx_nuts_async_tick", _lib.current_stream(), dref, rref_k, qf_v.data_ptr(),
                           lp.data_ptr(), g_.data_ptr())

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
     assert lib.bjx_pool_workspace_bytes(0, 8) == 0
     assert lib.bjx_pool_workspace_bytes(65536, 1024) == 512 * 4 * 1024 * 8  # 512 slabs x K=4 x D doubles
-    assert lib.bjx_abi_version() == 4  # 4: bjx_nuts_async_t gained gemm_pc .. gemm_cap (round 4)
+    assert lib.bjx_abi_version() == 5  # 5 (round 5): one tick kernel per shape, no kernel-selecting environment switches
 
 
 def test_error_reporting_without_gpu():

@@ -63,7 +63,9 @@ def test_free_running_gemm_equals_lockstep_gemm_steps(dev, monkeypatch, N, D, ca
     st, pos_s, infos = _steps(alg, prng.key(3), st0, T)
     monkeypatch.setenv("BJX_NUTS_FREE_GEMM", "1")
     if cap:
-        monkeypatch.setenv("BJX_NUTS_GEMM_CAP", str(cap))
+        import importlib
+
+        monkeypatch.setattr(importlib.import_module("blackjax_amd.nuts"), "_DENSE_GEMM_CAP", cap)
     final, positions, info = alg.run(prng.key(3), st0, T)
     _same(positions, info, final, st, pos_s, infos)
     assert len(set(t2n(info.num_trajectory_expansions).ravel().tolist())) > 1  # chains do leave lockstep
