@@ -830,7 +830,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             self.cap, self.n_ticks, self.reps = cap, n_ticks, reps
             self.tiered = True  # tail sequences follow tiers of the live-row count (cap / 512 / 128 / 32 rows)
             self.rows = [torch.zeros(cap, **i32) for _ in range(2)]
-            self.qf = [q[:1].expand(cap, D).contiguous() for _ in range(2)]  # valid positions everywhere
+            # valid positions everywhere.  repeat(), not expand().contiguous(): with cap == 1 the latter IS q[:1] (already
+            # contiguous, no copy), and the last live chain's pending positions were then written into chain 0's state
+            # row (round 5: found by the row-width sweep of tests/test_nuts_v3_gpu.py; latent since round 3)
+            self.qf = [q[:1].repeat(cap, 1) for _ in range(2)]
             self.n_dev = [torch.zeros(1, **i32) for _ in range(2)]
             self.run = []
             for k in range(2):

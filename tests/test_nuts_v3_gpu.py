@@ -82,3 +82,19 @@ def test_shared_nontrivial_metric_and_a_multi_stage_integrator(dev):
         alg = bjx.nuts(bjx.targets.NealFunnel(), 0.15, torch.ones(D2, device=dev), max_num_doublings=6,
                        integrator=bjx.integrators.yoshida)
         _run_vs_steps(alg, alg.init(q0), bjx.random.key(9), 3)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3])
+def test_tail_entered_with_one_live_chain_keeps_chain_zero_intact(dev, seed):
+    """Regression (round 5): a run whose recorded tail starts with exactly ONE live chain used to build its pending-
+    position buffer as ``q[:1].expand(1, D).contiguous()`` -- a VIEW of chain 0's state row -- so that chain's
+    leapfrog positions overwrote ``final.position[0]`` (log-density and gradient stayed right).  These three seeds
+    reproduced it deterministically (N = 70, D = 1 024, yoshida: a leaf lasts three ticks)."""
+    N, D, T = 70, 1024, 3
+    tgt = bjx.targets.NealFunnel()
+    q0 = 0.1 * torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    alg = bjx.nuts(tgt, 0.15, torch.ones(D, device=dev), max_num_doublings=6, integrator=bjx.integrators.yoshida)
+    final, pos, info = alg.run(bjx.random.key(9), alg.init(q0), T)
+    assert torch.equal(final.position, pos[-1])
+    lp, gr = tgt(final.position)
+    assert torch.equal(gr, final.logdensity_grad) and torch.equal(lp, final.logdensity)
