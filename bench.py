@@ -952,6 +952,30 @@ def bench_c4(args, ctx):
     eps_final = params["step_size"]
     pooled = ctx.gather_rows(torch.stack([eps_final.mean(), eps_final.min(), eps_final.max(),
                                           acc[-1].mean()]).reshape(1, 4))
+    # host cost of ISSUING one warm-up step: host_enqueue_ms_per_step below is measured inside
+    # the timed region, where launch calls block on a full queue, so it tracks the GPU time.  Here the SAME launch
+    # sequence per step (same schedule, same number of chain blocks, L leapfrogs + L callables per block, Welford,
+    # dual averaging) runs on 8 chains per block: every launch is a few microseconds of GPU work, so the wall time
+    # per step is an UPPER bound of what the host needs to issue a step.
+    host_issue_ms = None
+    if rank == 0:
+        try:
+            import types
+
+            n_blocks = (N + blk - 1) // blk
+            tiny_alg = types.SimpleNamespace(
+                init=bjx.hmc.init, build_kernel=lambda integ: bjx.hmc.build_kernel(integ, chain_block=8, use_graph=False))
+            warm_t = bjx.window_adaptation(tiny_alg, target, num_integration_steps=L, adaptation_info_fn=keep)
+            q_t = q0[:8 * n_blocks].contiguous()
+            warm_t.run(bjx.random.key(3), q_t, 3)
+            torch.cuda.synchronize()
+            k_h = min(40, args.steps)
+            t_h = time.perf_counter()
+            warm_t.run(bjx.random.key(4), q_t, k_h)
+            torch.cuda.synchronize()
+            host_issue_ms = (time.perf_counter() - t_h) / k_h * 1e3
+        except Exception as e:
+            print(f"bench.py: c4 host-issue probe failed: {e!r}", file=sys.stderr)
     if rank != 0:
         return None
     roofline = None
@@ -982,6 +1006,11 @@ def bench_c4(args, ctx):
         },
         "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per],
         "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "host_issue_ms_unthrottled": host_issue_ms,
+        "host_issue_over_ms_per_step": (host_issue_ms / (dt / args.steps * 1e3)) if host_issue_ms else None,
+        "host_note": "host_enqueue_ms_per_step is measured inside the timed region and includes launch calls blocking on a "
+                     "full queue; host_issue_ms_unthrottled is the wall time per step of the SAME launch sequence on 8 chains "
+                     "per block (plain launches): an upper bound of the host's own cost of issuing one warm-up step",
         "end_to_end_frac_of_32B_roofline": value / world / (HBM_PEAK_GBS * 1e9 / (32.0 * D)),
         "adapted": {"per_rank_[mean_eps,min_eps,max_eps,last_step_mean_acceptance]": pooled.tolist()},
         "roofline": roofline,

@@ -48,7 +48,7 @@ def _setup(dev, N, D, per_chain, rho=0.8, seed=0):
     return fn_o, tgt, imm, metric, q0
 
 
-@pytest.mark.parametrize("N,D,L,per_chain", [(128, 128, 5, False), (37, 30, 6, False), (20, 24, 5, True)])
+@pytest.mark.parametrize("N,D,L,per_chain", [(128, 128, 5, False), (37, 30, 6, False), (20, 24, 5, True), (256, 128, 3, False)])
 def test_mhmc_dense_parity(dev, N, D, L, per_chain):
     fn_o, tgt, imm, metric, q0 = _setup(dev, N, D, per_chain)
     st_o = ohmc.init(q0, fn_o)
@@ -68,7 +68,7 @@ def test_mhmc_dense_parity(dev, N, D, L, per_chain):
     assert moved > 0
 
 
-@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (45, 20, False), (18, 16, True)])
+@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (45, 20, False), (18, 16, True), (256, 128, False)])
 def test_dynamic_hmc_dense_parity(dev, N, D, per_chain):
     """Per-chain random trajectory lengths through the MASKED dense leapfrog (finished chains are
     copied through untouched by the GEMM's prologue / epilogue)."""
@@ -91,7 +91,7 @@ def test_dynamic_hmc_dense_parity(dev, N, D, per_chain):
     assert len(lengths) >= 4
 
 
-@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (45, 20, False), (18, 16, True)])
+@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (45, 20, False), (18, 16, True), (256, 128, False)])
 def test_dmhmc_dense_parity(dev, N, D, per_chain):
     """blackjax.dmhmc with a dense metric (blackjax/__init__.py:155-163; VERDICT r2 "missing" #4): per-chain
     random trajectory lengths AND progressive sampling of one state per trajectory -- the masked dense
@@ -122,7 +122,7 @@ def test_dmhmc_dense_parity(dev, N, D, per_chain):
 
 
 @pytest.mark.parametrize("name", ["mclachlan", "yoshida", "omelyan"])
-@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (33, 18, False), (12, 16, True)])
+@pytest.mark.parametrize("N,D,per_chain", [(128, 128, False), (33, 18, False), (12, 16, True), (256, 128, False)])
 def test_palindromic_integrators_dense_parity(dev, name, N, D, per_chain):
     fn_o, tgt, imm, metric, q0 = _setup(dev, N, D, per_chain, seed=5)
     st_o = ohmc.init(q0, fn_o)

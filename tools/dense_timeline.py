@@ -45,9 +45,9 @@ def stats(x):
 
 
 import os
-out = {"BJX_DENSE_FAIR": os.environ.get("BJX_DENSE_FAIR", "unset"), "clock": "wall_clock64 (100 MHz); all figures in microseconds; 512 workgroups, two per CU, one round",
+out = {"kernel": "k_dense_gemm_tn8 (128 x 128, eight waves, two workgroups per CU)", "workgroups": n_wg, "clock": "wall_clock64 (100 MHz); all figures in microseconds; 512 workgroups, two per CU, one round",
        "stamps": ["entry", "first K-tile staged (after the first barrier)", "end of main loop", "end (stores acknowledged)"]}
-for name, fn in (("fused_tn8<EPI_DRIFT,2>", fused), ("plain_tn8<EPI_STORE,0>", plain)):
+for name, fn in (("fused<EPI_DRIFT,2>", fused), ("plain<EPI_STORE,0>", plain)):
     runs = []
     for rep in range(6):
         lib.bjx_dense_probe_set(None)

@@ -24,9 +24,10 @@ python - "$OUT" <<'PY'
 import csv, glob, json, collections, re, sys
 out = sys.argv[1]
 def name_of(k):
-    m = re.search(r'k_dense_gemm_tn8<\s*(\d)\s*,\s*(\d)\s*>', k)
+    m = re.search(r'k_dense_gemm_(tn8|tnw)<\s*(\d)\s*,\s*(\d)\s*>', k)
     if m:
-        return {"12": "fused_tn8<EPI_DRIFT,2>", "00": "plain_tn8<EPI_STORE,0>"}.get(m.group(1) + m.group(2))
+        base = {"12": "fused_%s<EPI_DRIFT,2>", "00": "plain_%s<EPI_STORE,0>"}.get(m.group(2) + m.group(3))
+        return base % m.group(1) if base else None
     if "k_dense" in k or "bjx" in k:
         return None
     if re.search(r'Cijk|gemm|sgemm', k):
