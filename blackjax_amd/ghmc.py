@@ -72,7 +72,9 @@ def inverse_mass_from_scale(momentum_inverse_scale, n_chains: int, dim: int, dev
     row stride 0 | D).  Accepted: a scalar, ``(D,)``, or one scale vector per chain ``(N, D)`` (what
     the vmapped reference kernel sees as 1-D per chain).  The reference reads a single chain's 2-D
     argument as a dense inverse mass matrix (blackjax#950): a ``(D, D)`` tensor that is not ``(N, D)``
-    is therefore refused rather than guessed at."""
+    is therefore refused rather than guessed at.  NOTE (round 4 behaviour change): an UNTAGGED square
+    ``(N, D)`` array with ``N == D`` is read as ONE dense inverse mass matrix, as the reference does -- tag per-chain
+    scales with ``metrics.PerChainDiag`` when the number of chains equals the dimension."""
     x = momentum_inverse_scale
     if isinstance(x, SquaredScale):
         if tuple(x.imm.shape) != (n_chains, dim) or x.imm.dtype != torch.float32 or not x.imm.is_contiguous():
@@ -240,8 +242,19 @@ def as_top_level_api(logdensity_fn: Callable, step_size, momentum_inverse_scale,
             raise ValueError("ghmc.init needs an rng_key (momentum and slice are drawn at initialisation)")
         return init(position, logdensity_fn, rng_key, chain_offset=chain_offset)
 
+    converted: dict = {}  # device -> the user's scale / matrix as ONE float32 device tensor
+
     def step_fn(rng_key, state):
-        return kernel(rng_key, state, logdensity_fn, step_size, momentum_inverse_scale, alpha, delta,
-                      chain_offset=chain_offset)
+        # A NumPy array, a CPU or a float64 tensor would otherwise become a NEW device tensor at every step: for a dense
+        # (D, D) inverse mass matrix that is an fp64 Cholesky + triangular solve per step (the metric cache is keyed
+        # on the tensor's identity).  Tagged per-chain forms and SquaredScale are device tensors already.
+        mis = momentum_inverse_scale
+        plain = not isinstance(mis, (SquaredScale, metrics.Metric, metrics.PerChainDiag, metrics.PerChainDiagTensor))
+        if plain and not callable(mis) and not isinstance(mis, (int, float)):
+            dev = state.position.device
+            if dev not in converted:
+                converted[dev] = torch.as_tensor(mis).to(device=dev, dtype=torch.float32).contiguous()
+            mis = converted[dev]
+        return kernel(rng_key, state, logdensity_fn, step_size, mis, alpha, delta, chain_offset=chain_offset)
 
     return SamplingAlgorithm(init_fn, step_fn)

@@ -718,8 +718,12 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # K ticks per leaf; + one tick per transition: the busy-phase leaf kernel finishes a transition in the
     # tick AFTER the one that completed its tree (deferred transition ends, k_nuts_async_tick3<.., DEFER>)
     max_ticks = T * (((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 1) + 4
-    if gemm_bufs is not None:  # a chain may wait for a slot of the momentum list: at most ceil(N / cap) - 1 ticks per start
-        max_ticks += T * (-(-N // gemm_bufs[5]))
+    if gemm_bufs is not None:
+        # a chain may wait for a slot of the momentum list.  Slots are handed out by atomicAdd in arbitrary order and a
+        # waiting chain competes again in the next tick, so ceil(N / cap) - 1 ticks per start is the EXPECTED wait, not a
+        # strict bound: twice that plus a constant, so that a starved chain cannot trip the "did not finish
+        # within its tick bound" error spuriously (the bound only exists to stop a runaway loop)
+        max_ticks += 2 * T * (-(-N // gemm_bufs[5])) + 64
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
