@@ -249,18 +249,17 @@ typedef struct {
   float *adapt_mean, *adapt_m2; /* (N, D) Welford state, in/out */
   float* adapt_imm;           /* (N, D) per-chain diagonal inverse mass matrix, in/out */
   float* out_step_size;       /* optional (n_steps, N): the step size after the update of transition t */
-  /* Optional work buffers of the low-traffic tick kernels (diagonal metric, D % 4 == 0, D <= 512,
-   * 16-byte aligned buffers): rec = (N, BJX_NUTS_REC_WORDS) packed per-chain scalars (every scalar
-   * a leaf needs in one 128-byte line; the kernels own the layout, the caller only zero-fills it
-   * before the first tick), front_p = (N, D) momentum of the trajectory end that is integrating.
-   * Both NULL: the general kernels over the fs / is slot tables are used. */
+  /* Optional work buffers of the lean tick kernel (k_nuts_async_tick3: diagonal metric, D % 4 == 0, D <= 1 024,
+   * 16-byte aligned buffers; engine-resident targets: D <= 512): rec = (N, BJX_NUTS_REC_WORDS) packed per-chain
+   * scalars (every scalar a leaf needs in one 128-byte line; the kernels own the layout, the caller only zero-fills
+   * it before the first tick), front_p = (N, D) momentum of the trajectory end that is integrating.
+   * Both NULL: the general one-launch tick over the fs / is slot tables is used (k_nuts_async_fused). */
   int32_t* rec;
   float* front_p;
-  /* Optional work lists of the two-kernel ticks (both or neither): end_list = (2, N) compact rows
-   * whose transition ended in this tick's first kernel, end_count = int32[2], zeroed by the caller
-   * before the first tick; list `tick & 1` is used by tick number `tick`, which the caller advances
-   * by one per call (only its parity matters: a recorded sequence of an even number of ticks can be
-   * replayed). */
+  /* Work lists.  ABI 5 (round 5): the two-kernel ticks that used them are gone -- a transition end is now served
+   * by the chain's own wave in the NEXT tick's launch -- so for the diagonal-metric ticks end_list / end_count /
+   * tick are ignored (callers may pass NULL / 0).  GEMM mode (gemm_pc != NULL) still needs them: end_list = (2, N)
+   * chain and compact row of every slot of a tick's momentum list, end_count = int32[1]. */
   int32_t* end_list;
   int32_t* end_count;
   int32_t tick;
