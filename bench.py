@@ -1279,8 +1279,11 @@ def sub_configs(args, ctx):
         except Exception as e:  # a sub-object never fails the headline
             out[name] = {"value": None, "error": repr(e)[:400]}
 
+    # order: the MFMA-bound config right behind the HBM-bound headline, the latency-bound NUTS run after it (a long
+    # stretch of few-row launches leaves the chip in a lower power state, and a launch-level figure measured right
+    # behind it read 3-5 % low: 86-88 us where the same build measures 82-84 on its own, NOTEBOOK.md section 16)
+    run("c5_dense", lambda a: bench_c5(a, ctx), steps=10, warmup=6)
     run("c3_nuts", lambda a: bench_c3(a, ctx), steps=100, warmup=4)
-    run("c5_dense", lambda a: bench_c5(a, ctx), steps=10, warmup=2)
     run("c4_shard", lambda a: bench_c4(a, ctx), steps=200, warmup=3, leapfrogs=50)
     if "c4_shard" in out and out["c4_shard"].get("value") is not None:
         out["c4_shard"]["steps_note"] = ("a complete 200-step Stan schedule (the 1 000-step warm-up of configs[3] is "
