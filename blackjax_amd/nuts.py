@@ -757,7 +757,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
-    sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even: the work lists alternate per tick
+    sync_every = max(2, int(sync_every) + (int(sync_every) & 1))  # even (GEMM mode alternates its momentum lists per tick)
     import os as _os
 
     graph_max_rows = int(_os.environ.get("BJX_NUTS_TAIL_ROWS", graph_max_rows))

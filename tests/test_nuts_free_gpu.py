@@ -233,8 +233,8 @@ def test_fused_target_ticks_equal_the_external_callable_path(dev, target, N, D, 
     """``run(..., fuse_target=True)``: the tick kernels evaluate the library's own target themselves (one
     launch per tick, bjx_nuts_async_t.target_kind) with the device function the stand-alone target kernel
     runs -- every record, position and the final state are bit for bit those of the default path (two
-    launches per tick).  9 000 rows: the two-kernel ticks + work list; the small cases: one-launch ticks and
-    the recorded tail."""
+    launches per tick).  9 000 rows: the multi-tick kernel over a large batch; the small cases: the same kernel on the
+    recorded tail's fixed-capacity buffers."""
     import blackjax_amd as bjx
 
     g = torch.Generator(device=dev)

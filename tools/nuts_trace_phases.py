@@ -15,7 +15,7 @@ bucket = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 def kind(name):
     if "async_tick3<" in name:  # round 4: the lean leaf (with deferred transition ends: the whole tick)
         return "leaf"
-    if "async_tick2<" in name:  # k_nuts_async_tick2<NI, MODE, WAVES>: MODE 0 leaf, 1 end, 2 fused
+    if "async_tick2<" in name:  # k_nuts_async_tick2<NI, MODE, WAVES> (traces of rounds 2-4 only: removed in round 5): MODE 0 leaf, 1 end, 2 fused
         mode = name.split("async_tick2<")[1].split(",")[1].strip()
         return {"0": "leaf", "1": "end", "2": "fused"}.get(mode, "other")
     for key, k in (("async_leaf", "leaf"), ("async_end2", "end"), ("async_boundary", "end"),
