@@ -772,7 +772,11 @@ def bench_c2(args, ctx):
     # (b) wrapped in torch.compile (Inductor, if it works on this image) -- what a PyTorch user can do about the
     # autograd line above without writing HIP
     torch_elementwise_mode = torch_compile_mode = None
-    if extras and not args.no_torch_callable:
+    if extras and not args.no_torch_callable and world > 1:
+        # measure() contains barriers: a compile that fails on ONE rank only (ranks racing for the same Inductor / hiprtc
+        # cache) would leave the others waiting -- these two modes are single-GPU measurements
+        torch_elementwise_mode = torch_compile_mode = {"value": None, "skipped": "single-GPU runs only"}
+    elif extras and not args.no_torch_callable:
         k_t = max(2, args.steps // 4)
         try:
             t_c = time.perf_counter()
