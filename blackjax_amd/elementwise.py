@@ -221,7 +221,11 @@ def trace(fn: Callable, dim: int, device="cpu") -> ElementwiseSource:
     """``fn`` -> device source of a ``DeviceTarget`` struct (no GPU needed).  See the module docstring."""
     import torch.fx as fx
 
-    gm = fx.symbolic_trace(fn if isinstance(fn, torch.nn.Module) else _Wrap(fn))
+    try:
+        gm = fx.symbolic_trace(fn if isinstance(fn, torch.nn.Module) else _Wrap(fn))
+    except Exception as e:  # data-dependent control flow, shape arithmetic on q, ...: not an element-wise expression
+        raise NotImplementedError(f"from_elementwise: torch.fx could not trace the function ({type(e).__name__}: {e}); "
+                                  "pass the plain callable instead") from e
     gen = _Gen(dim, device)
     env: dict = {}
     out = None

@@ -43,6 +43,8 @@ def test_what_is_refused_says_why():
                       (lambda q: q * q, "sum over the last axis")):
         with pytest.raises(NotImplementedError, match=word):
             ew.trace(bad, D)
+    with pytest.raises(NotImplementedError, match="could not trace"):
+        ew.trace(lambda q: (q * q).sum(-1) if q.sum() > 0 else q.sum(-1), D)  # data-dependent control flow
     with pytest.raises(NotImplementedError, match="1 024"):
         bjx.targets.from_elementwise(FUNCTIONS["readme"], 2048, device="cpu")
 
