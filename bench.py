@@ -1059,6 +1059,18 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
 
     dt, per, _ = timed_region(ctx, whole_run, 1)
     st_run, _, rinfo = box["res"]
+    from blackjax_amd import _nuts as _bnuts
+
+    def spec_stats():
+        """counters of the run's two-stream speculative tail (include/bjx_nuts.h; empty when it was not taken)"""
+        st = dict(_bnuts._SPEC_STATS)
+        if st:
+            leaves = st["sequences"] * 64
+            st["us_per_leapfrog_stream_a"] = st["seconds"] / max(leaves, 1) * 1e6
+            st["wasted_share_of_pushed"] = st["stale"] / max(st["pushed"], 1)
+        return st or None
+
+    spec_T = spec_stats()
     steps_pc = rinfo.num_integration_steps.sum(0)  # (N,) leapfrogs of each chain over the run
     mine = torch.stack([steps_pc.sum().double(), steps_pc.max().double(),
                         rinfo.num_trajectory_expansions.float().mean().double(),
@@ -1085,7 +1097,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         t400 = {"value": tot4 / dt4, "unit": "chain-leapfrog-steps/s", "transitions": 400, "seconds": dt4,
                 "ms_per_transition": dt4 / 400 * 1e3, "frac_of_52B_roofline": tot4 / dt4 / (HBM_PEAK_GBS * 1e9 / (52.0 * D)),
                 "busiest_chain_leapfrogs": ticks4 - 400, "ticks_lower_bound": ticks4, "tick_period_avg_us": dt4 / max(ticks4, 1) * 1e6,
-                "utilisation": tot4 / (N * max(ticks4, 1))}
+                "utilisation": tot4 / (N * max(ticks4, 1)), "speculative_tail": spec_stats()}
         del ri4
 
     # ---- lockstep step(): the only call the reference's API has
@@ -1175,6 +1187,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         "ticks": ticks, "utilisation": tot / (world * N * max(ticks, 1)),
         "tick_period_avg_us": dt / max(ticks, 1) * 1e6,
         "mean_depth": float(pooled[:, 2].mean()), "frac_divergent": float(pooled[:, 3].mean()),
+        "speculative_tail": spec_T,
         "free_running_T400": t400,
         "lockstep_step": {
             "value": tot_l / dt_l, "unit": "chain-leapfrog-steps/s", "steps": lockstep_steps,

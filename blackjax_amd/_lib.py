@@ -213,6 +213,32 @@ SIGNATURES.update({
                                c_void_p, c_void_p],
 })
 
+class NutsSpec(ctypes.Structure):
+    """ctypes mirror of ``bjx_nuts_spec_t`` (include/bjx_nuts.h): the two-stream speculative tail of a run."""
+
+    _fields_ = [
+        ("n_rows", c_int64), ("n_rows_dev", c_void_p), ("rows", c_void_p),
+        ("ring", ctypes.c_int32), ("lead", ctypes.c_int32),
+        ("qf", c_void_p), ("fp", c_void_p),
+        ("eLq", c_void_p), ("eLp", c_void_p), ("eLg", c_void_p),
+        ("eRq", c_void_p), ("eRp", c_void_p), ("eRg", c_void_p),
+        ("iw", c_void_p), ("ring_g", c_void_p), ("ring_tag", c_void_p), ("avail", c_void_p), ("ack", c_void_p),
+        ("qf_book", c_void_p), ("bw", c_void_p), ("a_seq", c_void_p), ("dbg", c_void_p),
+    ]
+
+
+NUTS_SPEC_IW = 8   # BJX_NUTS_SPEC_IW
+NUTS_SPEC_TAG = 8  # BJX_NUTS_SPEC_TAG
+
+SIGNATURES.update({
+    "bjx_nuts_spec_enter": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), POINTER(NutsSpec)],
+    "bjx_nuts_spec_integrate": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), POINTER(NutsSpec), _f32p, _f32p,
+                                ctypes.c_int32],
+    "bjx_nuts_spec_book": [c_void_p, POINTER(NutsDesc), POINTER(NutsAsync), POINTER(NutsSpec), ctypes.c_int32,
+                           ctypes.c_int32],
+    "bjx_stream_probe": [c_void_p, c_void_p, c_void_p, ctypes.c_int32],
+})
+
 # include/bjx_pool.h (pooled cross-chain statistics; bjx_pool_workspace_bytes returns int64, see load())
 _f64p = c_void_p
 SIGNATURES.update({

@@ -471,6 +471,37 @@ def free_running_supports(integrator, metric_kind: str, dim: int) -> bool:
             and integrator.num_gradients_per_step - 1 <= _lib.NUTS_MAX_MID)
 
 
+_SIDE_STREAMS: dict = {}  # (device index, main stream handle) -> a stream that runs CONCURRENTLY with it, or False
+
+
+def _concurrent_side_stream(dev):
+    """A stream whose launches overlap those of the current stream, or None.  HIP streams share a few hardware
+    queues (four by default) and two streams on one queue run in order, so the pair is probed once
+    (``bjx_stream_probe``: a kernel on the candidate waits for a kernel launched after it on the current stream) and
+    the answer cached per (device, current stream)."""
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, main.cuda_stream)
+    hit = _SIDE_STREAMS.get(key)
+    if hit is not None:
+        return hit or None
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    found = False
+    for _ in range(8):
+        cand = torch.cuda.Stream(device=dev)
+        if cand.cuda_stream == main.cuda_stream:
+            continue
+        flag.zero_()
+        cand.wait_stream(main)
+        _lib.call("bjx_stream_probe", cand.cuda_stream, main.cuda_stream, flag.data_ptr(), 2000)
+        torch.cuda.synchronize(dev)
+        if int(flag[1].item()) == 1:
+            found = cand
+            break
+    _SIDE_STREAMS[key] = found
+    return found or None
+
+
+_SPEC_STATS: dict = {}  # counters of the last run's speculative tail (run_free fills it; empty when the tail was not taken)
 _DENSE_GEMM_CAP = 0  # run_free(dense_gemm=True): default size of a tick's momentum list (0 = a quarter of the ensemble)
 _WARNED_LOCKSTEP_RUN: set = set()
 
@@ -521,7 +552,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
              sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
              row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet,
-             dense_gemm: bool = False, dense_gemm_cap=None):
+             dense_gemm: bool = False, dense_gemm_cap=None, spec_rows=None):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -572,6 +603,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     ``run(T)`` equals ``T`` steps bit for bit -- instead of one fp64 matrix-vector product per chain
     (``bjx_nuts_async_t.gemm_*``); at most ``dense_gemm_cap`` chains (default: a quarter of the ensemble) start a
     transition per tick, the others wait one tick.
+
+    ``spec_rows`` (default 128, ``BJX_NUTS_SPEC_ROWS`` overrides, 0 = off): once at most that many chains are live the
+    run continues on the TWO-STREAM SPECULATIVE TAIL (include/bjx_nuts.h, "Speculative tail"; diagonal metric,
+    ``D % 4 == 0``, ``D <= 1024``, one-gradient integrators, recordable external callable, no adaptation): per
+    leapfrog the latency-critical stream runs the callable and a light integrator that follows the key's direction
+    schedule, while the tree bookkeeping -- the unchanged tick arithmetic -- replays the pushed gradients on a second
+    stream and restarts the integrator at every transition end.  Same results bit for bit; the callable is
+    additionally evaluated at a few positions past the end of each transition (wasted work, 2-3 leapfrogs).
 
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``."""
@@ -969,6 +1008,121 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     torch.cuda.synchronize()
             return issued
 
+    spec_rows = int(_os.environ.get("BJX_NUTS_SPEC_ROWS", 128 if spec_rows is None else spec_rows))
+    spec_ok = (spec_rows > 0 and can_record and rec is not None and not fused and gemm_bufs is None
+               and adaptation is None and not (general and len(drift_c) > 1) and D % 4 == 0 and D <= 1024
+               and max_depth <= 30)
+    side_stream = _concurrent_side_stream(dev) if spec_ok else None  # probed once per (device, stream), then cached
+    spec_ok = spec_ok and side_stream is not None
+
+    class _SpecTail:
+        """The two-stream speculative tail (include/bjx_nuts.h): stream A = the current stream, [callable, integrate]
+        per leapfrog as one recorded sequence; stream B = ``side``, one long-lived bookkeeping launch per sequence."""
+
+        RING = 64      # ring slots per row
+        LEAD = 4       # records the integrator may run ahead of the bookkeeper's consumed count (2: stalls; 4 .. 63: flat at
+                       # D = 256, where a record costs the bookkeeper 3.2 us against 4.9 us per leaf on stream A)
+        SEQ = 64       # leapfrogs per recorded sequence of stream A (32 / 64 / 128 measured within 4 % of each other)
+        SEQ0 = 8       # plain leapfrogs before the recording (kernels, allocator warm)
+        REPS = 2       # sequences queued per host poll
+        TIMEOUT_US = 20000
+
+        def __init__(self, cap):
+            self.cap = cap
+            self.rows = torch.zeros(cap, **i32)
+            self.qf = q[:1].repeat(cap, 1)  # valid positions everywhere (see _Tail)
+            self.n_dev = torch.zeros(1, **i32)
+            mk = lambda: torch.zeros((cap, D), **f32)  # noqa: E731
+            self.fp, self.qf_book = mk(), mk()
+            self.ends = [mk() for _ in range(6)]
+            self.iw = torch.zeros((cap, _lib.NUTS_SPEC_IW), **i32)
+            self.bw = torch.zeros((cap, _lib.NUTS_SPEC_IW), **i32)
+            self.ring_g = torch.zeros((cap, self.RING, D), **f32)
+            self.ring_tag = torch.zeros((cap, self.RING, _lib.NUTS_SPEC_TAG), **i32)
+            self.avail = torch.zeros(cap, **i32)
+            self.ack = torch.zeros(cap, dtype=torch.int64, device=dev)
+            self.a_seq = torch.zeros(1, **i32)
+            self.dbg = torch.zeros(8, **i32)
+            self.run = make_run(self.rows, cap)
+            self.run.n_rows_dev = self.n_dev.data_ptr()
+            e = self.ends
+            self.spec = _lib.NutsSpec(
+                n_rows=cap, n_rows_dev=self.n_dev.data_ptr(), rows=self.rows.data_ptr(), ring=self.RING,
+                lead=self.LEAD,
+                qf=self.qf.data_ptr(), fp=self.fp.data_ptr(), eLq=e[0].data_ptr(), eLp=e[1].data_ptr(),
+                eLg=e[2].data_ptr(), eRq=e[3].data_ptr(), eRp=e[4].data_ptr(), eRg=e[5].data_ptr(),
+                iw=self.iw.data_ptr(), ring_g=self.ring_g.data_ptr(), ring_tag=self.ring_tag.data_ptr(),
+                avail=self.avail.data_ptr(), ack=self.ack.data_ptr(), qf_book=self.qf_book.data_ptr(), bw=self.bw.data_ptr(),
+                a_seq=self.a_seq.data_ptr(), dbg=self.dbg.data_ptr())
+            self.rref, self.sref = ctypes.byref(self.run), ctypes.byref(self.spec)
+            self.side = side_stream
+            self.graph = None
+            self.seq_no = 0
+            self.t_enter = __import__("time").perf_counter()
+
+        def enter(self, src_rref, src_qf):
+            """Live rows of the source batch (between two ticks) -> this tail."""
+            _lib.call("bjx_nuts_async_compact", stream, dref, src_rref, src_qf.data_ptr(), self.rows.data_ptr(),
+                      self.qf.data_ptr(), src_work.data_ptr(), self.n_dev.data_ptr())
+            _lib.call("bjx_nuts_spec_enter", stream, dref, self.rref, self.sref)
+            self.side.wait_stream(torch.cuda.current_stream(dev))
+
+        def _seq_a(self, n):
+            for i in range(n):
+                lp, g_ = eval_logdensity(vg, self.qf)
+                _lib.call("bjx_nuts_spec_integrate", _lib.current_stream(), dref, self.rref, self.sref,
+                          lp.data_ptr(), g_.data_ptr(), 1 if i == n - 1 else 0)
+
+        def _book(self):
+            self.seq_no += 1
+            with torch.cuda.stream(self.side):
+                _lib.call("bjx_nuts_spec_book", _lib.current_stream(), dref, self.rref, self.sref, self.seq_no,
+                          self.TIMEOUT_US)
+
+        def advance(self):
+            """-> leapfrogs issued on stream A"""
+            nonlocal can_record
+            # the bookkeeper of a sequence is launched BEFORE the sequence: replaying a recorded sequence keeps the host
+            # busy for about as long as the GPU needs to run it (every node is enqueued by the host), so a bookkeeper
+            # launched behind the replay started a whole sequence late (measured: a ring of lag, 26-56 wasted
+            # leapfrogs per transition end instead of 3-4)
+            if self.graph is not None:
+                for _ in range(self.REPS):
+                    self._book()
+                    self.graph.replay()
+                return self.SEQ * self.REPS
+            n0 = self.SEQ0 if can_record else self.SEQ
+            self._book()
+            self._seq_a(n0)
+            if can_record:
+                try:
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                        self._seq_a(self.SEQ)
+                    self.graph = cg
+                except Exception:
+                    if use_graph is True:
+                        raise
+                    can_record = False
+                    torch.cuda.synchronize()
+            return n0
+
+        def poll(self):
+            with torch.cuda.stream(self.side):  # the finished-chain counter is stream B's
+                return poll_done()
+
+        def finish(self):
+            torch.cuda.current_stream(dev).wait_stream(self.side)
+            d = [int(v) for v in self.dbg.tolist()]
+            pushed = int(self.iw[:, 5].sum().item())
+            _SPEC_STATS.update(rows=self.cap, pushed=pushed, mismatches=d[0], stalls=d[1], restarts=d[2], stale=d[3],
+                               timeouts=d[4], out_of_order=d[5], sequences=self.seq_no,
+                               seconds=__import__("time").perf_counter() - self.t_enter,
+                               book_us_per_record=(d[6] / 100.0 / d[7]) if d[7] else None, book_records=d[7])
+            if d[0] or d[5]:
+                raise RuntimeError(f"speculative NUTS tail: the bookkeeper's replica disagreed with the integrator "
+                                   f"({d[0]} position mismatches, {d[5]} out-of-order records) -- results discarded")
+
     # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
     # the next one gets its turn (chains are independent, so the results do not depend on the
     # grouping).  One group by default -- see auto_row_block for the measurement.
@@ -1002,12 +1156,34 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         poll["primed"] = True
         return poll["last"]
 
+    spec_ctx = None
+    _SPEC_STATS.clear()
+
+    def to_spec(src_rref, src_qf, n_live):
+        nonlocal spec_ctx, ticks_left
+        spec_ctx = _SpecTail(max(1, n_live))
+        spec_ctx.enter(src_rref, src_qf)
+        poll["last"] = max(poll["last"], N - n_live)
+        ticks_left += ticks_left // 2 + 4096  # leapfrogs speculated past transition ends, ring stalls
+
     while ticks_left > 0:
+        if spec_ctx is not None:
+            ticks_left -= spec_ctx.advance()
+            if N - spec_ctx.poll() == 0:
+                break
+            continue
         if tail_ctx is not None:
+            if spec_ok and tail_ctx.n_cur <= spec_rows:
+                to_spec(ctypes.byref(tail_ctx.run[tail_ctx.cur]), tail_ctx.qf[tail_ctx.cur], tail_ctx.n_cur)
+                tail_ctx = None
+                continue
             ticks_left -= tail_ctx.advance()
             n_active = N - poll_done()
             if n_active == 0:
                 break
+            if spec_ok and n_active <= spec_rows:
+                tail_ctx.n_cur = n_active  # (an upper bound: the count is read one batch late)
+                continue
             if tail_ctx.wants_compaction(n_active):
                 tail_ctx.compact(n_active)
             continue
@@ -1025,6 +1201,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         n_active = N - int(n_done.item())  # one host sync per chunk
         if n_active == 0:
             break
+        if spec_ok and n_active <= spec_rows and len(groups) == 1:
+            to_spec(groups[0].rref, groups[0].qf, n_active)  # few live chains: every tick is pure latency from here on
+            groups = []
+            continue
         if n_active <= n_rows // 2 and n_rows > 64:
             # drop the finished chains from the batch (device-side compaction + gather); the groups
             # are merged into one batch of the live rows
@@ -1052,8 +1232,12 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 g_.logp_f, g_.gf = eval_logdensity(vg, g_.qf)  # the gathered positions, row for row
                 groups.append(g_)
     else:
+        if spec_ctx is not None:
+            torch.cuda.current_stream(dev).wait_stream(spec_ctx.side)
         if int(n_done.item()) != N:
             raise RuntimeError("free-running NUTS did not finish within its tick bound")
+    if spec_ctx is not None:
+        spec_ctx.finish()
     return HMCState(q, logp, g), positions, info
 
 

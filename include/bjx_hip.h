@@ -37,14 +37,15 @@
 extern "C" {
 #endif
 
-#define BJX_ABI_VERSION 5 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
+#define BJX_ABI_VERSION 6 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
                              int_mid_kick / int_mid_drift, bjx_rng_key_probe added (round 4); 4: bjx_nuts_async_t gained
                              gemm_pc .. gemm_cap (round 4); 5 (round 5): same entry points and layouts -- bjx_nuts_async_tick now
                              has ONE kernel per shape and reads no environment switch (an engine-resident target is ticked
                              ticks_per_launch >= 1 times per launch whatever the batch size; run->end_list / end_count are
                              only used in GEMM mode), multi-stage integrators tick free for rows of up to 1 024 floats, and the
                              shared-dense entry points REFUSE whole 128 x 128 tiles on buffers that are not 16-byte aligned
-                             instead of reading imm transposed */
+                             instead of reading imm transposed; 6 (round 5): bjx_nuts_spec_t and bjx_nuts_spec_enter / _integrate /
+                             _book added (two-stream speculative tail of a free-running run), nothing else changed */
 
 const char* bjx_last_error(void);
 int bjx_abi_version(void);

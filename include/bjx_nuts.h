@@ -364,6 +364,85 @@ int bjx_nuts_async_compact(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_
                            const float* qf_in, int32_t* rows_out, float* qf_out, int32_t* src_work,
                            int32_t* n_out);
 
+/* ---- Speculative tail of a free-running run (round 5, ABI 6) -------------------------------------
+ *
+ * With a handful of live chains a tick is pure latency: two DEPENDENT launches per leapfrog (tick kernel, user
+ * callable), each a launch boundary plus a couple of memory round trips.  Only two things are truly serial in a NUTS
+ * leaf, though: the position update that feeds the next gradient evaluation and that evaluation.  Everything else
+ * (energy, progressive sampling, checkpoints, U-turn tests, subtree merges, transition ends) merely decides WHEN THE
+ * TRANSITION STOPS -- within a transition the sequence of integration steps is fixed by the key alone (the direction
+ * of doubling d is bernoulli(split(fold_in(integrator_key, d), 3)[0]), trajectory.py:645-650, and any stop ends the
+ * transition, trajectory.py:672-715).  So the tail runs as two host-driven streams:
+ *
+ *   stream A (latency-critical):  [ user callable on qf  ->  bjx_nuts_spec_integrate ] per leapfrog.  The integrator
+ *       closes the leaf (kick), pushes the callable's (logp, gradient) with the leaf's identity (epoch, depth, s)
+ *       into a per-row ring, and opens the next leaf ALONG THE KEY'S DIRECTION SCHEDULE, across doubling boundaries
+ *       (it keeps its own copies of the two trajectory ends) -- one memory round trip, a few fmaf per element.
+ *   stream B (off the critical path):  bjx_nuts_spec_book, one long-lived launch per recorded sequence of stream A.
+ *       Each row's wave replays the UNCHANGED tick arithmetic (the lean leaf + deferred transition end of
+ *       bjx_nuts_async_tick) over the ring records in order, on its own copy of the pending position, so every
+ *       decision, record and state it produces is bit for bit what the one-stream tick produces.  When a
+ *       transition ends it publishes the next transition's start (epoch + 1, integrator key, step size; the first
+ *       pending position / momentum are its own buffers) and the integrator, which has meanwhile speculated a few
+ *       leaves past the end, restarts from there; ring records of an older epoch are skipped.
+ *
+ * Cost: the leaves speculated past each transition end (the bookkeeper's lag: 2-3 leapfrogs) -- wasted callable
+ * evaluations at positions of a trajectory the reference would not have continued (finite or not: a diverged
+ * trajectory may overflow; the callable sees what it would see one leaf before a divergence is detected).
+ * Synchronisation is device memory only (no events between the streams): counters are agent-scope atomics, ring
+ * data is published one kernel late (a record is announced by the NEXT integrate launch, i.e. after the launch
+ * that wrote it has completed), the book side fences before reading, and the integrator fences before reading a
+ * restart.  Nothing ever spins unboundedly: the integrator returns when its ring is full or its tree is exhausted,
+ * the bookkeeper returns when stream A's sequence counter reaches `target` (or after timeout_us).
+ * Every record carries the first four floats of the integrator's position; the bookkeeper compares them with its
+ * own replica and counts mismatches in dbg[0] -- the caller must treat a non-zero count as a failed run.
+ *
+ * Diagonal metric, D % 4 == 0, D <= 1024, one-gradient integrators, external callable, no per-chain adaptation. */
+#define BJX_NUTS_SPEC_IW 8    /* int32 words per row of bjx_nuts_spec_t.iw / .bw */
+#define BJX_NUTS_SPEC_TAG 8   /* int32 words per ring slot of ring_tag */
+typedef struct {
+  int64_t n_rows;             /* capacity: rows of every buffer below and launch geometry */
+  const int32_t* n_rows_dev;  /* optional device-side live count (<= n_rows), as bjx_nuts_async_t.n_rows_dev */
+  const int32_t* rows;        /* (n_rows,) chain of spec row b (bjx_nuts_async_compact output) */
+  int32_t ring;               /* slots per row, a power of two >= 8 */
+  int32_t lead;               /* records stream A may be ahead of stream B's consumed count (<= 0: ring - 1) */
+  float* qf;                  /* (n_rows, D) stream A: the callable's input, in/out */
+  float* fp;                  /* (n_rows, D) stream A: momentum after the opening kick */
+  float *eLq, *eLp, *eLg;     /* (n_rows, D) stream A: its copy of the leftmost trajectory state */
+  float *eRq, *eRp, *eRg;     /* ... and of the rightmost */
+  int32_t* iw;                /* (n_rows, BJX_NUTS_SPEC_IW) stream A: epoch, depth, s, directions, eps, pushed, state */
+  float* ring_g;              /* (n_rows, ring, D) gradients pushed by A */
+  int32_t* ring_tag;          /* (n_rows, ring, BJX_NUTS_SPEC_TAG): epoch, depth, s, logp bits, 4 position words */
+  int32_t* avail;             /* (n_rows,) records announced by A */
+  int64_t* ack;               /* (n_rows,) A -> B: (epoch << 32) | number of the first record of that epoch */
+  float* qf_book;             /* (n_rows, D) stream B: its replica of the pending position */
+  int32_t* bw;                /* (n_rows, BJX_NUTS_SPEC_IW) stream B -> A: epoch (-1 = chain finished), consumed, key, eps */
+  int32_t* a_seq;             /* int32[1]: sequences completed by stream A (bumped by integrate launches with bump != 0) */
+  int32_t* dbg;               /* int32[8]: 0 replica mismatches (must stay 0), 1 ring-full stalls, 2 restarts, 6 / 7 book time (100 MHz ticks) / records,
+                                 3 stale records skipped, 4 book time-outs, 5 out-of-order records (must stay 0) */
+} bjx_nuts_spec_t;
+
+/* Hand the rows over to the speculative tail: spec->rows / spec->qf (and *n_rows_dev) hold the output of
+ * bjx_nuts_async_compact for the live chains, each between two ticks (a leaf awaiting its gradient, or a
+ * transition end pending).  Fills every other buffer of `spec`. */
+int bjx_nuts_spec_enter(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run, const bjx_nuts_spec_t* spec);
+
+/* Stream A, once per leapfrog after the callable: logp_f (n_rows,), gf (n_rows, D) = callable outputs at spec->qf.
+ * bump != 0: the launch also counts a completed sequence in *a_seq (last launch of a recorded sequence). */
+int bjx_nuts_spec_integrate(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run,
+                            const bjx_nuts_spec_t* spec, const float* logp_f, const float* gf, int32_t bump);
+
+/* Stream B: consume ring records until *a_seq >= target (and the ring is drained) or timeout_us have passed. */
+int bjx_nuts_spec_book(void* stream, const bjx_nuts_t* nuts, const bjx_nuts_async_t* run,
+                       const bjx_nuts_spec_t* spec, int32_t target, int32_t timeout_us);
+
+/* Do launches on stream_wait and stream_set overlap?  (HIP streams share a small number of hardware queues; two
+ * streams that landed on the same queue run in order, and the speculative tail must not be used with such a pair.)
+ * Launches a one-wave kernel on stream_wait that spins until a kernel launched AFTER it on stream_set has set
+ * flag2[0], or timeout_us have passed; flag2 (device int32[2], zero on entry) reads {1, 1} afterwards when the two
+ * launches overlapped, {., 2} when they did not.  The caller synchronises and reads flag2. */
+int bjx_stream_probe(void* stream_wait, void* stream_set, int32_t* flag2, int32_t timeout_us);
+
 #ifdef __cplusplus
 }
 #endif

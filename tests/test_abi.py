@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
     assert lib.bjx_pool_workspace_bytes(0, 8) == 0
     assert lib.bjx_pool_workspace_bytes(65536, 1024) == 512 * 4 * 1024 * 8  # 512 slabs x K=4 x D doubles
-    assert lib.bjx_abi_version() == 5  # 5 (round 5): one tick kernel per shape, no kernel-selecting environment switches
+    assert lib.bjx_abi_version() == 6  # 6 (round 5): + the speculative-tail entry points (bjx_nuts_spec_*)
 
 
 def test_error_reporting_without_gpu():
@@ -94,3 +94,25 @@ def test_nuts_descriptor_and_slots_match_header():
     for name, i in _lib.NUTS_AT.items():
         assert enums["BJX_NUTS_AT_" + name] == i
     assert enums["BJX_NUTS_ADAPT_COLS"] == _lib.NUTS_ADAPT_COLS
+
+
+def test_spec_tail_descriptor_matches_header():
+    """ctypes mirror of bjx_nuts_spec_t (the two-stream speculative tail, ABI 6)."""
+    from blackjax_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "bjx_nuts.h")).read()
+    text_nc = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*?)\} bjx_nuts_spec_t;", text_nc, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int64_t|int32_t|uint32_t|float)\s*\*?", "", decl)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in _lib.NutsSpec._fields_], names
+    assert ctypes.sizeof(_lib.NutsSpec) == 8 * 3 + 4 * 2 + 8 * 17
+    assert int(re.search(r"#define BJX_NUTS_SPEC_IW (\d+)", text_nc).group(1)) == _lib.NUTS_SPEC_IW
+    assert int(re.search(r"#define BJX_NUTS_SPEC_TAG (\d+)", text_nc).group(1)) == _lib.NUTS_SPEC_TAG
+    lib = _lib.load()  # argument checking happens before any device work
+    assert lib.bjx_nuts_spec_book(None, None, None, None, 0, 0) != 0 and b"bjx_nuts_spec_book" in lib.bjx_last_error()

@@ -1,0 +1,129 @@
+"""Two-stream speculative tail of a free-running NUTS run (include/bjx_nuts.h "Speculative tail",
+blackjax_amd.nuts.run_free(spec_rows=...)): the light integrator on the latency-critical stream and the
+bookkeeper that replays the tick arithmetic on a second stream must reproduce the one-stream tail bit for bit --
+every per-transition record, every stored position, the final state -- and, through it, the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import blackjax_amd as bjx
+from blackjax_amd import _nuts as bnuts
+from oracle import hmc as ohmc
+from oracle import nuts as onuts
+from oracle import prng, targets as otargets
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _run(dev, fn, q0, eps, imm, T, max_depth, spec_rows, key=7, integrator=None, **kw):
+    st0 = bnuts.init(q0, fn)
+    extra = {} if integrator is None else {"integrator": integrator}
+    out = bnuts.run_free(bjx.random.key(key), st0, fn, eps, imm, T, max_depth, spec_rows=spec_rows, **extra, **kw)
+    return out, dict(bnuts._SPEC_STATS)
+
+
+def _assert_same(a, b):
+    (fa, pa, ia), (fb, pb, ib) = a, b
+    assert torch.equal(fa.position, fb.position)
+    assert torch.equal(fa.logdensity, fb.logdensity)
+    assert torch.equal(fa.logdensity_grad, fb.logdensity_grad)
+    if pa is not None:
+        assert torch.equal(pa, pb)
+    for name in ("logdensity", "acceptance_rate", "energy", "num_integration_steps", "num_trajectory_expansions",
+                 "is_divergent", "is_turning"):
+        x, y = getattr(ia, name), getattr(ib, name)
+        assert torch.equal(x, y) or (x.is_floating_point() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))), name
+
+
+@pytest.mark.parametrize("N,D,T,max_depth,eps", [
+    (24, 16, 12, 6, 0.2),     # spec tail from the first chunk on (N <= spec_rows)
+    (5, 256, 10, 8, 0.08),    # deep trees, one piece per lane fully used
+    (40, 512, 12, 7, 0.1),    # two pieces per lane
+    (9, 772, 12, 6, 0.1),     # three pieces, ragged last piece
+    (3, 1024, 12, 6, 0.1),    # four pieces
+    (1, 8, 30, 9, 0.05),      # a single chain
+])
+def test_spec_tail_equals_one_stream_tail_funnel(dev, N, D, T, max_depth, eps):
+    g = torch.Generator(device=dev)
+    g.manual_seed(N * 1000 + D)
+    q0 = 0.3 * torch.randn(N, D, device=dev, generator=g)
+    fn = bjx.targets.NealFunnel()
+    imm = torch.ones(D, device=dev)
+    ref, st_off = _run(dev, fn, q0, eps, imm, T, max_depth, spec_rows=0)
+    assert st_off == {}
+    got, st = _run(dev, fn, q0, eps, imm, T, max_depth, spec_rows=128)
+    assert st and st["mismatches"] == 0 and st["out_of_order"] == 0 and st["timeouts"] == 0, st
+    assert st["restarts"] >= 1, st  # transition ends after the hand-over restart the integrator
+    _assert_same(ref, got)
+    useful = int(ref[2].num_integration_steps.sum())
+    assert st["pushed"] <= useful + 64 * st["restarts"] + 64 * N, (st, useful)  # bounded waste per transition end
+
+
+def test_spec_tail_after_busy_phase_and_one_stream_tail(dev):
+    """2 048 chains: busy phase -> one-stream tail -> speculative tail (hand-over mid-tree, lagged counts)."""
+    N, D, T = 2048, 64, 10
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    q0 = 0.1 * torch.randn(N, D, device=dev, generator=g)
+    fn = bjx.targets.NealFunnel()
+    imm = torch.ones(D, device=dev)
+    ref, _ = _run(dev, fn, q0, 0.1, imm, T, 9, spec_rows=0)
+    got, st = _run(dev, fn, q0, 0.1, imm, T, 9, spec_rows=64)
+    assert st and st["mismatches"] == 0 and st["out_of_order"] == 0, st
+    assert 1 <= st["rows"] <= 64
+    _assert_same(ref, got)
+    # chain-major keys, per-chain step sizes and a per-chain diagonal metric, positions not stored
+    eps = 0.05 + 0.1 * torch.rand(N, device=dev, generator=g)
+    immc = bjx.metrics.PerChainDiag(0.5 + torch.rand(N, D, device=dev, generator=g))
+    kw = dict(key_layout="chain_major", store_positions=False)
+    ref2, _ = _run(dev, fn, q0, eps, immc, 5, 8, spec_rows=0, **kw)
+    got2, st2 = _run(dev, fn, q0, eps, immc, 5, 8, spec_rows=100, **kw)
+    assert st2 and st2["mismatches"] == 0 and st2["out_of_order"] == 0, st2
+    _assert_same(ref2, got2)
+
+
+def test_spec_tail_matches_oracle_gaussian_with_divergences(dev):
+    """Straight against the NumPy oracle (oracle/nuts.py), ill-conditioned Gaussian with a step size that diverges
+    now and then: tree sizes, flags and positions per transition."""
+    N, D, T, max_depth = 12, 32, 6, 7
+    sig = (10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(f32)
+    inv_var = (f32(1) / (sig * sig)).astype(f32)
+    q0 = (prng.normal(prng.key(1), (N, D)) * sig).astype(f32)
+    fn_o = otargets.diag_gaussian(inv_var)
+    fn_g = bjx.targets.DiagGaussian(torch.as_tensor(inv_var, device=dev))
+    eps = f32(0.19)
+    run_key = prng.key(42)
+    st0 = bnuts.init(torch.as_tensor(q0, device=dev), fn_g)
+    final, positions, info = bnuts.run_free(run_key, st0, fn_g, float(eps), torch.ones(D, device=dev), T, max_depth,
+                                            divergence_threshold=50, spec_rows=128)
+    st = dict(bnuts._SPEC_STATS)
+    assert st and st["mismatches"] == 0 and st["out_of_order"] == 0, st
+    st_o = ohmc.init(q0, fn_o)
+    for t in range(T):
+        st_o, info_o = onuts.kernel(prng.split(run_key, T)[t], st_o, fn_o, eps, np.ones(D, f32), max_depth,
+                                    divergence_threshold=50)
+        assert np.array_equal(info.num_integration_steps[t].cpu().numpy(), info_o.num_integration_steps), t
+        assert np.array_equal(info.is_divergent[t].cpu().numpy(), info_o.is_divergent)
+        assert np.array_equal(info.is_turning[t].cpu().numpy(), info_o.is_turning)
+        np.testing.assert_allclose(positions[t].cpu().numpy(), st_o.position, rtol=1e-6, atol=1e-6)
+
+
+def test_spec_tail_plain_torch_callable(dev):
+    """An external PyTorch callable (hand-written value-and-gradient pair, declared recordable)."""
+    N, D, T = 16, 64, 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    scale = torch.linspace(0.5, 2.0, D, device=dev)
+
+    def pair(x):
+        gr = -(x * scale)
+        return 0.5 * (x * gr).sum(-1), gr
+
+    fn = bjx.capturable(bjx.returns_pair(pair))
+    imm = torch.ones(D, device=dev)
+    ref, _ = _run(dev, fn, q0, 0.3, imm, T, 6, spec_rows=0)
+    got, st = _run(dev, fn, q0, 0.3, imm, T, 6, spec_rows=128)
+    assert st and st["mismatches"] == 0 and st["out_of_order"] == 0, st
+    _assert_same(ref, got)
