@@ -187,7 +187,7 @@ class NutsAsync(ctypes.Structure):
         ("adapt_mu", c_void_p), ("adapt_step_size", c_void_p), ("adapt_mean", c_void_p),
         ("adapt_m2", c_void_p), ("adapt_imm", c_void_p), ("out_step_size", c_void_p),
         ("rec", c_void_p), ("front_p", c_void_p), ("end_list", c_void_p), ("end_count", c_void_p),
-        ("tick", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("n_rows_dev", c_void_p),
+        ("tick", ctypes.c_int32), ("keep_ends", ctypes.c_int32), ("n_rows_dev", c_void_p),
         ("mass_sqrt_t", c_void_p), ("v0", c_void_p),
         ("target_kind", ctypes.c_int32), ("ticks_per_launch", ctypes.c_int32), ("target_vec", c_void_p),
         ("int_stages", ctypes.c_int32), ("reserved3", ctypes.c_int32),

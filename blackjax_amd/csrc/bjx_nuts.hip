@@ -1193,9 +1193,11 @@ enum {
   RW_PW = RW_U0 + 4, RW_PSLPA, RW_PLOGP, RW_PENERGY, RW_ACC, RW_NSTATES, RW_KP, RW_KPB, RW_IK, RW_IKB,
   RW_DIV, RW_TURN,
   RW_END,
-  RW_STAGE = RW_END  // multi-stage integrators (bjx_nuts_async_t.int_stages > 1): gradients of the leaf in flight already used
+  RW_STAGE = RW_END,  // multi-stage integrators (bjx_nuts_async_t.int_stages > 1): gradients of the leaf in flight already used
+  RW_LLOGP = RW_END + 1, RW_RLOGP  // bjx_nuts_async_t.keep_ends: log-density of the leftmost / rightmost trajectory state
 };
-static_assert(RW_U0 == 12 && RW_PW == 16 && RW_END == 28 && RW_STAGE < BJX_NUTS_REC_WORDS, "record layout");
+static_assert(RW_U0 == 12 && RW_PW == 16 && RW_END == 28 && RW_STAGE < BJX_NUTS_REC_WORDS && RW_RLOGP < BJX_NUTS_REC_WORDS,
+              "record layout");
 
 __device__ __forceinline__ int rec_i(int w, int k) { return __builtin_amdgcn_readlane(w, k); }
 __device__ __forceinline__ float rec_f(int w, int k) { return __int_as_float(__builtin_amdgcn_readlane(w, k)); }
@@ -2211,6 +2213,34 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
   bool done = false;
   if (!grow) {  // the transition is complete
     rw[RW_LAZY] = lazy;
+    if (ax.keep_ends) {
+      // NUTSInfo.trajectory_leftmost_state / rightmost_state (nuts.py:66-70): the end that was moving is in registers,
+      // the other one is parked in its arrays -- or still the transition's initial state (lazy), copied now
+      // because the chain state is about to be replaced by the accepted proposal
+      float* mq = (dir > 0 ? nt.Rq : nt.Lq) + base;
+      float* mg = (dir > 0 ? nt.Rg : nt.Lg) + base;
+      float* mp = (dir > 0 ? nt.Rp : nt.Lp) + base;
+      const bool z0 = (lazy & other_bit) != 0;
+      float* oq = (dir > 0 ? nt.Lq : nt.Rq) + base;
+      float* og = (dir > 0 ? nt.Lg : nt.Rg) + base;
+      float* opw = (dir > 0 ? nt.Lp : nt.Rp) + base;
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+        if (ok[k]) {
+          str<VEC>(mq + j0[k], R.X[k]);
+          str<VEC>(mg + j0[k], R.G[k]);
+          str<VEC>(mp + j0[k], R.P[k]);
+          if (z0) {
+            str<VEC>(oq + j0[k], ldr<VEC>(nt.q0 + base + j0[k]));
+            str<VEC>(og + j0[k], ldr<VEC>(nt.g0 + base + j0[k]));
+            str<VEC>(opw + j0[k], OP[k]);  // (loaded from p0 above)
+          }
+        }
+      if (g == 0) {
+        recp[dir > 0 ? RW_RLOGP : RW_LLOGP] = __float_as_int(lp);
+        if (z0) recp[dir > 0 ? RW_LLOGP : RW_RLOGP] = __float_as_int(ax.logp[c]);
+      }
+    }
     if (g == 0) ax.phase[c] = 3;
     done = true;
   } else {
@@ -2246,6 +2276,7 @@ __device__ __forceinline__ bool async_leaf3_row(const bjx_nuts_t& nt, const bjx_
       float* eg = (dir > 0 ? nt.Rg : nt.Lg) + base;
       float* ep = (dir > 0 ? nt.Rp : nt.Lp) + base;
       const bool z0 = (lazy & other_bit) != 0;
+      if (ax.keep_ends && g == 0) recp[dir > 0 ? RW_RLOGP : RW_LLOGP] = __float_as_int(lp);
       const float* oq = (z0 ? nt.q0 : (dir2 > 0 ? nt.Rq : nt.Lq)) + base;
       const float* og = (z0 ? nt.g0 : (dir2 > 0 ? nt.Rg : nt.Lg)) + base;
 #pragma unroll

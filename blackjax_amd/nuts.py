@@ -552,7 +552,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
              sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
              row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet,
-             dense_gemm: bool = False, dense_gemm_cap=None, spec_rows=None):
+             dense_gemm: bool = False, dense_gemm_cap=None, spec_rows=None, keep_ends: bool = False,
+             _handle: Optional[dict] = None):
     """``num_steps`` NUTS transitions of every chain WITHOUT lockstep (include/bjx_nuts.h,
     "free-running chains"): per tick each chain integrates one leapfrog of its own current tree and
     a chain that completes a transition starts its next one at once, so the user callable always
@@ -612,6 +613,16 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     stream and restarts the integrator at every transition end.  Same results bit for bit; the callable is
     additionally evaluated at a few positions past the end of each transition (wasted work, 2-3 leapfrogs).
 
+    ``keep_ends`` (lean tick kernels: diagonal metric, ``D % 4 == 0``, ``D <= 1024``): every chain leaves the two ends of
+    its LAST transition's trajectory in the work arrays (``bjx_nuts_async_t.keep_ends``) -- what ``step`` needs for
+    ``NUTSInfo.trajectory_leftmost_state`` / ``rightmost_state``.
+
+    ``_handle`` (private; ``key_layout="step"``, a plain key, no adaptation / fuse_target / dense_gemm): a dict that makes
+    the call PERSISTENT -- every buffer is owned by the workspace and the per-call inputs (state, key, step size,
+    metric) are copied into static buffers, so the recorded tail sequences survive the call; the dict then holds
+    ``rerun(rng_key, state, step_size, inverse_mass_matrix)``, which repeats the run on the same workspace without
+    any allocation or recording, and ``work`` (the arrays ``keep_ends`` fills).  Results of a persistent call are clones.
+
     Returns ``(final_state, positions, info)``: ``positions`` is ``(num_steps, N, D)`` (``None`` when
     ``store_positions=False``), ``info`` a ``NUTSRunInfo``."""
     import numpy as np
@@ -634,6 +645,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     vg = value_and_grad(logdensity_fn)
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
+    persistent = _handle is not None
+    if persistent and (key_layout != "step" or adaptation is not None or fuse_target or dense_gemm
+                       or bjx_random.key_spec(rng_key)[2] >= 0 or N == 0):
+        raise ValueError("a persistent free-running workspace serves key_layout='step' with a plain key, without "
+                         "adaptation, fuse_target or dense_gemm")
     adapt_fields = {}
     out_step_size = None
     if adaptation is not None:
@@ -672,6 +688,13 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     if gemm and (metric.kind != "dense" or general or fuse_target):
         raise NotImplementedError("dense_gemm=True: one shared dense inverse mass matrix, velocity Verlet, no fuse_target")
     eps, eps_pc = step_size_args(step_size, N, dev)
+    eps_buf = imm_buf = None
+    if persistent:  # static copies: recorded launches carry the descriptors by value
+        eps_buf = torch.empty(N, **f32)
+        eps_buf.fill_(eps) if eps_pc is None else eps_buf.copy_(eps_pc)
+        imm_buf = metric.imm.clone()
+        metric = metric._replace(imm=imm_buf)
+        eps, eps_pc = 0.0, eps_buf
     if adaptation is not None and (eps_pc is None or eps_pc.data_ptr() != adaptation["step_size"].data_ptr()
                                    or metric.imm.data_ptr() != adaptation["imm"].data_ptr()
                                    or metric.imm_stride != D):
@@ -750,6 +773,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         rec=_lib.ptr(rec), front_p=_lib.ptr(front_p), end_list=end_list.data_ptr(),
         end_count=end_count.data_ptr(), mass_sqrt_t=_lib.ptr(metric.mass_sqrt_t if v0 is not None else None),
         v0=_lib.ptr(v0), **adapt_fields)
+    if keep_ends:
+        if rec is None or fuse_target or D % 4 != 0 or D > 1024:
+            raise NotImplementedError("keep_ends is served by the lean tick kernels: diagonal metric, D % 4 == 0, D <= 1024, "
+                                      "external callable")
+        run.keep_ends = 1
     if gemm_bufs is not None:
         (run.gemm_pc, run.gemm_vc, run.gemm_z, run.gemm_pm, run.gemm_vm) = (b.data_ptr() for b in gemm_bufs[:5])
         run.gemm_cap = gemm_bufs[5]
@@ -1123,18 +1151,6 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 raise RuntimeError(f"speculative NUTS tail: the bookkeeper's replica disagreed with the integrator "
                                    f"({d[0]} position mismatches, {d[5]} out-of-order records) -- results discarded")
 
-    # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
-    # the next one gets its turn (chains are independent, so the results do not depend on the
-    # grouping).  One group by default -- see auto_row_block for the measurement.
-    rb = auto_row_block(N, D) if row_block is None else int(row_block)
-    blk = N if not rb or rb >= N else rb
-    groups = []
-    for s0 in range(0, N, blk):
-        n_g = min(blk, N - s0)
-        rows_g = None if blk >= N else torch.arange(s0, s0 + n_g, **i32)
-        groups.append(_Group(rows_g, n_g, qf[s0:s0 + n_g]))
-    tail_ctx = None
-    ticks_left = max_ticks
     # Lagged completion polling for the tail: the finished-chain count is copied to pinned host memory
     # behind every batch of replays and the host reads the copy of the PREVIOUS batch, so the next
     # batch is always queued before the host waits -- the GPU never idles on the round trip of a
@@ -1156,89 +1172,159 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         poll["primed"] = True
         return poll["last"]
 
-    spec_ctx = None
-    _SPEC_STATS.clear()
+    groups: list = []
+    tail_ctx = spec_ctx = None
+    ticks_left = max_ticks
+    static = {"tail": None, "spec": None}  # persistent workspace: the tails (and their recorded sequences) of earlier calls
 
     def to_spec(src_rref, src_qf, n_live):
         nonlocal spec_ctx, ticks_left
-        spec_ctx = _SpecTail(max(1, n_live))
+        if persistent:  # fixed capacity: one recording serves every call
+            if static["spec"] is None:
+                static["spec"] = _SpecTail(max(1, min(N, spec_rows)))
+            spec_ctx = static["spec"]
+            spec_ctx.dbg.zero_()
+            spec_ctx.t_enter = __import__("time").perf_counter()
+        else:
+            spec_ctx = _SpecTail(max(1, n_live))
         spec_ctx.enter(src_rref, src_qf)
         poll["last"] = max(poll["last"], N - n_live)
         ticks_left += ticks_left // 2 + 4096  # leapfrogs speculated past transition ends, ring stalls
 
-    while ticks_left > 0:
-        if spec_ctx is not None:
-            ticks_left -= spec_ctx.advance()
-            if N - spec_ctx.poll() == 0:
-                break
-            continue
-        if tail_ctx is not None:
-            if spec_ok and tail_ctx.n_cur <= spec_rows:
-                to_spec(ctypes.byref(tail_ctx.run[tail_ctx.cur]), tail_ctx.qf[tail_ctx.cur], tail_ctx.n_cur)
-                tail_ctx = None
+    def execute():
+        """The run itself, on the buffers set up above (a persistent workspace calls it once per transition)."""
+        nonlocal groups, tail_ctx, spec_ctx, ticks_left
+        # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
+        # the next one gets its turn (chains are independent, so the results do not depend on the
+        # grouping).  One group by default -- see auto_row_block for the measurement.
+        rb = auto_row_block(N, D) if row_block is None else int(row_block)
+        blk = N if not rb or rb >= N else rb
+        groups = []
+        for s0 in range(0, N, blk):
+            n_g = min(blk, N - s0)
+            rows_g = None if blk >= N else torch.arange(s0, s0 + n_g, **i32)
+            groups.append(_Group(rows_g, n_g, qf[s0:s0 + n_g]))
+        tail_ctx = spec_ctx = None
+        ticks_left = max_ticks
+        poll.update(primed=False, last=0)
+        _SPEC_STATS.clear()
+        while ticks_left > 0:
+            if spec_ctx is not None:
+                ticks_left -= spec_ctx.advance()
+                if N - spec_ctx.poll() == 0:
+                    break
                 continue
-            ticks_left -= tail_ctx.advance()
-            n_active = N - poll_done()
+            if tail_ctx is not None:
+                if spec_ok and tail_ctx.n_cur <= spec_rows:
+                    to_spec(ctypes.byref(tail_ctx.run[tail_ctx.cur]), tail_ctx.qf[tail_ctx.cur], tail_ctx.n_cur)
+                    tail_ctx = None
+                    continue
+                ticks_left -= tail_ctx.advance()
+                n_active = N - poll_done()
+                if n_active == 0:
+                    break
+                if spec_ok and n_active <= spec_rows:
+                    tail_ctx.n_cur = n_active  # (an upper bound: the count is read one batch late)
+                    continue
+                if tail_ctx.wants_compaction(n_active):
+                    tail_ctx.compact(n_active)
+                continue
+            n_rows = sum(g_.n_rows for g_ in groups)
+            tail = n_rows <= graph_max_rows
+            n_ticks = sync_every * (4 if tail else 1)
+            for g_ in groups:
+                # a multi-group schedule replays fixed-size groups for many chunks: record at once; a
+                # single small group (a run that STARTS with few chains) is recorded once its batch size
+                # has lasted 4 plain chunks
+                rec_now = can_record and ticks_left < max_ticks and (
+                    use_graph is True or len(groups) > 1 or (tail and g_.eager_chunks >= 4))
+                g_.advance(n_ticks, rec_now)
+            ticks_left -= n_ticks
+            n_active = N - int(n_done.item())  # one host sync per chunk
             if n_active == 0:
                 break
-            if spec_ok and n_active <= spec_rows:
-                tail_ctx.n_cur = n_active  # (an upper bound: the count is read one batch late)
-                continue
-            if tail_ctx.wants_compaction(n_active):
-                tail_ctx.compact(n_active)
-            continue
-        n_rows = sum(g_.n_rows for g_ in groups)
-        tail = n_rows <= graph_max_rows
-        n_ticks = sync_every * (4 if tail else 1)
-        for g_ in groups:
-            # a multi-group schedule replays fixed-size groups for many chunks: record at once; a
-            # single small group (a run that STARTS with few chains) is recorded once its batch size
-            # has lasted 4 plain chunks
-            rec_now = can_record and ticks_left < max_ticks and (
-                use_graph is True or len(groups) > 1 or (tail and g_.eager_chunks >= 4))
-            g_.advance(n_ticks, rec_now)
-        ticks_left -= n_ticks
-        n_active = N - int(n_done.item())  # one host sync per chunk
-        if n_active == 0:
-            break
-        if spec_ok and n_active <= spec_rows and len(groups) == 1:
-            to_spec(groups[0].rref, groups[0].qf, n_active)  # few live chains: every tick is pure latency from here on
-            groups = []
-            continue
-        if n_active <= n_rows // 2 and n_rows > 64:
-            # drop the finished chains from the batch (device-side compaction + gather); the groups
-            # are merged into one batch of the live rows
-            if can_record and n_active <= graph_max_rows:
-                tail_ctx = _Tail(n_active, sync_every, 4)
-                tail_ctx.enter(groups, n_active)
-                poll["last"] = N - n_active
+            if spec_ok and n_active <= spec_rows and len(groups) == 1:
+                to_spec(groups[0].rref, groups[0].qf, n_active)  # few live chains: every tick is pure latency from here on
                 groups = []
                 continue
-            rows_all = torch.empty(n_rows, **i32)
-            qf_all = torch.empty((n_rows, D), **f32)
-            off = 0
-            for g_ in groups:
-                _lib.call("bjx_nuts_async_compact", stream, dref, g_.rref, g_.qf.data_ptr(),
-                          rows_all[off:].data_ptr(), qf_all[off:].data_ptr(), src_work.data_ptr(),
-                          n_out.data_ptr())
-                off += int(n_out.item()) if len(groups) > 1 else n_active
-            assert off == n_active, (off, n_active)
-            rb = auto_row_block(n_active, D) if row_block is None else int(row_block)
-            blk_now = n_active if not rb or rb >= n_active else rb
-            groups = []
-            for s0 in range(0, n_active, blk_now):
-                n_g = min(blk_now, n_active - s0)
-                g_ = _Group(rows_all[s0:s0 + n_g], n_g, qf_all[s0:s0 + n_g])
-                g_.logp_f, g_.gf = eval_logdensity(vg, g_.qf)  # the gathered positions, row for row
-                groups.append(g_)
-    else:
+            if n_active <= n_rows // 2 and n_rows > 64:
+                # drop the finished chains from the batch (device-side compaction + gather); the groups
+                # are merged into one batch of the live rows
+                if can_record and n_active <= graph_max_rows:
+                    if persistent:
+                        if static["tail"] is None:
+                            static["tail"] = _Tail(min(N, graph_max_rows), sync_every, 4)
+                        tail_ctx = static["tail"]
+                    else:
+                        tail_ctx = _Tail(n_active, sync_every, 4)
+                    tail_ctx.enter(groups, n_active)
+                    poll["last"] = N - n_active
+                    groups = []
+                    continue
+                rows_all = torch.empty(n_rows, **i32)
+                qf_all = torch.empty((n_rows, D), **f32)
+                off = 0
+                for g_ in groups:
+                    _lib.call("bjx_nuts_async_compact", stream, dref, g_.rref, g_.qf.data_ptr(),
+                              rows_all[off:].data_ptr(), qf_all[off:].data_ptr(), src_work.data_ptr(),
+                              n_out.data_ptr())
+                    off += int(n_out.item()) if len(groups) > 1 else n_active
+                assert off == n_active, (off, n_active)
+                rb = auto_row_block(n_active, D) if row_block is None else int(row_block)
+                blk_now = n_active if not rb or rb >= n_active else rb
+                groups = []
+                for s0 in range(0, n_active, blk_now):
+                    n_g = min(blk_now, n_active - s0)
+                    g_ = _Group(rows_all[s0:s0 + n_g], n_g, qf_all[s0:s0 + n_g])
+                    g_.logp_f, g_.gf = eval_logdensity(vg, g_.qf)  # the gathered positions, row for row
+                    groups.append(g_)
+        else:
+            if spec_ctx is not None:
+                torch.cuda.current_stream(dev).wait_stream(spec_ctx.side)
+            if int(n_done.item()) != N:
+                raise RuntimeError("free-running NUTS did not finish within its tick bound")
         if spec_ctx is not None:
-            torch.cuda.current_stream(dev).wait_stream(spec_ctx.side)
-        if int(n_done.item()) != N:
-            raise RuntimeError("free-running NUTS did not finish within its tick bound")
-    if spec_ctx is not None:
-        spec_ctx.finish()
-    return HMCState(q, logp, g), positions, info
+            spec_ctx.finish()
+        groups = []
+        if persistent:  # the buffers are reused by the next call
+            c = lambda t: None if t is None else t.clone()  # noqa: E731
+            return (HMCState(q.clone(), logp.clone(), g.clone()), c(positions),
+                    NUTSRunInfo(*[c(getattr(info, f)) for f in NUTSRunInfo._fields]))
+        return HMCState(q, logp, g), positions, info
+
+    if not persistent:
+        return execute()
+
+    kind0, imm_shape0 = metric.kind, tuple(imm_buf.shape)
+
+    def rerun(rng_key2, state2, step_size2, inverse_mass_matrix2):
+        """One more run on this workspace: new key, state, step size and metric; no allocation, no recording."""
+        k0_, k1_, fold_ = bjx_random.key_spec(rng_key2)
+        m2 = metrics.default_metric(inverse_mass_matrix2, N, D, dev)
+        if fold_ >= 0 or m2.kind != kind0 or tuple(m2.imm.shape) != imm_shape0:
+            raise ValueError("persistent free-running workspace: the key kind or the metric's shape changed")
+        q.copy_(check_batch(state2.position, "state.position"))
+        logp.copy_(check_batch(state2.logdensity, "state.logdensity"))
+        g.copy_(check_batch(state2.logdensity_grad, "state.logdensity_grad"))
+        e2, epc2 = step_size_args(step_size2, N, dev)
+        eps_buf.fill_(e2) if epc2 is None else eps_buf.copy_(epc2)
+        imm_buf.copy_(m2.imm)
+        # the key's two words as integer fills (no host-to-device copy, hence no host synchronisation)
+        step_keys[0, 0].fill_(int(np.uint32(k0_).astype(np.int32)))
+        step_keys[0, 1].fill_(int(np.uint32(k1_).astype(np.int32)))
+        for b_ in (t_done, phase, n_done, rec):
+            b_.zero_()
+        return execute()
+
+    _handle["rerun"] = rerun
+    _handle["work"] = {"p": p, "bufs": bufs, "rec": rec}
+    # EVERY device buffer the descriptors point to must outlive this call: the kernels of later reruns reach them through
+    # raw pointers, and a tensor that only this frame referenced (checkpoints, slot tables, the front momentum ...) would
+    # go back to the allocator on return -- and be handed to somebody else while the workspace still writes to it
+    # (found as box-independent but allocation-pattern-dependent wrong draws on the second call: NOTEBOOK.md section 16.8)
+    _handle["keep"] = [q, logp, g, p, qf, t_done, phase, n_done, rec, front_p, end_list, end_count, ck_r, ck_rs, fs, is_,
+                       step_keys, src_work, n_out, eps_buf, imm_buf, info, positions, bufs, dense_f, v0, gemm_bufs, metric]
+    return execute()
 
 
 def _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions):
@@ -1278,7 +1364,8 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                      integrator=integrators.velocity_verlet, chain_offset: int = 0,
                      recompact_every: int = 16, use_graph="auto",
                      graph_sync_every: int = 4, run_use_graph="auto", dense_gemm="auto",
-                     fuse_target: bool = False) -> SamplingAlgorithm:
+                     fuse_target: bool = False, step_driver: str = "auto",
+                     step_spec_rows: Optional[int] = None) -> SamplingAlgorithm:
     """blackjax/mcmc/nuts.py:150-220.  Besides ``init`` / ``step`` the returned algorithm has
     ``run(rng_key, state, num_steps, *, key_layout="step_major", store_positions=True)``: the same
     ``num_steps`` transitions with free-running chains (``run_free``), which is how many-chain NUTS
@@ -1293,9 +1380,66 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     general = integrator is not integrators.velocity_verlet
     if fuse_target and general:
         raise NotImplementedError("fuse_target=True: the free-running tick kernels integrate with velocity Verlet")
+    if step_driver not in ("auto", "lockstep", "free"):
+        raise ValueError("step_driver must be 'auto', 'lockstep' or 'free'")
     fuse_default = bool(fuse_target)
     kernel = build_kernel(integrator, divergence_threshold, recompact_every=recompact_every,
                           use_graph=use_graph, graph_sync_every=graph_sync_every, dense_gemm=dense_gemm)
+    # ``step`` as ONE free-running transition on a persistent workspace (round 5).  The lockstep tree makes every chain
+    # wait at every leaf of the deepest tree of the ensemble -- two dependent launches per leaf for a handful of live
+    # chains during most of a transition; the free-running tick kernels with the two-stream speculative tail spend
+    # 4.9 us instead of ~7-8 us on such a leaf, and give the same draws and the same NUTSInfo bit for bit
+    # (tests/test_nuts_step_free_gpu.py).  What used to make this path lose -- buffers and tail recordings set up per
+    # call -- now happens once per (shape, callable, stream): run_free(_handle=...).
+    free_ws: dict = {}
+    free_bad: set = set()
+    step_driver = _os_environ().get("BJX_NUTS_STEP_DRIVER", step_driver)
+
+    def _free_step_key(rng_key, state):
+        if step_driver == "lockstep" or fuse_default or use_graph is False or run_use_graph is False:
+            return None
+        if not is_capturable(logdensity_fn):
+            return None
+        pos = state.position
+        if not (isinstance(pos, torch.Tensor) and pos.is_cuda and pos.ndim == 2 and pos.dtype == torch.float32):
+            return None
+        n_, d_ = pos.shape
+        if n_ == 0 or d_ % 4 != 0 or d_ > 1024 or int(max_num_doublings) < 1 or key_spec(rng_key)[2] >= 0:
+            return None
+        m = metrics.default_metric(inverse_mass_matrix, n_, d_, pos.device)
+        if m.kind != "diag" or (general and not free_running_supports(integrator, m.kind, d_)):
+            return None
+        k = (n_, d_, tuple(m.imm.shape), pos.device.index, torch.cuda.current_stream(pos.device).cuda_stream)
+        return None if k in free_bad else k
+
+    def _free_step(wkey, rng_key, state):
+        h = free_ws.get(wkey)
+        if h is None:
+            h = {}
+            try:
+                new_state, _, ri = run_free(
+                    rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, 1, max_num_doublings,
+                    divergence_threshold=divergence_threshold, chain_offset=chain_offset, key_layout="step",
+                    store_positions=False, use_graph=True if use_graph is True else run_use_graph,
+                    integrator=integrator, keep_ends=True, spec_rows=step_spec_rows, _handle=h)
+            except RuntimeError:
+                if step_driver == "free":
+                    raise
+                free_bad.add(wkey)  # (a recording failed: this shape stays on the lockstep driver)
+                torch.cuda.synchronize(state.position.device)
+                return None
+            free_ws[wkey] = h
+        else:
+            new_state, _, ri = h["rerun"](rng_key, state, step_size, inverse_mass_matrix)
+        w = h["work"]
+        b_, rec_f = w["bufs"], w["rec"].view(torch.float32)
+        c = lambda t: t.clone()  # noqa: E731
+        info = NUTSInfo(
+            c(w["p"]), ri.is_divergent[0], ri.is_turning[0], ri.energy[0],
+            IntegratorState(c(b_["Lq"]), c(b_["Lp"]), c(rec_f[:, 29]), c(b_["Lg"])),
+            IntegratorState(c(b_["Rq"]), c(b_["Rp"]), c(rec_f[:, 30]), c(b_["Rg"])),
+            ri.num_trajectory_expansions[0], ri.num_integration_steps[0], ri.acceptance_rate[0])
+        return new_state, info
 
     def init_fn(position, rng_key=None):
         del rng_key
@@ -1310,6 +1454,11 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             return new_state, NUTSInfo(None, ri.is_divergent[0], ri.is_turning[0], ri.energy[0], None, None,
                                        ri.num_trajectory_expansions[0], ri.num_integration_steps[0],
                                        ri.acceptance_rate[0])
+        wkey = _free_step_key(rng_key, state)
+        if wkey is not None:
+            out = _free_step(wkey, rng_key, state)
+            if out is not None:
+                return out
         return kernel(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix,
                       max_num_doublings, chain_offset=chain_offset)
 

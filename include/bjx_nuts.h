@@ -263,7 +263,10 @@ typedef struct {
   int32_t* end_list;
   int32_t* end_count;
   int32_t tick;
-  int32_t reserved2;
+  int32_t keep_ends;          /* ABI 6, lean tick kernel only (rec / front_p given): != 0 makes a chain that completes a
+                                 transition leave both trajectory ends in nuts->Lq/Lp/Lg, Rq/Rp/Rg and their log-densities in
+                                 words 29 / 30 of its record (as float bits) -- NUTSInfo.trajectory_leftmost_state /
+                                 rightmost_state (nuts.py:66-70) of the chain's LAST transition; meant for n_steps == 1 */
   /* Optional device-side row count: when non-NULL the kernels process min(n_rows, *n_rows_dev) rows
    * (launch geometry still follows n_rows).  Lets ONE recorded sequence of ticks serve every batch
    * size of a run's tail: bjx_nuts_async_compact writes the new count to its n_out argument, which
