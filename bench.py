@@ -1111,6 +1111,29 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
 
     dt_l, per_l, _ = timed_region(ctx, one_step, lockstep_steps)
     tot_l = float(ctx.gather_rows(acc.reshape(1, 1)).sum())
+    # the same calls on the lockstep tree driver (step_driver="lockstep": rounds 1-4's `step`), rank 0 of a one-GPU run
+    lock_cmp = None
+    if world == 1:
+        try:
+            alg_lock = bjx.nuts(bjx.targets.NealFunnel(), eps, torch.ones(D, device=dev), max_num_doublings=max_depth,
+                                chain_offset=rank * N, use_graph="auto", step_driver="lockstep")
+            st_k = state
+            for t in range(n_warm):
+                st_k, _ = alg_lock.step(keys[t], st_k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st_k, tot_k = state, 0
+            infos = []
+            for i in range(lockstep_steps):
+                st_k, info_k = alg_lock.step(keys[n_warm + i], st_k)
+                infos.append(info_k.num_integration_steps)
+            torch.cuda.synchronize()
+            dt_k = time.perf_counter() - t0
+            tot_k = float(torch.stack(infos).sum())
+            lock_cmp = {"value": tot_k / dt_k, "ms_per_transition": dt_k / lockstep_steps * 1e3,
+                        "same_final_state": bool(torch.equal(st_k.position, st_box["state"].position))}
+        except Exception as e:
+            print(f"bench.py: c3 lockstep-driver comparison failed: {e!r}", file=sys.stderr)
 
     # ---- one full-ensemble tick bracketed with HIP events (plain launches, no graph), rank 0
     tick_us = None
@@ -1194,8 +1217,11 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
             "ms_per_transition": dt_l / lockstep_steps * 1e3,
             "mean_leapfrogs_per_chain_transition": tot_l / (world * N * lockstep_steps),
             "frac_of_52B_roofline": tot_l / dt_l / world / peak_rate,
-            "note": "alg.step (the reference's kernel API: all chains in lockstep, HIP-graph driver); a transition lasts "
-                    "as long as the deepest tree of the ensemble"},
+            "step_driver": "auto -> one free-running transition on a persistent workspace (two-stream speculative tail)",
+            "lockstep_tree_driver": lock_cmp,
+            "note": "alg.step (the reference's kernel API: one transition of every chain per call; a transition lasts as "
+                    "long as the deepest tree of the ensemble -- 1 023 dependent leapfrogs of two launches each); the "
+                    "key `lockstep_step` is kept from rounds 1-4, when the lockstep tree driver served it"},
         "roofline": roofline,
         "parity": parity,
     }
