@@ -1292,8 +1292,21 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     NUTSRunInfo(*[c(getattr(info, f)) for f in NUTSRunInfo._fields]))
         return HMCState(q, logp, g), positions, info
 
+    def guarded():
+        """execute(); should it raise while the second stream of a speculative tail still has work queued, wait for the
+        device before the frame's buffers go back to the allocator."""
+        try:
+            return execute()
+        except BaseException:
+            if spec_ctx is not None:
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception:
+                    pass
+            raise
+
     if not persistent:
-        return execute()
+        return guarded()
 
     kind0, imm_shape0 = metric.kind, tuple(imm_buf.shape)
 
@@ -1314,7 +1327,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         step_keys[0, 1].fill_(int(np.uint32(k1_).astype(np.int32)))
         for b_ in (t_done, phase, n_done, rec):
             b_.zero_()
-        return execute()
+        return guarded()
 
     _handle["rerun"] = rerun
     _handle["work"] = {"p": p, "bufs": bufs, "rec": rec}
@@ -1324,7 +1337,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # (found as box-independent but allocation-pattern-dependent wrong draws on the second call: NOTEBOOK.md section 16.8)
     _handle["keep"] = [q, logp, g, p, qf, t_done, phase, n_done, rec, front_p, end_list, end_count, ck_r, ck_rs, fs, is_,
                        step_keys, src_work, n_out, eps_buf, imm_buf, info, positions, bufs, dense_f, v0, gemm_bufs, metric]
-    return execute()
+    return guarded()
 
 
 def _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions):
