@@ -1175,7 +1175,14 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     groups: list = []
     tail_ctx = spec_ctx = None
     ticks_left = max_ticks
-    static = {"tail": None, "spec": None}  # persistent workspace: the tails (and their recorded sequences) of earlier calls
+    # ONE transition from a common start (`step`): every chain with d doublings ends at tick 2^d + 1 (start, 2^d - 1
+    # leaves, deferred end), so the live count only changes there -- the host looks right behind those ticks and compacts
+    # once at most 70 % of a batch is live.  Measured at C3 (tools/step_vs_run1.py, same call): 7.2 ms per transition
+    # against 7.9 with the schedule of a long run (a look every 16 ticks, compaction at one half) and 7.4 with a look
+    # every 8 ticks.  Runs of many transitions keep the old schedule: their chains desynchronise within a transition.
+    cohort_plan, compact_frac = None, 0.5
+    if T == 1 and not fused and gemm_bufs is None:
+        cohort_plan, compact_frac = [(1 << d_) + 1 for d_ in range(4, max_depth + 1)], 0.7
 
     def to_spec(src_rref, src_qf, n_live):
         nonlocal spec_ctx, ticks_left
@@ -1232,6 +1239,9 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             n_rows = sum(g_.n_rows for g_ in groups)
             tail = n_rows <= graph_max_rows
             n_ticks = sync_every * (4 if tail else 1)
+            if cohort_plan is not None:  # one transition: look at the batch where a cohort of trees has just ended
+                done_ticks = max_ticks - ticks_left
+                n_ticks = next((b_ - done_ticks for b_ in cohort_plan if b_ > done_ticks), n_ticks)
             for g_ in groups:
                 # a multi-group schedule replays fixed-size groups for many chunks: record at once; a
                 # single small group (a run that STARTS with few chains) is recorded once its batch size
@@ -1247,7 +1257,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 to_spec(groups[0].rref, groups[0].qf, n_active)  # few live chains: every tick is pure latency from here on
                 groups = []
                 continue
-            if n_active <= n_rows // 2 and n_rows > 64:
+            if n_active <= int(n_rows * compact_frac) and n_rows > 64:
                 # drop the finished chains from the batch (device-side compaction + gather); the groups
                 # are merged into one batch of the live rows
                 if can_record and n_active <= graph_max_rows:
