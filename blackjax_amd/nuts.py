@@ -1183,6 +1183,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     cohort_plan, compact_frac = None, 0.5
     if T == 1 and not fused and gemm_bufs is None:
         cohort_plan, compact_frac = [(1 << d_) + 1 for d_ in range(4, max_depth + 1)], 0.7
+    static = {"tail": None, "spec": None}  # persistent workspace: the tails (and their recorded sequences) of earlier calls
 
     def to_spec(src_rref, src_qf, n_live):
         nonlocal spec_ctx, ticks_left
