@@ -1446,10 +1446,16 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                     divergence_threshold=divergence_threshold, chain_offset=chain_offset, key_layout="step",
                     store_positions=False, use_graph=True if use_graph is True else run_use_graph,
                     integrator=integrator, keep_ends=True, spec_rows=step_spec_rows, _handle=h)
-            except RuntimeError:
+            except RuntimeError as err:
                 if step_driver == "free":
                     raise
-                free_bad.add(wkey)  # (a recording failed: this shape stays on the lockstep driver)
+                # a recording failed (or the speculative tail's replica check fired): say so, and keep this shape on
+                # the lockstep tree driver, which restarts the transition from `state` (never modified here)
+                import warnings
+
+                warnings.warn(f"blackjax_amd.nuts.step: the free-running driver failed for this shape ({err}); "
+                              "falling back to the lockstep tree driver", RuntimeWarning, stacklevel=3)
+                free_bad.add(wkey)
                 torch.cuda.synchronize(state.position.device)
                 return None
             free_ws[wkey] = h
