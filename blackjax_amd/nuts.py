@@ -1458,6 +1458,8 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
                 free_bad.add(wkey)
                 torch.cuda.synchronize(state.position.device)
                 return None
+            while len(free_ws) >= 2:  # a workspace is ~20 (N, D) buffers: keep the two most recent shapes only
+                free_ws.pop(next(iter(free_ws)))
             free_ws[wkey] = h
         else:
             new_state, _, ri = h["rerun"](rng_key, state, step_size, inverse_mass_matrix)

@@ -43,6 +43,8 @@ def _assert_same(a, b):
     (9, 772, 12, 6, 0.1),     # three pieces, ragged last piece
     (3, 1024, 12, 6, 0.1),    # four pieces
     (1, 8, 30, 9, 0.05),      # a single chain
+    (16, 16, 60, 2, 0.3),     # two doublings at most: the integrator's tree is exhausted after three leaves
+    (16, 16, 80, 1, 0.3),     # one doubling: every transition is one leaf
 ])
 def test_spec_tail_equals_one_stream_tail_funnel(dev, N, D, T, max_depth, eps):
     g = torch.Generator(device=dev)

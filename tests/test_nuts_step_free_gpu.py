@@ -101,3 +101,28 @@ def test_free_step_workspace_reuse_with_run(dev):
     final, positions, info = alg.run(bjx.random.key(21), st0, T)  # run == the step loop (step-major keys)
     assert torch.equal(final.position, st_a.position)
     assert torch.equal(info.num_integration_steps[-1], ia.num_integration_steps)
+
+
+def test_free_step_shapes_come_and_go(dev):
+    """Three ensemble sizes through ONE algorithm object (the driver keeps the two most recent workspaces), shallow
+    depth limits, and the lockstep fall-back for a ChainMajorKey."""
+    fn = bjx.targets.NealFunnel()
+    D = 32
+    imm = torch.ones(D, device=dev)
+    for max_depth in (1, 2, 5):
+        free = bjx.nuts(fn, 0.2, imm, max_num_doublings=max_depth, step_driver="auto")
+        lock = bjx.nuts(fn, 0.2, imm, max_num_doublings=max_depth, step_driver="lockstep")
+        for N in (8, 40, 8, 130):
+            g = torch.Generator(device=dev)
+            g.manual_seed(N)
+            st_f = st_l = lock.init(0.3 * torch.randn(N, D, device=dev, generator=g))
+            for k in bjx.random.split(bjx.random.key(N), 3):
+                st_l, il = lock.step(k, st_l)
+                st_f, if_ = free.step(k, st_f)
+                _same_state(st_l, st_f)
+                _same_info(il, if_)
+        ck = bjx.random.ChainMajorKey(bjx.random.key(5), 3)  # (run key, transition): the lockstep tree driver's case
+        a, ia = free.step(ck, st_f)
+        b, ib = lock.step(ck, st_l)
+        _same_state(a, b)
+        _same_info(ia, ib)
