@@ -366,14 +366,16 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
                       "inverse_mass_matrix": metrics.PerChainDiagTensor.tag(imm_pc), **extra_parameters}
         return AdaptationResults(state, parameters), run_info
 
-    def run(rng_key, position, num_steps: int = 1000, *, chain_offset: int = 0,
+    def run(rng_key, position, num_steps: Optional[int] = None, *, chain_offset: int = 0,
             free_running: bool = False, fuse_target: bool = False):
-        """staged_adaptation.py:860-876,968-981 (single-chain path, batched over chains).
+        """staged_adaptation.py:756-786,860-876,968-981 (single-chain path, batched over chains).  ``num_steps=None``
+        is the reference's sentinel for "not given": 1 000 steps (its other meaning belongs to ``metric="auto"``).
         ``free_running=True`` (NUTS, diagonal metric): see ``_run_free_running``; with it,
         ``fuse_target=True`` evaluates a ``blackjax_amd.targets`` log-density inside the tick kernels
         (``nuts.run_free``: same results, outside the external-callable contract)."""
         if fuse_target and not free_running:
             raise ValueError("fuse_target=True needs free_running=True")
+        num_steps = 1000 if num_steps is None else int(num_steps)
         position = check_batch(position, "position")
         n, d = position.shape
         run_key = key_words(rng_key)
