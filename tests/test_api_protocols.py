@@ -1,4 +1,4 @@
-"""The reference's protocol checks (tests/test_api_protocols.py:148-240) for the samplers this engine
+"""The reference's protocol checks (tests/test_api_protocols.py:176-232) for the samplers this engine
 exposes: the factory returns a SamplingAlgorithm, ``init``'s first parameter is ``position``, ``step``'s
 first two are ``rng_key, state``; the GPU half does the init -> step round trip with the reference's
 calling conventions (``init(position)`` or, for dhmc / dmhmc / ghmc, ``init(position, rng_key)``)."""
