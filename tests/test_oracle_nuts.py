@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from oracle import hmc as ohmc
 from oracle import nuts as onuts
@@ -45,6 +46,26 @@ def test_dynamic_expansion_outcomes():
         assert (div, turn, depth) == (should_div, should_turn, doublings), (eps, div, turn, depth)
         if doublings == 10:
             assert n_states == 1023
+
+
+@pytest.mark.parametrize("eps,should_diverge", [(0.0001, False), (1000.0, True)])
+def test_progressive_integration_divergence(eps, should_diverge):
+    """tests/mcmc/test_trajectory.py:20-75: standard normal, position 1.0, momentum = normal(key(0)), divergence
+    threshold 1000 (the module constant there): a step of 1000 diverges at once, a step of 1e-4 never does (the
+    reference integrates one subtree of at most 100 leaves; here the whole transition, depth limit 10)."""
+    fn = targets.diag_gaussian(np.ones(1, f32))
+    metric = ohmc.default_metric(np.ones(1, f32))
+    key = prng.key(0)
+    q = np.ones((1, 1), f32)
+    p = prng.normal(key, (1,))[None].astype(f32)
+    lp, g = fn(q)
+    out = onuts._one_chain(key, ohmc.IntegratorState(q, p, lp, g), fn, f32(eps), metric, 10, 1000)
+    _, _, _, _, depth, n_states, _, div, turn = out
+    assert div is should_diverge or bool(div) == should_diverge
+    if should_diverge:
+        assert depth == 1 and n_states == 1  # the first leaf already diverges: nothing is added to the trajectory
+    else:
+        assert depth == 10 and n_states == 1023 and not turn
 
 
 def test_nuts_statistics_normal():
