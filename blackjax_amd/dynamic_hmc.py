@@ -24,7 +24,7 @@ from .hmc import HMCInfo, IntegratorState
 from .random import key_spec
 
 __all__ = ["DynamicHMCState", "init", "build_kernel", "as_top_level_api", "chain_keys",
-           "next_key_fn", "randint_steps_fn", "halton_sequence", "halton_steps_fn"]
+           "next_key_fn", "randint_steps_fn", "halton_sequence", "halton_steps_fn", "rescale", "halton_trajectory_length"]
 
 
 class DynamicHMCState(NamedTuple):
@@ -74,6 +74,23 @@ def halton_sequence(i: int, max_bits: int = 10) -> np.float32:
         if ((int(i) + 1) >> k) & 1:
             v = np.float32(v + np.float32(0.5 / (1 << k)))
     return v
+
+
+def rescale(mu) -> np.float32:
+    """blackjax/mcmc/adjusted_mclmc.py:281-288 (imported by dynamic_hmc.py:23): ``s`` such that
+    ``round(U(0, 1) * s + 0.5)`` has expected value ``mu`` (fp32, as the reference computes it)."""
+    mu = np.float32(mu)
+    k = np.floor(np.float32(2.0) * mu - np.float32(1.0))
+    x = k * (mu - np.float32(0.5) * (k + np.float32(1.0))) / (k + np.float32(1.0) - mu)
+    return np.float32(k + x)
+
+
+def halton_trajectory_length(i: int, trajectory_length_adjustment: float, max_bits: int = 10) -> int:
+    """blackjax/mcmc/dynamic_hmc.py:218-223 for a host integer: a quasi-random number of integration steps with mean
+    ``trajectory_length_adjustment`` -- ``rint(0.5 + halton_sequence(i) * rescale(adjustment))`` (round half to even,
+    as ``jnp.rint``)."""
+    s = rescale(trajectory_length_adjustment)
+    return int(np.rint(np.float32(np.float32(0.5) + np.float32(halton_sequence(i, max_bits) * s))))
 
 
 def halton_steps_fn(max_bits: int, jitter_amount: float = 1.0) -> Callable:

@@ -22,7 +22,7 @@ from ._util import (check_batch, eval_logdensity, is_capturable, step_size_args,
 from .base import SamplingAlgorithm
 from .random import key_spec
 
-__all__ = ["HMCState", "HMCInfo", "IntegratorState", "init", "build_kernel", "as_top_level_api"]
+__all__ = ["HMCState", "HMCInfo", "IntegratorState", "init", "flip_momentum", "build_kernel", "as_top_level_api"]
 
 
 class HMCState(NamedTuple):
@@ -52,6 +52,13 @@ class HMCInfo(NamedTuple):
     energy: torch.Tensor
     proposal: IntegratorState
     num_integration_steps: int
+
+
+def flip_momentum(state: IntegratorState) -> IntegratorState:
+    """blackjax/mcmc/hmc.py:95-112: the end state of a trajectory with its momentum negated (time reversibility).  The
+    transition kernels do this inside their finishing launch (``k_hmc_finish_*``: the flipped momentum is what ``HMCInfo.
+    proposal`` carries); this is the stand-alone function of the reference for code that builds on it."""
+    return IntegratorState(state.position, -1.0 * state.momentum, state.logdensity, state.logdensity_grad)
 
 
 def init(position: torch.Tensor, logdensity_fn: Callable) -> HMCState:

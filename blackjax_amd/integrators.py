@@ -53,3 +53,13 @@ def check_supported(integrator, allow_general: bool = False):
         "this sampler/metric implements the velocity_verlet integrator only; got %r "
         "(mclachlan / yoshida / omelyan: see blackjax_amd.integrators for where they are available)"
         % (integrator,))
+
+
+def __getattr__(name):
+    # blackjax/mcmc/integrators.py:43-53 defines IntegratorState; here it lives with the samplers that fill it
+    # (blackjax_amd.hmc) -- resolved lazily because that module imports this one
+    if name == "IntegratorState":
+        from .hmc import IntegratorState
+
+        return IntegratorState
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

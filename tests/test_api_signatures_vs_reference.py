@@ -52,6 +52,7 @@ def _ref_fields(node):
 # (reference file, definition[, enclosing function]) -> (our module, attribute)
 _FUNCTIONS = [
     ("mcmc/hmc.py", "init", None, "hmc", "init"),
+    ("mcmc/hmc.py", "flip_momentum", None, "hmc", "flip_momentum"),
     ("mcmc/hmc.py", "build_kernel", None, "hmc", "build_kernel"),
     ("mcmc/hmc.py", "as_top_level_api", None, "hmc", "as_top_level_api"),
     ("mcmc/nuts.py", "build_kernel", None, "nuts", "build_kernel"),
@@ -60,6 +61,8 @@ _FUNCTIONS = [
     ("mcmc/dynamic_hmc.py", "build_kernel", None, "dynamic_hmc", "build_kernel"),
     ("mcmc/dynamic_hmc.py", "as_top_level_api", None, "dynamic_hmc", "as_top_level_api"),
     ("mcmc/dynamic_hmc.py", "halton_sequence", None, "dynamic_hmc", "halton_sequence"),
+    ("mcmc/dynamic_hmc.py", "halton_trajectory_length", None, "dynamic_hmc", "halton_trajectory_length"),
+    ("mcmc/adjusted_mclmc.py", "rescale", None, "dynamic_hmc", "rescale"),
     ("mcmc/ghmc.py", "init", None, "ghmc", "init"),
     ("mcmc/ghmc.py", "build_kernel", None, "ghmc", "build_kernel"),
     ("mcmc/ghmc.py", "as_top_level_api", None, "ghmc", "as_top_level_api"),
@@ -85,6 +88,7 @@ _TUPLES = [
     ("mcmc/hmc.py", "HMCInfo", "hmc", "HMCInfo"),
     ("mcmc/nuts.py", "NUTSInfo", "nuts", "NUTSInfo"),
     ("mcmc/integrators.py", "IntegratorState", "hmc", "IntegratorState"),
+    ("mcmc/integrators.py", "IntegratorState", "integrators", "IntegratorState"),
     ("mcmc/dynamic_hmc.py", "DynamicHMCState", "dynamic_hmc", "DynamicHMCState"),
     ("mcmc/ghmc.py", "GHMCState", "ghmc", "GHMCState"),
     ("adaptation/staged_adaptation.py", "StagedAdaptationState", "adaptation", "StagedAdaptationState"),
@@ -132,7 +136,7 @@ def _has_default(path, name, inside, arg):
     return arg in with_default
 
 
-@pytest.mark.parametrize("path,name,mod,attr", _TUPLES, ids=[a for _, _, _, a in _TUPLES])
+@pytest.mark.parametrize("path,name,mod,attr", _TUPLES, ids=[f"{m}.{a}" for _, _, m, a in _TUPLES])
 def test_state_and_info_tuples_have_the_reference_fields(path, name, mod, attr):
     ref = _ref_fields(_find(_ref_module(path), name))
     ours = list(_ours(mod, attr)._fields)
