@@ -12,7 +12,8 @@ functions its HMC / NUTS / adaptation code calls, ``import blackjax`` works and 
 ``dynamic_multiplicative_expansion`` / ``dynamic_progressive_integration``, ``iterative_uturn_numpyro``,
 ``progressive_*_sampling``, ``gaussian_euclidean`` / ``_format_covariance``, ``generalized_two_stage_integrator``,
 ``dual_averaging``, ``welford_algorithm``, ``mass_matrix_adaptation``, ``staged_adaptation`` / ``build_schedule``,
-``run_inference_algorithm``, ``ghmc`` -- the reference's code, unmodified, read from where it lies.
+``run_inference_algorithm``, ``ghmc``, ``chees_adaptation``, ``meads_adaptation``, ``diagnostics.effective_sample_size`` /
+``rhat`` / ``ess_bulk`` / ``ess_tail`` -- the reference's code, unmodified, read from where it lies.
 
 What the fixtures pin and what they do not:
 * pinned: everything those functions DECIDE -- which key is split where, how a tree grows, when it stops, what is accepted,
@@ -313,6 +314,69 @@ def ghmc_case():
     return out
 
 
+# ------------------------------------------------------------------------------------------------ ChEES, MEADS, diagnostics
+def chees_case():
+    """``chees_adaptation(...).run`` with the optimiser of the reference's own test (tests/adaptation/test_adaptation.py:
+    104: adam(0.5, b1=0, b2=0.95) -- here tests/refshim/optax's restatement of Adam), every step's transition and state."""
+    import optax
+
+    N, D, T = 16, 4, 40
+    spec = dict(N=N, D=D, T=T, lo=-0.3, hi=0.3, q0_key_seed=7, run_key_seed=11, initial_step_size=0.1,
+                adam=dict(learning_rate=0.5, b1=0.0, b2=0.95))
+    fn = make_target(dict(kind="diag_gaussian", lo=-0.3, hi=0.3, D=D))
+    q0 = jax.random.normal(jax.random.key(7), (N, D))
+    warm = blackjax.chees_adaptation(fn, num_chains=N)
+    (last, params), info = warm.run(jax.random.key(11), q0, step_size=0.1, optim=optax.adam(**spec["adam"]), num_steps=T)
+    ad, tr = info.adaptation_state, info.info
+    spec.update(
+        position=f32hex(info.state.position), proposal_position=f32hex(tr.proposal.position),
+        proposal_momentum=f32hex(tr.proposal.momentum), acceptance_rate=f32hex(tr.acceptance_rate),
+        is_accepted=ints(tr.is_accepted), is_divergent=ints(tr.is_divergent), num_integration_steps=ints(tr.num_integration_steps),
+        step_size=f32hex(ad.step_size), log_step_size_ma=f32hex(ad.log_step_size_moving_average),
+        trajectory_length=f32hex(ad.trajectory_length), log_trajectory_length_ma=f32hex(ad.log_trajectory_length_moving_average),
+        da_log_x=f32hex(ad.da_state.log_x), da_log_x_avg=f32hex(ad.da_state.log_x_avg), da_step=ints(ad.da_state.step),
+        da_avg_error=f32hex(ad.da_state.avg_error), da_mu=f32hex(ad.da_state.mu),
+        adam_count=ints(ad.optim_state.count), adam_mu=f32hex(ad.optim_state.mu), adam_nu=f32hex(ad.optim_state.nu),
+        random_generator_arg=ints(ad.random_generator_arg), step=ints(ad.step),
+        final_step_size=f32hex(params["step_size"]), final_num_leapfrog=f32hex(params["integration_steps_params"][0]),
+        final_position=f32hex(last.position), final_random_generator_arg=ints(last.random_generator_arg))
+    return spec
+
+
+def meads_case():
+    N, D = 16, 6
+    sig = sigma_ladder(D, -0.5, 0.5)
+    fn = make_target(dict(kind="diag_gaussian", lo=-0.5, hi=0.5, D=D))
+    q0 = jnp.asarray(sig) * jax.random.normal(jax.random.key(21), (N, D))
+    warm = blackjax.meads_adaptation(fn, num_chains=N, num_folds=4)
+    run_key = jax.random.key(5)
+    (last, params), info = warm.run(run_key, 1.5 * q0, num_steps=12)
+    return dict(N=N, D=D, lo=-0.5, hi=0.5, q0_key_seed=21, q0_scale=1.5, num_steps=12, num_folds=4, run_key=words(run_key),
+                step_size_per_step=f32hex(info.adaptation_state.step_size), alpha_per_step=f32hex(info.adaptation_state.alpha),
+                delta_per_step=f32hex(info.adaptation_state.delta),
+                is_accepted_per_step=ints(info.info.is_accepted), final_position=f32hex(last.position),
+                parameters={k: f32hex(v) for k, v in params.items()})
+
+
+def diagnostics_case():
+    """``effective_sample_size`` / ``rhat`` / ``ess_bulk`` / ``ess_tail`` on NumPy-generated chains (no jax.random)."""
+    rng = np.random.default_rng(12345)
+    iid = rng.standard_normal((4, 200, 3)).astype(np.float32)
+    e = rng.standard_normal((8, 500)).astype(np.float32)
+    ar = np.zeros_like(e)
+    for t in range(1, 500):
+        ar[:, t] = np.float32(0.7) * ar[:, t - 1] + e[:, t]
+    shifted = (rng.standard_normal((4, 300)) + np.array([0.0, 0.5, -0.5, 1.0])[:, None]).astype(np.float32)
+    out = {}
+    for name, x in (("iid_4x200x3", iid), ("ar1_8x500", ar), ("shifted_4x300", shifted)):
+        xa = jnp.asarray(x)
+        rec = dict(x=f32hex(x), ess=f32hex(blackjax.diagnostics.effective_sample_size(xa)),
+                   rhat=f32hex(blackjax.diagnostics.rhat(xa)), psr=f32hex(blackjax.diagnostics.potential_scale_reduction(xa)),
+                   ess_bulk=f32hex(blackjax.diagnostics.ess_bulk(xa)), ess_tail=f32hex(blackjax.diagnostics.ess_tail(xa)))
+        out[name] = rec
+    return out
+
+
 def sha256_of(paths):
     out = {}
     for p in paths:
@@ -331,7 +395,8 @@ def main():
             "blackjax/mcmc/proposal.py", "blackjax/mcmc/integrators.py", "blackjax/mcmc/metrics.py", "blackjax/mcmc/dynamic_hmc.py",
             "blackjax/mcmc/ghmc.py", "blackjax/util.py", "blackjax/optimizers/dual_averaging.py",
             "blackjax/adaptation/step_size.py", "blackjax/adaptation/mass_matrix.py", "blackjax/adaptation/staged_adaptation.py",
-            "blackjax/adaptation/window_adaptation.py", "pyproject.toml"]),
+            "blackjax/adaptation/window_adaptation.py", "blackjax/adaptation/chees_adaptation.py",
+            "blackjax/adaptation/meads_adaptation.py", "blackjax/diagnostics.py", "pyproject.toml"]),
         "samplers": {}, "warmup": {},
     }
     # BJX_REF_SHIM_ONLY="samplers:a,b;schedules;ghmc" regenerates a subset (tests/test_ref_shim_fixtures.py re-runs three
@@ -365,6 +430,12 @@ def main():
             print("warmup", spec["name"], file=sys.stderr)
     if selected("ghmc"):
         out["ghmc"] = ghmc_case()
+    if selected("chees"):
+        out["chees"] = chees_case()
+    if selected("meads"):
+        out["meads"] = meads_case()
+    if selected("diagnostics"):
+        out["diagnostics"] = diagnostics_case()
     path = os.environ.get("BJX_REF_SHIM_OUT") or os.path.join(HERE, "ref_shim_fixtures.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -92,7 +92,7 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     """Any ``jax.<something>`` not defined below, and the third-party packages the reference imports at module level
     but the hot path never calls (optax ...), import as permissive stub modules."""
 
-    ROOTS = ("jax", "optax", "chex", "fastprogress", "jaxopt", "jaxlib")
+    ROOTS = ("jax", "chex", "fastprogress", "jaxopt", "jaxlib")  # (optax: tests/refshim/optax restates adam)
 
     def find_spec(self, fullname, path=None, target=None):
         root = fullname.split(".")[0]
@@ -150,6 +150,15 @@ class Array(torch.Tensor):
     def __hash__(self):
         return id(self)
 
+    def __getitem__(self, idx):
+        # JAX gather semantics: out-of-bounds integer-array indices are CLAMPED (diagnostics.py:275,297 rely on it)
+        adv = _advanced(idx)
+        t = self.as_subclass(torch.Tensor)
+        if adv is None:
+            return _wrap(torch.Tensor.__getitem__(t, _idx(idx) if not isinstance(idx, torch.Tensor) else idx))
+        adv = tuple(torch.clamp(torch.where(i < 0, i + t.shape[d], i), 0, t.shape[d] - 1) for d, i in enumerate(adv))
+        return _wrap(torch.Tensor.__getitem__(t, adv))
+
     # booleans take part in arithmetic as 0 / 1 in JAX (``1 - do_accept``, proposal.py:255); torch refuses ``-`` on them
     def _num(self):
         t = self.as_subclass(torch.Tensor)
@@ -165,6 +174,61 @@ class Array(torch.Tensor):
 
     def __neg__(self):
         return _wrap(-self._num())
+
+    # NumPy-style reductions (``x.var(axis=0, ddof=1, keepdims=True)``, diagnostics.py:233); internal code works on
+    # plain tensors (``_t``), so these only serve the reference's calls
+    def _jnp(self):
+        return sys.modules["jax.numpy"]
+
+    def sum(self, axis=None, keepdims=False, dtype=None, dim=None, keepdim=None):
+        return self._jnp().sum(self, axis if dim is None else dim, keepdims if keepdim is None else keepdim)
+
+    def mean(self, axis=None, keepdims=False, dim=None, keepdim=None):
+        return self._jnp().mean(self, axis if dim is None else dim, keepdims if keepdim is None else keepdim)
+
+    def var(self, axis=None, ddof=0, keepdims=False):
+        return self._jnp().var(self, axis, ddof, keepdims)
+
+    def std(self, axis=None, ddof=0, keepdims=False):
+        return self._jnp().std(self, axis, ddof, keepdims)
+
+    def max(self, axis=None, keepdims=False):
+        return self._jnp().max(self, axis, keepdims)
+
+    def min(self, axis=None, keepdims=False):
+        return self._jnp().min(self, axis, keepdims)
+
+    def any(self, axis=None, keepdims=False):
+        return self._jnp().any(self, axis, keepdims)
+
+    def all(self, axis=None, keepdims=False):
+        return self._jnp().all(self, axis, keepdims)
+
+    def prod(self, axis=None):
+        return self._jnp().prod(self, axis)
+
+    def argsort(self, axis=-1):
+        return self._jnp().argsort(self, axis)
+
+    def ravel(self):
+        return self._jnp().ravel(self)
+
+    def flatten(self):
+        return self._jnp().ravel(self)
+
+    def swapaxes(self, a, b):
+        return self._jnp().swapaxes(self, a, b)
+
+    def transpose(self, *axes):
+        if len(axes) == 1 and isinstance(axes[0], (tuple, list)):
+            axes = tuple(axes[0])
+        return self._jnp().transpose(self, axes or None)
+
+    def copy(self):
+        return self.clone()
+
+    def conj(self):
+        return self._jnp().conjugate(self)
 
 
 class _SizeProxy(int):
@@ -195,13 +259,35 @@ def _idx(idx):
     return idx
 
 
+def _advanced(idx):
+    """(tensors, ok): ``idx`` as a tuple of index tensors when it consists of integer tensors / ints only."""
+    parts = idx if isinstance(idx, tuple) else (idx,)
+    if not parts or not all(isinstance(p, (int, torch.Tensor)) and not (isinstance(p, torch.Tensor) and p.dtype == torch.bool)
+                            for p in parts):
+        return None
+    if not any(isinstance(p, torch.Tensor) for p in parts):
+        return None
+    return tuple(p.as_subclass(torch.Tensor).long() if isinstance(p, torch.Tensor) else torch.tensor(p) for p in parts)
+
+
 class _AtIdx:
     def __init__(self, x, idx):
-        self.x, self.idx = x, _idx(idx)
+        self.x, self.idx = x, idx
 
     def set(self, v):
         y = self.x.clone()
-        y[self.idx] = v
+        adv = _advanced(self.idx)
+        if adv is None:
+            y[_idx(self.idx)] = v
+            return y
+        # JAX scatter semantics: updates at out-of-bounds indices are DROPPED (diagnostics.py:275 relies on it)
+        adv = torch.broadcast_tensors(*adv)
+        ok = torch.ones_like(adv[0], dtype=torch.bool)
+        for d, i in enumerate(adv):
+            ok &= (i >= -y.shape[d]) & (i < y.shape[d])
+        vt = torch.broadcast_to(asarray(v).as_subclass(torch.Tensor).to(y.dtype), adv[0].shape + tuple(y.shape[len(adv):]))
+        yt = y.as_subclass(torch.Tensor)
+        yt[tuple(i[ok] for i in adv)] = vt[ok]
         return y
 
     def add(self, v):
@@ -510,6 +596,12 @@ numpy = _importlib.import_module(__name__ + ".numpy")
 lax = _importlib.import_module(__name__ + ".lax")
 random = _importlib.import_module(__name__ + ".random")
 scipy = _importlib.import_module(__name__ + ".scipy")
+
+nn = _StubModule("jax.nn")
+nn.logsumexp = lambda a, axis=None, b=None, keepdims=False: scipy.special.logsumexp(a, axis=axis, keepdims=keepdims)
+nn.sigmoid = lambda x: scipy.special.expit(x)
+nn.softmax = lambda x, axis=-1: _wrap(torch.softmax(asarray(x).as_subclass(torch.Tensor), dim=axis))
+sys.modules["jax.nn"] = nn
 
 typing = _StubModule("jax.typing")
 typing.ArrayLike = object

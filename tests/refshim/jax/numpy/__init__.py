@@ -155,16 +155,23 @@ def _axis(axis):
     return None if axis is None else (tuple(axis) if isinstance(axis, (tuple, list)) else int(axis))
 
 
-def sum(x, axis=None, keepdims=False, dtype=None):
+def sum(x, axis=None, keepdims=False, dtype=None, where=None):
     t = _t(x)
     if t.dtype == torch.bool:
         t = t.to(torch.int32)
+    if where is not None:  # masked reduction: the excluded elements contribute zero
+        t = torch.where(_t(where).to(torch.bool), t, torch.zeros((), dtype=t.dtype))
     return _wrap(torch.sum(t) if axis is None and not keepdims else torch.sum(t, dim=_axis(axis), keepdim=keepdims))
 
 
-def mean(x, axis=None, keepdims=False):
+def mean(x, axis=None, keepdims=False, where=None):
     t = _t(x)
     t = t if t.is_floating_point() else t.to(torch.float32)
+    if where is not None:  # sum over the selected elements / their count (nan when none is selected, as in NumPy / JAX)
+        m = torch.broadcast_to(_t(where).to(torch.bool), t.shape)
+        num = sum(t, axis, keepdims, where=m)
+        den = sum(m.to(t.dtype), axis, keepdims)
+        return _wrap(_t(num) / _t(den))
     return _wrap(torch.mean(t) if axis is None and not keepdims else torch.mean(t, dim=_axis(axis), keepdim=keepdims))
 
 
@@ -200,12 +207,68 @@ def argmin(x, axis=None):
     return _wrap(torch.argmin(_t(x)) if axis is None else torch.argmin(_t(x), dim=int(axis)))
 
 
-def any(x, axis=None):
-    return _wrap(torch.any(_t(x).to(torch.bool)) if axis is None else torch.any(_t(x).to(torch.bool), dim=int(axis)))
+def any(x, axis=None, keepdims=False):
+    t = _t(x).to(torch.bool)
+    return _wrap(torch.any(t) if axis is None and not keepdims else
+                 torch.any(t, dim=tuple(range(t.ndim)) if axis is None else _axis(axis), keepdim=keepdims))
 
 
-def all(x, axis=None):
-    return _wrap(torch.all(_t(x).to(torch.bool)) if axis is None else torch.all(_t(x).to(torch.bool), dim=int(axis)))
+def all(x, axis=None, keepdims=False):
+    t = _t(x).to(torch.bool)
+    return _wrap(torch.all(t) if axis is None and not keepdims else
+                 torch.all(t, dim=tuple(range(t.ndim)) if axis is None else _axis(axis), keepdim=keepdims))
+
+
+def repeat(x, repeats, axis=None, total_repeat_length=None):
+    t = _t(x)
+    r = repeats if isinstance(repeats, int) else _t(repeats).long()
+    return _wrap(torch.repeat_interleave(t.reshape(-1) if axis is None else t, r, dim=None if axis is None else int(axis)))
+
+
+def average(x, axis=None, weights=None):
+    if weights is None:
+        return mean(x, axis)
+    t, w = _t(x), _t(weights)
+    if axis is None:
+        return _wrap(torch.sum(t * w) / torch.sum(w))
+    shape = [1] * t.ndim
+    shape[int(axis)] = -1
+    wv = w.reshape(shape) if w.ndim == 1 else w
+    return _wrap(torch.sum(t * wv, dim=int(axis)) / torch.sum(wv, dim=int(axis)))
+
+
+def nanmean(x, axis=None):
+    return _wrap(torch.nanmean(_t(x)) if axis is None else torch.nanmean(_t(x), dim=_axis(axis)))
+
+
+def median(x, axis=None):
+    t = _t(x)
+    return quantile(t, 0.5, axis=axis)  # numpy semantics (mean of the two middle values), unlike torch.median
+
+
+def quantile(x, q, axis=None, method="linear"):
+    t = _t(x)
+    t = t if t.is_floating_point() else t.to(torch.float32)
+    qt = _t(q).to(t.dtype)
+    return _wrap(torch.quantile(t.reshape(-1) if axis is None else t, qt, dim=None if axis is None else int(axis), interpolation=method))
+
+
+def moveaxis(x, source, destination):
+    return _wrap(torch.movedim(_t(x), source, destination))
+
+
+def indices(dimensions, dtype=None):
+    grids = torch.meshgrid(*[torch.arange(int(n), dtype=_np_dtype_to_torch(dtype) or torch.int32) for n in dimensions], indexing="ij")
+    return _wrap(torch.stack(grids))
+
+
+def conjugate(x):
+    return _wrap(torch.conj(_t(x)).resolve_conj())
+
+
+conj = conjugate
+real = lambda x: _wrap(torch.real(_t(x)))  # noqa: E731
+imag = lambda x: _wrap(torch.imag(_t(x)))  # noqa: E731
 
 
 def cumsum(x, axis=0):
@@ -234,7 +297,11 @@ def outer(a, b):
 
 
 def einsum(spec, *ops, **kw):
-    return _wrap(torch.einsum(spec, *[_t(o) for o in ops]))
+    ts = [_t(o) for o in ops]
+    dt = ts[0].dtype
+    for t in ts[1:]:
+        dt = torch.promote_types(dt, t.dtype)
+    return _wrap(torch.einsum(spec, *[t.to(dt) for t in ts]))
 
 
 def tensordot(a, b, axes=2):
@@ -403,5 +470,9 @@ linalg.__getattr__ = lambda item: _Missing(f"jax.numpy.linalg.{item}")
 sys.modules["jax.numpy.linalg"] = linalg
 
 fft = types.ModuleType("jax.numpy.fft")
+fft.rfft = lambda x, n=None, axis=-1: _wrap(torch.fft.rfft(_t(x), n=n, dim=axis))
+fft.irfft = lambda x, n=None, axis=-1: _wrap(torch.fft.irfft(_t(x), n=n, dim=axis))
+fft.fft = lambda x, n=None, axis=-1: _wrap(torch.fft.fft(_t(x), n=n, dim=axis))
+fft.ifft = lambda x, n=None, axis=-1: _wrap(torch.fft.ifft(_t(x), n=n, dim=axis))
 fft.__getattr__ = lambda item: _Missing(f"jax.numpy.fft.{item}")
 sys.modules["jax.numpy.fft"] = fft

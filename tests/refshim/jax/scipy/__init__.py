@@ -46,6 +46,7 @@ special.logit = lambda x: _wrap(torch.logit(_t(x)))
 special.erf = lambda x: _wrap(torch.erf(_t(x)))
 special.erfinv = lambda x: _wrap(torch.erfinv(_t(x)))
 special.gammaln = lambda x: _wrap(torch.lgamma(_t(x)))
+special.ndtri = lambda x: _wrap(torch.special.ndtri(_t(x)))
 special.__getattr__ = lambda item: _Missing(f"jax.scipy.special.{item}")
 
 stats = types.ModuleType("jax.scipy.stats")

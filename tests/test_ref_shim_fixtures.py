@@ -3,8 +3,9 @@
 ``tests/golden/ref_shim_fixtures.json`` is written by ``tests/golden/gen_ref_shim_fixtures.py``: ``/root/reference/blackjax``
 imported unmodified on top of ``tests/refshim`` (torch / NumPy stand-in for the ~60 JAX functions the hot path calls --
 NOT JAX, read its docstring) and run: ``blackjax.hmc / mhmc / dynamic_hmc / nuts / ghmc`` transitions (diagonal and dense
-metrics, all four integrators, rejections, divergences, depth limits), ``run_inference_algorithm``, ``build_schedule`` and
-four ``window_adaptation`` runs with every step's adaptation state.  What this pins: everything the reference's code DECIDES
+metrics, all four integrators, rejections, divergences, depth limits), ``run_inference_algorithm``, ``build_schedule``,
+four ``window_adaptation`` runs with every step's adaptation state, a ``chees_adaptation`` and a ``meads_adaptation`` run
+and the diagnostics (``effective_sample_size``, ``rhat``, ``ess_bulk``, ``ess_tail``).  What this pins: everything the reference's code DECIDES
 (key consumption, tree growth and termination, acceptance, adaptation updates, window ends) and its arithmetic up to fp32
 rounding.  What it does not: the ``jax.random`` bit streams (the stand-in's ``jax.random`` is ``oracle/prng.py``: SURVEY row
 a34 stays "parity unpinned").
@@ -280,20 +281,129 @@ def test_ghmc_equals_the_reference_code():
         np.testing.assert_allclose(st.slice, unhex(rec["slice"]), rtol=2e-4, atol=2e-6)
 
 
+def test_meads_equals_the_reference_code():
+    """``meads_adaptation(...).run``, 12 steps, 16 chains in 4 folds (fold freezing, cross-fold roll, three reshuffles)."""
+    from oracle import meads as omeads
+
+    m = FX["meads"]
+    N, D = m["N"], m["D"]
+    sig = ladder(D, m["lo"], m["hi"])
+    fn = otargets.diag_gaussian((f32(1) / (sig * sig)).astype(f32))
+    q0 = (sig * prng.normal(prng.key(m["q0_key_seed"]), (N, D))).astype(f32)
+    last, params, hist = omeads.run(np.asarray(m["run_key"], np.uint32), (f32(m["q0_scale"]) * q0).astype(f32), fn,
+                                    m["num_steps"], num_folds=m["num_folds"])
+    assert np.stack([h[2].is_accepted for h in hist]).astype(int).tolist() == m["is_accepted_per_step"]
+    np.testing.assert_allclose(np.stack([h[1].step_size for h in hist]), unhex(m["step_size_per_step"]), rtol=2e-5)
+    np.testing.assert_allclose(np.stack([h[1].alpha for h in hist]), unhex(m["alpha_per_step"]), rtol=2e-5)
+    np.testing.assert_allclose(np.stack([h[1].delta for h in hist]), unhex(m["delta_per_step"]), rtol=2e-5)
+    np.testing.assert_allclose(last.position, unhex(m["final_position"]), rtol=1e-4, atol=5e-5)
+    for name, v in m["parameters"].items():
+        np.testing.assert_allclose(params[name], unhex(v), rtol=2e-5)
+
+
+def _chees_setup(c):
+    from oracle import chees as ochees
+
+    N, D, T = c["N"], c["D"], c["T"]
+    sig = ladder(D, c["lo"], c["hi"])
+    fn = otargets.diag_gaussian((f32(1) / (sig * sig)).astype(f32))
+    q0 = prng.normal(prng.key(c["q0_key_seed"]), (N, D))
+    return ochees, N, D, T, fn, q0
+
+
+def test_chees_run_equals_the_reference_code():
+    """``chees_adaptation(...).run`` as a whole (pooled statistics damp rounding differences: 40 steps stay within 1e-5):
+    per-step step size, trajectory length and leapfrog counts, accept bits, final parameters.  (The optimiser on the
+    reference side is tests/refshim/optax's restatement of Adam: optax itself is third party, not under /root/reference.)"""
+    c = FX["chees"]
+    ochees, N, D, T, fn, q0 = _chees_setup(c)
+    rec = lambda t, state, info, adapt: (state.position.copy(), info, adapt)  # noqa: E731
+    last, rga, params, (adapt, hist) = ochees.run(fn, prng.key(c["run_key_seed"]), q0, c["initial_step_size"],
+                                                  ochees.Adam(**c["adam"]), T, num_chains=N, record=rec)
+    assert [int(h[1].num_integration_steps) for h in hist] == [n[0] for n in c["num_integration_steps"]]
+    assert np.stack([h[1].is_accepted for h in hist]).astype(int).tolist() == c["is_accepted"]
+    assert np.stack([h[1].is_divergent for h in hist]).astype(int).tolist() == c["is_divergent"]
+    np.testing.assert_allclose([h[2].step_size for h in hist], unhex(c["step_size"]), rtol=2e-5)
+    np.testing.assert_allclose([h[2].trajectory_length for h in hist], unhex(c["trajectory_length"]), rtol=2e-5)
+    np.testing.assert_allclose(np.stack([h[0] for h in hist]), unhex(c["position"]), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(params["step_size"], unhex(c["final_step_size"]), rtol=2e-6)
+    np.testing.assert_allclose(params["integration_steps_params"][0], unhex(c["final_num_leapfrog"]), rtol=2e-5)
+    assert [int(adapt.random_generator_arg)] * N == c["final_random_generator_arg"]
+
+
+def test_chees_updates_equal_the_reference_code_step_by_step():
+    """Teacher forcing: the reference's adaptation state at t, its step-t proposals / acceptance probabilities -> the
+    oracle's ``update`` (harmonic-mean acceptance, dual averaging, ChEES criterion gradient, Adam, clipping, moving
+    averages) -> the reference's state at t + 1; and the transition of each step from the reference's positions."""
+    c = FX["chees"]
+    ochees, N, D, T, fn, q0 = _chees_setup(c)
+    max_bits = int(np.ceil(np.log2(T + 1000)))  # chees_adaptation.py:761-765 (max_sampling_steps = 1000)
+    jitter = lambda i: f32(f32(ochees.halton_sequence(i, max_bits) * f32(1.0)) + f32(0.0))  # noqa: E731
+    init, update = ochees.base(jitter, lambda i: i + 1, ochees.Adam(**c["adam"]), ochees.OPTIMAL_TARGET_ACCEPTANCE_RATE,
+                               0.5, 1000, True)
+    st = init(0, c["initial_step_size"])
+    pos, pp, pm = unhex(c["position"]), unhex(c["proposal_position"]), unhex(c["proposal_momentum"])
+    acc, div = unhex(c["acceptance_rate"]), np.asarray(c["is_divergent"], bool)
+    names = ("step_size", "log_step_size_ma", "trajectory_length", "log_trajectory_length_ma", "da_log_x", "da_log_x_avg",
+             "da_avg_error", "da_mu", "adam_mu", "adam_nu")
+    F = {k: unhex(c[k]) for k in names}
+    keys = prng.split(prng.key(c["run_key_seed"]), T)
+    for t in range(T):
+        prev = q0 if t == 0 else pos[t - 1]
+        L = ochees.integration_steps(jitter(st.random_generator_arg), f32(st.trajectory_length / st.step_size))
+        assert L == c["num_integration_steps"][t][0], t
+        s2, info = ohmc.kernel(keys[t], ohmc.init(prev, fn), fn, st.step_size, np.ones(D, f32), L)
+        assert info.is_accepted.astype(int).tolist() == c["is_accepted"][t], t
+        np.testing.assert_allclose(s2.position, pos[t], rtol=1e-4, atol=2e-5)
+        new = update(st, pp[t], pm[t], prev, acc[t], div[t], np.ones(D, f32))
+        got = {"step_size": new.step_size, "log_step_size_ma": new.log_step_size_moving_average,
+               "trajectory_length": new.trajectory_length, "log_trajectory_length_ma": new.log_trajectory_length_moving_average,
+               "da_log_x": new.da_state.log_step_size, "da_log_x_avg": new.da_state.log_step_size_avg,
+               "da_avg_error": new.da_state.avg_error, "da_mu": new.da_state.mu,
+               "adam_mu": new.optim_state.mu, "adam_nu": new.optim_state.nu}
+        for k, v in got.items():
+            np.testing.assert_allclose(v, F[k][t], rtol=2e-5, atol=2e-7, err_msg=f"{k} at step {t}")
+        assert (new.random_generator_arg, new.step, new.da_state.step, new.optim_state.count) == (
+            c["random_generator_arg"][t], c["step"][t], c["da_step"][t], c["adam_count"][t]), t
+        st = ochees.ChEESAdaptationState(  # continue from the REFERENCE's state
+            F["step_size"][t], F["log_step_size_ma"][t], F["trajectory_length"][t], F["log_trajectory_length_ma"][t],
+            oad.DualAveragingState(F["da_log_x"][t], F["da_log_x_avg"][t], int(c["da_step"][t]), F["da_avg_error"][t], F["da_mu"][t]),
+            type(new.optim_state)(int(c["adam_count"][t]), F["adam_mu"][t], F["adam_nu"][t]),
+            c["random_generator_arg"][t], c["step"][t])
+
+
+@pytest.mark.parametrize("name", sorted(FX["diagnostics"]))
+def test_diagnostics_equal_the_reference_code(name):
+    """``effective_sample_size`` / ``rhat`` / ``potential_scale_reduction`` / ``ess_bulk`` / ``ess_tail`` of the reference
+    (diagnostics.py, executed) on NumPy-generated chains: the PRODUCT's implementation on CPU tensors, and the oracle's."""
+    import torch
+
+    import blackjax_amd.diagnostics as product
+    from oracle import diagnostics as odiag
+
+    r = FX["diagnostics"][name]
+    x = unhex(r["x"])
+    for fn, key in (("effective_sample_size", "ess"), ("rhat", "rhat"), ("potential_scale_reduction", "psr"),
+                    ("ess_bulk", "ess_bulk"), ("ess_tail", "ess_tail")):
+        ref = unhex(r[key])
+        np.testing.assert_allclose(np.asarray(getattr(product, fn)(torch.as_tensor(x))), ref, rtol=2e-5, err_msg=f"product {fn}")
+        np.testing.assert_allclose(np.asarray(getattr(odiag, fn)(x)), ref, rtol=2e-5, err_msg=f"oracle {fn}")
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/blackjax"), reason="/root/reference is not on this box")
 def test_generator_reproduces_the_committed_fixture():
     """The committed file IS what the generator writes today (the reference on the stand-in, in its own process)."""
     import tempfile
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, BJX_REF_SHIM_OUT=os.path.join(tmp, "out.json"), BJX_REF_SHIM_ONLY="samplers:hmc_rejections,nuts_funnel,mhmc;schedules;ghmc")
+        env = dict(os.environ, BJX_REF_SHIM_OUT=os.path.join(tmp, "out.json"), BJX_REF_SHIM_ONLY="samplers:hmc_rejections,nuts_funnel,mhmc;schedules;ghmc;diagnostics")
         subprocess.run([sys.executable, os.path.join(HERE, "golden", "gen_ref_shim_fixtures.py")], check=True, env=env,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
         with open(env["BJX_REF_SHIM_OUT"]) as fh:
             again = json.load(fh)
     for name in ("hmc_rejections", "nuts_funnel", "mhmc"):
         assert again["samplers"][name] == FX["samplers"][name], name
-    assert again["schedules"] == FX["schedules"] and again["ghmc"] == FX["ghmc"]
+    assert again["schedules"] == FX["schedules"] and again["ghmc"] == FX["ghmc"] and again["diagnostics"] == FX["diagnostics"]
     assert again["reference_sources_sha256"] == FX["reference_sources_sha256"]
 
 
