@@ -140,12 +140,12 @@ def sampler_case(spec):
         alg = getattr(blackjax, algo)(fn, spec["eps"], imm, spec["L"], **kw)
     elif algo == "nuts":
         alg = blackjax.nuts(fn, spec["eps"], imm, max_num_doublings=spec["max_num_doublings"], **kw)
-    elif algo == "dynamic_hmc":
-        alg = blackjax.dynamic_hmc(fn, spec["eps"], imm, **kw)
+    elif algo in ("dynamic_hmc", "dmhmc"):
+        alg = getattr(blackjax, algo)(fn, spec["eps"], imm, **kw)
     else:
         raise ValueError(algo)
     q0 = initial_positions(spec, N, D)
-    if algo == "dynamic_hmc":
+    if algo in ("dynamic_hmc", "dmhmc"):
         arg_keys = jax.random.split(jax.random.key(spec["arg_key_seed"]), N)
         states = jax.vmap(alg.init)(q0, arg_keys)
     else:
@@ -166,7 +166,7 @@ def sampler_case(spec):
                    rightmost_position=sel(info.trajectory_rightmost_state.position))
     else:
         out.update(is_accepted=ints(info.is_accepted), proposal_position=sel(info.proposal.position))
-    if algo == "dynamic_hmc":
+    if algo in ("dynamic_hmc", "dmhmc"):
         out.update(next_random_generator_arg=np.asarray(new.random_generator_arg).astype(np.uint32).tolist())
     return out
 
@@ -197,6 +197,8 @@ SAMPLER_CASES = [
          target=dict(kind="ar1", rho=0.8), q0_key_seed=19, step_key_seed=20),
     dict(name="dynamic_hmc", algorithm="dynamic_hmc", N=32, D=12, eps=0.3, metric="identity",
          target=dict(kind="diag_gaussian", lo=-0.3, hi=0.3), q0_key_seed=21, step_key_seed=22, arg_key_seed=23),
+    dict(name="dmhmc", algorithm="dmhmc", N=24, D=10, eps=0.3, metric="identity",
+         target=dict(kind="diag_gaussian", lo=-0.3, hi=0.3), q0_key_seed=36, step_key_seed=37, arg_key_seed=38),
     # as in gen_jax_fixtures.py
     dict(name="nuts_funnel", algorithm="nuts", N=16, D=10, eps=0.2, max_num_doublings=6, metric="identity",
          target=dict(kind="funnel"), q0_key_seed=2, q0_scale=0.5, step_key_seed=4),
@@ -377,6 +379,21 @@ def diagnostics_case():
     return out
 
 
+def host_helpers_case():
+    """dynamic_hmc.py:205-223 / adjusted_mclmc.py:281-288: the Halton helpers the engine mirrors on the host."""
+    from blackjax.mcmc.adjusted_mclmc import rescale
+    from blackjax.mcmc.dynamic_hmc import halton_sequence, halton_trajectory_length
+
+    out = {"halton": {}, "trajectory_length": {}, "rescale": {}}
+    for bits in (5, 10, 11):
+        out["halton"][str(bits)] = f32hex([halton_sequence(jnp.asarray(i, jnp.int32), bits) for i in range(70)])
+    for adj in (1.7, 5.0, 12.3):
+        out["trajectory_length"][str(adj)] = ints([halton_trajectory_length(jnp.asarray(i, jnp.int32), adj) for i in range(70)])
+    for mu in (1.0, 1.7, 2.5, 5.0, 12.3, 100.0):
+        out["rescale"][str(mu)] = f32hex(rescale(jnp.asarray(mu)))
+    return out
+
+
 def sha256_of(paths):
     out = {}
     for p in paths:
@@ -436,6 +453,8 @@ def main():
         out["meads"] = meads_case()
     if selected("diagnostics"):
         out["diagnostics"] = diagnostics_case()
+    if selected("host_helpers"):
+        out["host_helpers"] = host_helpers_case()
     path = os.environ.get("BJX_REF_SHIM_OUT") or os.path.join(HERE, "ref_shim_fixtures.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

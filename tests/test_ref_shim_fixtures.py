@@ -136,11 +136,11 @@ def test_oracle_transition_equals_the_reference_code(name):
         elif algo == "nuts":
             st, info = onuts.kernel(key, ohmc.init(q0, fn), fn, f32(c["eps"]), imm, c["max_num_doublings"], thr,
                                     coefficients=coef)
-        else:
+        else:  # dynamic_hmc / dmhmc (dynamic trajectory lengths; dmhmc: with the multinomial proposal)
             s0 = ohmc.init(q0, fn)
             ds = ohmc.DynamicHMCState(s0.position, s0.logdensity, s0.logdensity_grad,
                                       prng.split(prng.key(c["arg_key_seed"]), N))
-            st, info = ohmc.dynamic_hmc_kernel(key, ds, fn, f32(c["eps"]), imm, thr)
+            st, info = ohmc.dynamic_hmc_kernel(key, ds, fn, f32(c["eps"]), imm, thr, multinomial=algo == "dmhmc")
             dyn = st.random_generator_arg
     d = info._asdict()
     if algo == "nuts":
@@ -372,6 +372,20 @@ def test_chees_updates_equal_the_reference_code_step_by_step():
             c["random_generator_arg"][t], c["step"][t])
 
 
+def test_host_helpers_equal_the_reference_code():
+    """The PRODUCT's host-side Halton helpers (blackjax_amd/dynamic_hmc.py) against dynamic_hmc.py:205-223 executed."""
+    import importlib
+
+    product = importlib.import_module("blackjax_amd.dynamic_hmc")
+    h = FX["host_helpers"]
+    for bits, ref in h["halton"].items():
+        assert [product.halton_sequence(i, int(bits)) for i in range(70)] == unhex(ref).tolist(), bits
+    for adj, ref in h["trajectory_length"].items():
+        assert [product.halton_trajectory_length(i, float(adj)) for i in range(70)] == ref, adj
+    for mu, ref in h["rescale"].items():
+        np.testing.assert_allclose(product.rescale(float(mu)), unhex(ref), rtol=2e-7)
+
+
 @pytest.mark.parametrize("name", sorted(FX["diagnostics"]))
 def test_diagnostics_equal_the_reference_code(name):
     """``effective_sample_size`` / ``rhat`` / ``potential_scale_reduction`` / ``ess_bulk`` / ``ess_tail`` of the reference
@@ -409,7 +423,7 @@ def test_generator_reproduces_the_committed_fixture():
 
 # ------------------------------------------------------------------------------------------------ the HIP path
 _NOT_YET_ON_HARDWARE = pytest.mark.xfail(strict=False, reason="written after round 5's last GPU call: never run on hardware")
-_GPU_CASES = [n for n, c in sorted(FX["samplers"].items()) if c["algorithm"] in ("hmc", "mhmc", "nuts")]
+_GPU_CASES = [n for n, c in sorted(FX["samplers"].items()) if c["algorithm"] in ("hmc", "mhmc", "nuts")]  # (dynamic: per-chain keys)
 
 
 @pytest.mark.gpu
