@@ -35,23 +35,30 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, os.path.join(ROOT, "tests", "refshim"))  # ONLY in this process: a module named jax lives there
-sys.path.insert(0, REF)
+# BJX_REAL_JAX=1: the SAME cases on a real JAX + BlackJAX installation (any machine that has them; PYTHONPATH may point at
+# a BlackJAX checkout) -> tests/golden/ref_jax_fixtures.json, which tests/test_ref_shim_fixtures.py picks up as a second
+# fixture set.  That run DOES exercise jax.random and closes SURVEY row a34 for every stream these cases consume.
+REAL_JAX = os.environ.get("BJX_REAL_JAX", "0") == "1"
+if not REAL_JAX:
+    sys.path.insert(0, os.path.join(ROOT, "tests", "refshim"))  # ONLY in this process: a module named jax lives there
+    sys.path.insert(0, REF)
+    # blackjax/_version.py is written by setuptools_scm at install time; the source tree has none
+    _v = types.ModuleType("blackjax._version")
+    _v.__version__ = "reference-source-tree"
+    sys.modules["blackjax._version"] = _v
+else:
+    os.environ.setdefault("JAX_PLATFORMS", "cpu")
 sys.path.insert(0, ROOT)
-# blackjax/_version.py is written by setuptools_scm at install time; the source tree has none
-_v = types.ModuleType("blackjax._version")
-_v.__version__ = "reference-source-tree"
-sys.modules["blackjax._version"] = _v
 
 import numpy as np  # noqa: E402
 
-import jax  # noqa: E402  (tests/refshim/jax)
+import jax  # noqa: E402  (tests/refshim/jax unless BJX_REAL_JAX=1)
 import jax.numpy as jnp  # noqa: E402
 
-assert jax.__version__.endswith("refshim"), "this generator must run on the stand-in, not on a real JAX"
-import blackjax  # noqa: E402  (/root/reference/blackjax)
+assert jax.__version__.endswith("refshim") != REAL_JAX, "stand-in vs real JAX: check BJX_REAL_JAX and sys.path"
+import blackjax  # noqa: E402  (/root/reference/blackjax on the stand-in)
 
-assert os.path.realpath(blackjax.__file__).startswith(REF + "/"), blackjax.__file__
+assert REAL_JAX or os.path.realpath(blackjax.__file__).startswith(REF + "/"), blackjax.__file__
 
 
 def words(k):
@@ -167,7 +174,7 @@ def sampler_case(spec):
     else:
         out.update(is_accepted=ints(info.is_accepted), proposal_position=sel(info.proposal.position))
     if algo in ("dynamic_hmc", "dmhmc"):
-        out.update(next_random_generator_arg=np.asarray(new.random_generator_arg).astype(np.uint32).tolist())
+        out.update(next_random_generator_arg=words(new.random_generator_arg))
     return out
 
 
@@ -396,17 +403,22 @@ def host_helpers_case():
 
 def sha256_of(paths):
     out = {}
+    base = REF if not REAL_JAX else os.path.dirname(os.path.dirname(os.path.abspath(blackjax.__file__)))
     for p in paths:
-        with open(os.path.join(REF, p), "rb") as fh:
-            out[p] = hashlib.sha256(fh.read()).hexdigest()
+        full = os.path.join(base, p)
+        if os.path.exists(full):
+            with open(full, "rb") as fh:
+                out[p] = hashlib.sha256(fh.read()).hexdigest()
     return out
 
 
 def main():
     out = {
         "generator": "tests/golden/gen_ref_shim_fixtures.py",
-        "what": "the reference's own source executed on tests/refshim (torch/NumPy stand-in for JAX; jax.random = oracle/prng.py). "
-                "NOT produced by JAX; does not pin the jax.random bit streams (SURVEY a34).",
+        "what": ("the reference's own source executed on tests/refshim (torch/NumPy stand-in for JAX; jax.random = oracle/prng.py). "
+                 "NOT produced by JAX; does not pin the jax.random bit streams (SURVEY a34).") if not REAL_JAX else
+                f"BlackJAX {getattr(blackjax, '__version__', '?')} on JAX {jax.__version__} (CPU): the real reference, jax.random included.",
+        "real_jax": REAL_JAX,
         "reference_sources_sha256": sha256_of([
             "blackjax/mcmc/hmc.py", "blackjax/mcmc/nuts.py", "blackjax/mcmc/trajectory.py", "blackjax/mcmc/termination.py",
             "blackjax/mcmc/proposal.py", "blackjax/mcmc/integrators.py", "blackjax/mcmc/metrics.py", "blackjax/mcmc/dynamic_hmc.py",
@@ -455,7 +467,7 @@ def main():
         out["diagnostics"] = diagnostics_case()
     if selected("host_helpers"):
         out["host_helpers"] = host_helpers_case()
-    path = os.environ.get("BJX_REF_SHIM_OUT") or os.path.join(HERE, "ref_shim_fixtures.json")
+    path = os.environ.get("BJX_REF_SHIM_OUT") or os.path.join(HERE, "ref_jax_fixtures.json" if REAL_JAX else "ref_shim_fixtures.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")

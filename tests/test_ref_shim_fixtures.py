@@ -36,7 +36,19 @@ PATH = os.path.join(HERE, "golden", "ref_shim_fixtures.json")
 f32 = np.float32
 
 with open(PATH) as _fh:
-    FX = json.load(_fh)
+    FX = json.load(_fh)  # the stand-in's set: committed, defines the case names
+# the same cases from a REAL JAX + BlackJAX (BJX_REAL_JAX=1 python tests/golden/gen_ref_shim_fixtures.py on a machine that
+# has them): absent so far.  When present every comparison below runs against it as well -- and then jax.random IS checked.
+JAX_PATH = os.path.join(HERE, "golden", "ref_jax_fixtures.json")
+_SETS = {"reference-on-stand-in": FX}
+if os.path.exists(JAX_PATH):
+    with open(JAX_PATH) as _fh:
+        _SETS["reference-on-real-jax"] = json.load(_fh)
+
+
+@pytest.fixture(params=sorted(_SETS))
+def fx(request):
+    return _SETS[request.param]
 
 
 def unhex(x):
@@ -121,8 +133,8 @@ def _coefficients(c):
 
 
 @pytest.mark.parametrize("name", sorted(FX["samplers"]))
-def test_oracle_transition_equals_the_reference_code(name):
-    c = FX["samplers"][name]
+def test_oracle_transition_equals_the_reference_code(fx, name):
+    c = fx["samplers"][name]
     N, D = c["N"], c["D"]
     fn, q0, imm = oracle_target(c["target"], D), initial_positions(c, N, D), metric_of(c, D)
     key = np.asarray(c["step_key"], np.uint32)
@@ -164,19 +176,19 @@ def test_cases_cover_what_they_are_named_for():
     assert len(set(s["nuts_funnel"]["num_integration_steps"])) > 1
 
 
-def test_schedules_equal_the_reference_code():
+def test_schedules_equal_the_reference_code(fx):
     """staged_adaptation.py:366-403 executed, 16 lengths -- the oracle's AND the product's ``build_schedule``."""
     from blackjax_amd.adaptation import build_schedule as product_schedule
 
-    for T, ref in FX["schedules"].items():
+    for T, ref in fx["schedules"].items():
         assert [[int(a), int(bool(b))] for a, b in oad.build_schedule(int(T))] == ref, T
         assert [[int(a), int(bool(b))] for a, b in product_schedule(int(T))] == ref, T
 
 
-def test_run_inference_key_layout_equals_the_reference_code():
+def test_run_inference_key_layout_equals_the_reference_code(fx):
     """Step-major keys (scan over ``split(key, T)`` of vmap over ``split(keys[t], N)``), and the reference's own
     ``run_inference_algorithm(initial_position=...)`` on one chain (util.py:198-203: the key is split once more first)."""
-    r = FX["run_inference"]
+    r = fx["run_inference"]
     N, D, L, T = r["N"], r["D"], r["L"], r["T"]
     fn = oracle_target(r["target"], D)
     q0 = prng.normal(prng.key(r["q0_key_seed"]), (N, D))
@@ -200,10 +212,10 @@ def _warmup_arrays(c):
 
 
 @pytest.mark.parametrize("name", sorted(FX["warmup"]))
-def test_adaptation_updates_equal_the_reference_code_step_by_step(name):
+def test_adaptation_updates_equal_the_reference_code_step_by_step(fx, name):
     """Every step of the reference's run: its state at t, its new position and acceptance rate -> the oracle's
     ``adapt_update`` -> its state at t + 1 (dual averaging, Welford, window ends with shrinkage, re-initialisation)."""
-    c = FX["warmup"][name]
+    c = fx["warmup"][name]
     N, D, T, diag = c["N"], c["D"], c["T"], c["diag"]
     pos, acc = unhex(c["position"]), unhex(c["acceptance_rate"])
     L, step, wn = _warmup_arrays(c)
@@ -235,10 +247,10 @@ def test_adaptation_updates_equal_the_reference_code_step_by_step(name):
 
 
 @pytest.mark.parametrize("name", sorted(FX["warmup"]))
-def test_warmup_transitions_equal_the_reference_code_step_by_step(name):
+def test_warmup_transitions_equal_the_reference_code_step_by_step(fx, name):
     """The transition inside each warm-up step: chain key ``split(run_key, N)[c]``, step key ``split(chain_key, T)[t]``
     (staged_adaptation.py:868), the step size and metric of the state BEFORE the step -- from the reference's position."""
-    c = FX["warmup"][name]
+    c = fx["warmup"][name]
     N, D, T, diag = c["N"], c["D"], c["T"], c["diag"]
     fn = oracle_target(c["target"], D)
     q = initial_positions(c, N, D)
@@ -264,14 +276,17 @@ def test_warmup_transitions_equal_the_reference_code_step_by_step(name):
     assert moved > 10
 
 
-def test_ghmc_equals_the_reference_code():
-    g = FX["ghmc"]
+def test_ghmc_equals_the_reference_code(fx):
+    g = fx["ghmc"]
     N, D = g["N"], g["D"]
     sig = ladder(D, g["lo"], g["hi"])
     fn = otargets.diag_gaussian((f32(1) / (sig * sig)).astype(f32))
     q0 = (sig * prng.normal(prng.key(g["q0_key_seed"]), (N, D))).astype(f32)
     st = oghmc.init(q0, fn, np.asarray(g["init_key"], np.uint32))
-    assert np.array_equal(st.momentum, unhex(g["init_momentum"])) and np.array_equal(st.slice, unhex(g["init_slice"]))
+    # (bit-equal on the stand-in, whose jax.random IS the oracle's; XLA's f32 log1p inside erf_inv is not correctly rounded,
+    # so a real JAX's normal draws may sit an ulp or two away)
+    np.testing.assert_allclose(st.momentum, unhex(g["init_momentum"]), rtol=5e-7, atol=1e-7)
+    np.testing.assert_allclose(st.slice, unhex(g["init_slice"]), rtol=5e-7, atol=1e-7)
     for k, rec in zip(np.asarray(g["step_keys"], np.uint32), g["steps"]):
         st, info = oghmc.kernel(k, st, fn, g["eps"], sig, g["alpha"], g["delta"])
         assert info.is_accepted.astype(int).tolist() == rec["is_accepted"]
@@ -281,11 +296,11 @@ def test_ghmc_equals_the_reference_code():
         np.testing.assert_allclose(st.slice, unhex(rec["slice"]), rtol=2e-4, atol=2e-6)
 
 
-def test_meads_equals_the_reference_code():
+def test_meads_equals_the_reference_code(fx):
     """``meads_adaptation(...).run``, 12 steps, 16 chains in 4 folds (fold freezing, cross-fold roll, three reshuffles)."""
     from oracle import meads as omeads
 
-    m = FX["meads"]
+    m = fx["meads"]
     N, D = m["N"], m["D"]
     sig = ladder(D, m["lo"], m["hi"])
     fn = otargets.diag_gaussian((f32(1) / (sig * sig)).astype(f32))
@@ -311,11 +326,11 @@ def _chees_setup(c):
     return ochees, N, D, T, fn, q0
 
 
-def test_chees_run_equals_the_reference_code():
+def test_chees_run_equals_the_reference_code(fx):
     """``chees_adaptation(...).run`` as a whole (pooled statistics damp rounding differences: 40 steps stay within 1e-5):
     per-step step size, trajectory length and leapfrog counts, accept bits, final parameters.  (The optimiser on the
     reference side is tests/refshim/optax's restatement of Adam: optax itself is third party, not under /root/reference.)"""
-    c = FX["chees"]
+    c = fx["chees"]
     ochees, N, D, T, fn, q0 = _chees_setup(c)
     rec = lambda t, state, info, adapt: (state.position.copy(), info, adapt)  # noqa: E731
     last, rga, params, (adapt, hist) = ochees.run(fn, prng.key(c["run_key_seed"]), q0, c["initial_step_size"],
@@ -331,11 +346,11 @@ def test_chees_run_equals_the_reference_code():
     assert [int(adapt.random_generator_arg)] * N == c["final_random_generator_arg"]
 
 
-def test_chees_updates_equal_the_reference_code_step_by_step():
+def test_chees_updates_equal_the_reference_code_step_by_step(fx):
     """Teacher forcing: the reference's adaptation state at t, its step-t proposals / acceptance probabilities -> the
     oracle's ``update`` (harmonic-mean acceptance, dual averaging, ChEES criterion gradient, Adam, clipping, moving
     averages) -> the reference's state at t + 1; and the transition of each step from the reference's positions."""
-    c = FX["chees"]
+    c = fx["chees"]
     ochees, N, D, T, fn, q0 = _chees_setup(c)
     max_bits = int(np.ceil(np.log2(T + 1000)))  # chees_adaptation.py:761-765 (max_sampling_steps = 1000)
     jitter = lambda i: f32(f32(ochees.halton_sequence(i, max_bits) * f32(1.0)) + f32(0.0))  # noqa: E731
@@ -372,12 +387,12 @@ def test_chees_updates_equal_the_reference_code_step_by_step():
             c["random_generator_arg"][t], c["step"][t])
 
 
-def test_host_helpers_equal_the_reference_code():
+def test_host_helpers_equal_the_reference_code(fx):
     """The PRODUCT's host-side Halton helpers (blackjax_amd/dynamic_hmc.py) against dynamic_hmc.py:205-223 executed."""
     import importlib
 
     product = importlib.import_module("blackjax_amd.dynamic_hmc")
-    h = FX["host_helpers"]
+    h = fx["host_helpers"]
     for bits, ref in h["halton"].items():
         assert [product.halton_sequence(i, int(bits)) for i in range(70)] == unhex(ref).tolist(), bits
     for adj, ref in h["trajectory_length"].items():
@@ -387,7 +402,7 @@ def test_host_helpers_equal_the_reference_code():
 
 
 @pytest.mark.parametrize("name", sorted(FX["diagnostics"]))
-def test_diagnostics_equal_the_reference_code(name):
+def test_diagnostics_equal_the_reference_code(fx, name):
     """``effective_sample_size`` / ``rhat`` / ``potential_scale_reduction`` / ``ess_bulk`` / ``ess_tail`` of the reference
     (diagnostics.py, executed) on NumPy-generated chains: the PRODUCT's implementation on CPU tensors, and the oracle's."""
     import torch
@@ -395,7 +410,7 @@ def test_diagnostics_equal_the_reference_code(name):
     import blackjax_amd.diagnostics as product
     from oracle import diagnostics as odiag
 
-    r = FX["diagnostics"][name]
+    r = fx["diagnostics"][name]
     x = unhex(r["x"])
     for fn, key in (("effective_sample_size", "ess"), ("rhat", "rhat"), ("potential_scale_reduction", "psr"),
                     ("ess_bulk", "ess_bulk"), ("ess_tail", "ess_tail")):
@@ -429,14 +444,14 @@ _GPU_CASES = [n for n, c in sorted(FX["samplers"].items()) if c["algorithm"] in 
 @pytest.mark.gpu
 @_NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("name", _GPU_CASES)
-def test_hip_transition_equals_the_reference_code(dev, name):
+def test_hip_transition_equals_the_reference_code(fx, dev, name):
     """The HIP kernels against the reference's own code, no oracle in between (the engine's shared dense metric runs on
     the fp32 MFMA GEMM: the same 1e-5 as the oracle's fp64-accumulated products)."""
     import torch
 
     import blackjax_amd as bjx
 
-    c = FX["samplers"][name]
+    c = fx["samplers"][name]
     N, D = c["N"], c["D"]
     t = c["target"]
     if t["kind"] == "diag_gaussian":
