@@ -32,6 +32,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True  # importing /root/reference/blackjax must not leave __pycache__ directories in the read-only tree
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
