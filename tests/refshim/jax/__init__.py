@@ -92,7 +92,7 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     """Any ``jax.<something>`` not defined below, and the third-party packages the reference imports at module level
     but the hot path never calls (optax ...), import as permissive stub modules."""
 
-    ROOTS = ("jax", "chex", "fastprogress", "jaxopt", "jaxlib")  # (optax: tests/refshim/optax restates adam)
+    ROOTS = ("jax", "fastprogress", "jaxopt", "jaxlib")  # (optax, chex, absl: small restatements beside this package)
 
     def find_spec(self, fullname, path=None, target=None):
         root = fullname.split(".")[0]
@@ -523,24 +523,32 @@ def vmap(f, in_axes=0, out_axes=0, **kwargs):
 
 
 def value_and_grad(fun, argnums=0, has_aux=False, **kwargs):
-    if argnums != 0:
-        raise NotImplementedError("refshim value_and_grad: argnums != 0")
+    nums = (argnums,) if isinstance(argnums, int) else tuple(argnums)
 
-    def vg(x, *args, **kw):
-        leaves, d = tree_flatten(x)
+    def vg(*args, **kw):
+        flats = [tree_flatten(args[i]) for i in nums]
         with torch.enable_grad():
-            req = [asarray(v).detach().clone().as_subclass(torch.Tensor).requires_grad_(True) for v in leaves]
-            out = fun(tree_unflatten(d, [_wrap(r) for r in req]), *args, **kw)
+            reqs = [[asarray(v).detach().clone().as_subclass(torch.Tensor).requires_grad_(True) for v in leaves]
+                    for leaves, _ in flats]
+            call = list(args)
+            for i, (_, d), req in zip(nums, flats, reqs):
+                call[i] = tree_unflatten(d, [_wrap(r) for r in req])
+            out = fun(*call, **kw)
             val, aux = out if has_aux else (out, None)
             val_t = asarray(val)
+            flat_req = [r for req in reqs for r in req]
             if val_t.requires_grad:
-                grads = torch.autograd.grad(val_t.as_subclass(torch.Tensor), req, allow_unused=True)
+                grads = torch.autograd.grad(val_t.as_subclass(torch.Tensor), flat_req, allow_unused=True)
             else:
-                grads = [None] * len(req)
-        grads = [_wrap(torch.zeros_like(r) if g is None else g.detach()) for g, r in zip(grads, req)]
+                grads = [None] * len(flat_req)
+        grads = [_wrap(torch.zeros_like(r) if g is None else g.detach()) for g, r in zip(grads, flat_req)]
+        trees, k = [], 0
+        for (_, d), req in zip(flats, reqs):
+            trees.append(tree_unflatten(d, grads[k:k + len(req)]))
+            k += len(req)
+        g_out = trees[0] if isinstance(argnums, int) else tuple(trees)
         val_d = _wrap(val_t.detach())
-        g_tree = tree_unflatten(d, grads)
-        return ((val_d, aux), g_tree) if has_aux else (val_d, g_tree)
+        return ((val_d, aux), g_out) if has_aux else (val_d, g_out)
 
     return vg
 
@@ -548,8 +556,8 @@ def value_and_grad(fun, argnums=0, has_aux=False, **kwargs):
 def grad(fun, argnums=0, has_aux=False, **kwargs):
     vg = value_and_grad(fun, argnums, has_aux)
 
-    def g(x, *args, **kw):
-        out = vg(x, *args, **kw)
+    def g(*args, **kw):
+        out = vg(*args, **kw)
         return (out[1], out[0][1]) if has_aux else out[1]
 
     return g

@@ -89,3 +89,21 @@ def permutation(k, x, axis=0, independent=False):
         return asarray(_p.permutation(_key(k), int(x)).astype(np.int32))
     idx = _p.permutation(_key(k), int(x.shape[0]))
     return x[idx.astype(np.int64)]
+
+
+def choice(k, a, shape=(), replace=True, p=None, axis=0):
+    """jax/_src/random.py::choice for the scalar / with-replacement uses of the reference's tests: without ``p`` an index
+    from ``randint(key, shape, 0, n)``; with ``p`` the inverse-CDF draw ``searchsorted(cumsum(p), p_total * (1 - uniform))``."""
+    arr = asarray(np.arange(int(a))) if isinstance(a, (int, np.integer)) else asarray(a)
+    n = int(arr.shape[0])
+    shp = _shape(shape)
+    if not replace:
+        raise NotImplementedError("refshim choice: replace=False")
+    if p is None:
+        if shp != ():
+            raise NotImplementedError("refshim choice: scalar draws only without p")
+        return arr[int(_p.randint(_key(k), 0, n))]
+    pc = np.cumsum(np.asarray(p.detach().numpy() if hasattr(p, "detach") else p, dtype=np.float32), dtype=np.float32)
+    r = pc[-1] * (np.float32(1.0) - _p.uniform(_key(k), shp))
+    ind = np.searchsorted(pc, r, side="left")
+    return arr[asarray(np.asarray(ind, dtype=np.int64))] if shp != () else arr[int(ind)]

@@ -57,6 +57,22 @@ _norm.logpdf = lambda x, loc=0.0, scale=1.0: _wrap(
     -0.5 * ((_t(x) - _t(loc)) / _t(scale)) ** 2 - torch.log(_t(scale)) - 0.9189385332046727)
 _norm.__getattr__ = lambda item: _Missing(f"jax.scipy.stats.norm.{item}")
 stats.norm = _norm
+_mvn = types.ModuleType("jax.scipy.stats.multivariate_normal")
+
+
+def _mvn_logpdf(x, mean, cov):
+    xt, mt, ct = _t(x), _t(mean), _t(cov)
+    d = xt - mt
+    L = torch.linalg.cholesky(ct)
+    z = torch.linalg.solve_triangular(L, d.unsqueeze(-1), upper=False).squeeze(-1)
+    k = d.shape[-1]
+    return _wrap(-0.5 * (k * 1.8378770664093453 + 2.0 * torch.log(torch.diagonal(L)).sum() + (z * z).sum(-1)))
+
+
+_mvn.logpdf = _mvn_logpdf
+_mvn.__getattr__ = lambda item: _Missing(f"jax.scipy.stats.multivariate_normal.{item}")
+stats.multivariate_normal = _mvn
+sys.modules["jax.scipy.stats.multivariate_normal"] = _mvn
 
 sys.modules["jax.scipy.linalg"], sys.modules["jax.scipy.special"] = linalg, special
 sys.modules["jax.scipy.stats"], sys.modules["jax.scipy.stats.norm"] = stats, _norm
