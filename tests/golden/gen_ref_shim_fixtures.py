@@ -388,6 +388,28 @@ def diagnostics_case():
     return out
 
 
+def c1_moments_case():
+    """BASELINE.json configs[0] as SURVEY.md 8(d) spells it out: blackjax.hmc on the 1 024-dim isotropic Gaussian, 128 chains,
+    L = 10, eps = 0.1, T = 100 transitions (scan over split(key(0), T) of vmap over split(keys[t], N)), q0 = normal(key(1)).
+    Records every accept bit and the posterior moments over all 12 800 draws (north_star: "posterior moments within 1e-5 of
+    reference")."""
+    N, D, L, T, eps = 128, 1024, 10, 100, 0.1
+    fn = make_target(dict(kind="diag_gaussian", lo=0.0, hi=0.0, D=D))
+    alg = blackjax.hmc(fn, eps, jnp.ones(D), L)
+    states = jax.vmap(alg.init)(jax.random.normal(jax.random.key(1), (N, D)))
+
+    def one_step(st, k):
+        st, info = jax.vmap(alg.step)(jax.random.split(k, N), st)
+        return st, (st.position, info.is_accepted, info.acceptance_rate)
+
+    final, (pos, acc, rate) = jax.lax.scan(one_step, states, jax.random.split(jax.random.key(0), T))
+    P = np.asarray(pos).astype(np.float64)
+    return dict(N=N, D=D, L=L, T=T, eps=eps, q0_key_seed=1, run_key_seed=0, is_accepted=ints(acc),
+                mean=np.asarray(P.mean((0, 1))).tolist(), var=np.asarray(P.var((0, 1))).tolist(),
+                mean_acceptance_rate=float(np.asarray(rate).astype(np.float64).mean()), rows=[0, N - 1],
+                final_position_rows=f32hex(np.asarray(final.position)[[0, N - 1]]))
+
+
 def host_helpers_case():
     """dynamic_hmc.py:205-223 / adjusted_mclmc.py:281-288: the Halton helpers the engine mirrors on the host."""
     from blackjax.mcmc.adjusted_mclmc import rescale
@@ -469,6 +491,8 @@ def main():
         out["diagnostics"] = diagnostics_case()
     if selected("host_helpers"):
         out["host_helpers"] = host_helpers_case()
+    if selected("c1_moments"):
+        out["c1_moments"] = c1_moments_case()  # ~2 minutes of Python loops
     path = os.environ.get("BJX_REF_SHIM_OUT") or os.path.join(HERE, "ref_jax_fixtures.json" if REAL_JAX else "ref_shim_fixtures.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

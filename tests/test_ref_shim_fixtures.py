@@ -387,6 +387,24 @@ def test_chees_updates_equal_the_reference_code_step_by_step(fx):
             c["random_generator_arg"][t], c["step"][t])
 
 
+def test_c1_posterior_moments_equal_the_reference_code(fx):
+    """BASELINE.json configs[0] over its 100 transitions: every one of the 12 800 accept bits equal, the
+    posterior moments over all draws within 1e-6 (north_star asks for 1e-5; measured 5e-9 / 2e-8), the final positions
+    within 2e-5 -- an isotropic Gaussian at eps L = 1 does not amplify rounding differences."""
+    c = fx["c1_moments"]
+    N, D, L, T = c["N"], c["D"], c["L"], c["T"]
+    fn = otargets.diag_gaussian(np.ones(D, f32))
+    q0 = prng.normal(prng.key(c["q0_key_seed"]), (N, D))
+    st, pos, infos = ohmc.run(prng.key(c["run_key_seed"]), ohmc.init(q0, fn), fn, f32(c["eps"]), np.ones(D, f32), L, T)
+    assert np.stack([i.is_accepted for i in infos]).astype(int).tolist() == c["is_accepted"]
+    P = pos.astype(np.float64)
+    assert np.abs(P.mean((0, 1)) - np.asarray(c["mean"])).max() < 1e-6
+    assert np.abs(P.var((0, 1)) - np.asarray(c["var"])).max() < 1e-6
+    np.testing.assert_allclose(st.position[c["rows"]], unhex(c["final_position_rows"]), rtol=0, atol=2e-5)
+    rate = np.stack([i.acceptance_rate for i in infos]).astype(np.float64).mean()
+    assert abs(rate - c["mean_acceptance_rate"]) < 1e-5
+
+
 def test_host_helpers_equal_the_reference_code(fx):
     """The PRODUCT's host-side Halton helpers (blackjax_amd/dynamic_hmc.py) against dynamic_hmc.py:205-223 executed."""
     import importlib
