@@ -21,6 +21,12 @@ What it records (all under jax's default ``jax_threefry_partitionable``, float32
 
 tests/test_jax_fixtures.py loads the file when present and compares the oracle (CPU) and the HIP
 path (GPU) with it; until then the RNG bit stream stays "parity unpinned" (NOTEBOOK.md section 3).
+
+Run ALSO ``BJX_REAL_JAX=1 python tests/golden/gen_ref_shim_fixtures.py`` on that machine: the richer case set (20 sampler
+cases, four warm-ups with every step's state, ChEES, MEADS, diagnostics, C1 over 100 transitions) that round 5 generated
+from the reference's source on a stand-in for JAX; tests/test_ref_shim_fixtures.py picks the real-JAX file up as a second
+fixture set.  (Its warm-up comparison is step by step from the reference's state: a whole adaptive run, as recorded by
+``window_adaptation()`` below, amplifies one-ulp differences tenfold every few steps and will not hold 1e-3 over 40 steps.)
 """
 import json
 import os
