@@ -180,16 +180,16 @@ class Array(torch.Tensor):
     def _jnp(self):
         return sys.modules["jax.numpy"]
 
-    def sum(self, axis=None, keepdims=False, dtype=None, dim=None, keepdim=None):
+    def sum(self, axis=None, keepdims=False, dtype=None, dim=None, keepdim=None, out=None):
         return self._jnp().sum(self, axis if dim is None else dim, keepdims if keepdim is None else keepdim)
 
-    def mean(self, axis=None, keepdims=False, dim=None, keepdim=None):
+    def mean(self, axis=None, keepdims=False, dim=None, keepdim=None, dtype=None, out=None):  # (np.mean(x) calls x.mean(dtype=, out=))
         return self._jnp().mean(self, axis if dim is None else dim, keepdims if keepdim is None else keepdim)
 
-    def var(self, axis=None, ddof=0, keepdims=False):
+    def var(self, axis=None, ddof=0, keepdims=False, dtype=None, out=None):
         return self._jnp().var(self, axis, ddof, keepdims)
 
-    def std(self, axis=None, ddof=0, keepdims=False):
+    def std(self, axis=None, ddof=0, keepdims=False, dtype=None, out=None):
         return self._jnp().std(self, axis, ddof, keepdims)
 
     def max(self, axis=None, keepdims=False):
