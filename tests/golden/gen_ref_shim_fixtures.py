@@ -184,6 +184,13 @@ SAMPLER_CASES = [
     # BASELINE.json configs[0] (the reference's CPU-runnable case), as in gen_jax_fixtures.py
     dict(name="hmc_c1", algorithm="hmc", N=128, D=1024, L=10, eps=0.1, metric="identity",
          target=dict(kind="diag_gaussian", lo=0.0, hi=0.0), q0_key_seed=1, step_key_seed=0),
+    # BASELINE.json configs[1] / [4] / [2] at their own D, L, eps (fewer chains: a chain is a Python loop here)
+    dict(name="hmc_c2_like", algorithm="hmc", N=16, D=1024, L=50, eps=0.25, metric="ladder",
+         target=dict(kind="diag_gaussian", lo=-1.0, hi=1.0), q0_key_seed=1, q0_scale="sigma", step_key_seed=60),
+    dict(name="hmc_c5_like", algorithm="hmc", N=16, D=512, L=20, eps=0.5, metric="ar1_dense", metric_rho=0.9,
+         target=dict(kind="ar1", rho=0.9), q0_key_seed=1, step_key_seed=61),
+    dict(name="nuts_c3_like", algorithm="nuts", N=48, D=256, eps=0.1, max_num_doublings=10, metric="identity",
+         target=dict(kind="funnel"), q0_key_seed=1, step_key_seed=62),
     dict(name="hmc_ladder_ideal_mass", algorithm="hmc", N=32, D=64, L=12, eps=0.25, metric="ladder",
          target=dict(kind="diag_gaussian", lo=-1.0, hi=1.0), q0_key_seed=5, q0_scale="sigma", step_key_seed=6),
     dict(name="hmc_rejections", algorithm="hmc", N=64, D=16, L=7, eps=0.9, metric="identity",
