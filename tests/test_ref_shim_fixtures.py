@@ -495,3 +495,46 @@ def test_hip_transition_equals_the_reference_code(fx, dev, name):
     else:
         d["proposal_position"] = n(info.proposal.position)
     _check_sampler(c, n(st.position), d, c["algorithm"] == "nuts")
+
+
+@pytest.mark.gpu
+@_NOT_YET_ON_HARDWARE
+@pytest.mark.parametrize("name", sorted(FX["warmup"]))
+def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name):
+    """The warm-up's device kernels (``bjx_da_init / bjx_da_update``, ``bjx_welford_update_*``, ``bjx_welford_final_*`` through
+    the product's own wrappers) from the reference's state at t to its state at t + 1 -- the teacher-forced comparison of
+    ``test_adaptation_updates_equal_the_reference_code_step_by_step`` with the HIP path in the oracle's place."""
+    import torch
+
+    from blackjax_amd import adaptation as ad
+
+    c = FX["warmup"][name]
+    N, D, T, diag = c["N"], c["D"], c["T"], c["diag"]
+    pos, acc = unhex(c["position"]), unhex(c["acceptance_rate"])
+    L, step, wn = _warmup_arrays(c)
+    dv = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    target, shrink = c.get("target_acceptance_rate", 0.8), c.get("shrinkage", 0.0)
+    ss, _ = ad._da_init(torch.ones(N, device=dev), from_log_avg=False)
+    imm = torch.ones(D, device=dev) if diag else torch.eye(D, device=dev)
+    m2_0 = torch.zeros((N, D), device=dev) if diag else torch.zeros((N, D, D), device=dev)
+    mm = ad.MassMatrixAdaptationState(imm, ad.WelfordAlgorithmState(torch.zeros((N, D), device=dev), m2_0, 0))
+    for t, (stage, end) in enumerate(ad.build_schedule(T)):
+        if stage == 1:
+            mm = ad.MassMatrixAdaptationState(mm.inverse_mass_matrix, ad._welford_update(mm.wc_state, dv(pos[:, t])))
+        ss, step_size = ad._da_update(ss, dv(acc[:, t]), target)
+        if end:
+            mm = ad._mm_final(mm, shrink)
+            ss, step_size = ad._da_init(ss.log_step_size_avg, from_log_avg=True)
+        got = {"log_step_size": ss.log_step_size, "log_step_size_avg": ss.log_step_size_avg, "avg_error": ss.avg_error,
+               "mu": ss.mu, "step_size": step_size, "welford_mean": mm.wc_state.mean, "welford_m2": mm.wc_state.m2}
+        for k, v in got.items():
+            np.testing.assert_allclose(v.cpu().numpy(), L[k][:, t], rtol=5e-6, atol=1e-7, err_msg=f"{k} at step {t}")
+        imm_now = mm.inverse_mass_matrix
+        imm_now = imm_now.expand((N,) + tuple(imm_now.shape)) if imm_now.ndim == (1 if diag else 2) else imm_now
+        np.testing.assert_allclose(imm_now.cpu().numpy(), L["inverse_mass_matrix"][:, t], rtol=5e-6, atol=1e-7, err_msg=f"imm at {t}")
+        assert ss.step == int(step[0, t]) and mm.wc_state.sample_size == int(wn[0, t]), t
+        # continue from the REFERENCE's state
+        ss = ad.DualAveragingAdaptationState(dv(L["log_step_size"][:, t]), dv(L["log_step_size_avg"][:, t]), int(step[0, t]),
+                                             dv(L["avg_error"][:, t]), dv(L["mu"][:, t]))
+        mm = ad.MassMatrixAdaptationState(dv(L["inverse_mass_matrix"][:, t]),
+                                          ad.WelfordAlgorithmState(dv(L["welford_mean"][:, t]), dv(L["welford_m2"][:, t]), int(wn[0, t])))
