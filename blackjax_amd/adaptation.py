@@ -500,7 +500,13 @@ def staged_adaptation(algorithm, logdensity_fn: Callable, metric: str = "welford
             "(the multi-chain pooled gate is implemented in the meta-adaptation "
             "controller). For other metric strings pass n_chains=1 (default) and "
             "vmap the warmup call externally.")
-    if not isinstance(metric, str) or metric not in _RECIPES:
+    if not isinstance(metric, str):  # staged_adaptation.py:509-515 (this engine has no MetricRecipe / MetricCore objects)
+        raise TypeError(
+            f"staged_adaptation: metric must be a str, MetricRecipe, or MetricCore "
+            f"(got {type(metric).__name__}). "
+            f"Pass a registry name (e.g. 'welford_diag') or construct a "
+            f"MetricRecipe or MetricCore directly.")
+    if metric not in _RECIPES:
         raise NotImplementedError(
             f"staged_adaptation(metric={metric!r}): this engine builds the Welford recipes "
             f"{sorted(_RECIPES)}; 'auto' (experimental meta-adaptation), 'fisher_diag' and MetricCore / "

@@ -67,6 +67,7 @@ def test_staged_adaptation_argument_checks():
     kw = dict(num_integration_steps=3)
     _expect("adaptation/staged_adaptation.py", 666, lambda: bjx.staged_adaptation(bjx.hmc, _fn, n_chains=0, **kw))
     _expect("adaptation/staged_adaptation.py", 668, lambda: bjx.staged_adaptation(bjx.hmc, _fn, n_chains=2, **kw))
+    _expect("adaptation/staged_adaptation.py", 510, lambda: bjx.staged_adaptation(bjx.hmc, _fn, metric=3, **kw))
     with pytest.raises(NotImplementedError, match="auto"):
         bjx.staged_adaptation(bjx.hmc, _fn, metric="auto", max_grad_budget=50_000, **kw)
     with pytest.raises(NotImplementedError):
