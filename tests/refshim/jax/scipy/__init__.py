@@ -57,6 +57,13 @@ _norm.logpdf = lambda x, loc=0.0, scale=1.0: _wrap(
     -0.5 * ((_t(x) - _t(loc)) / _t(scale)) ** 2 - torch.log(_t(scale)) - 0.9189385332046727)
 _norm.__getattr__ = lambda item: _Missing(f"jax.scipy.stats.norm.{item}")
 stats.norm = _norm
+_expon = types.ModuleType("jax.scipy.stats.expon")
+_expon.logpdf = lambda x, loc=0.0, scale=1.0: _wrap(torch.where(
+    (_t(x) - _t(loc)) / _t(scale) >= 0, -((_t(x) - _t(loc)) / _t(scale)) - torch.log(_t(scale).to(torch.float32)),
+    torch.tensor(-float("inf"))))
+_expon.__getattr__ = lambda item: _Missing(f"jax.scipy.stats.expon.{item}")
+stats.expon = _expon
+sys.modules["jax.scipy.stats.expon"] = _expon
 _mvn = types.ModuleType("jax.scipy.stats.multivariate_normal")
 
 
