@@ -292,11 +292,16 @@ class _AtIdx:
 
     def add(self, v):
         y = self.x.clone()
-        y[self.idx] += v
+        y[_idx(self.idx)] += v
+        return y
+
+    def multiply(self, v):
+        y = self.x.clone()
+        y[_idx(self.idx)] *= v
         return y
 
     def get(self):
-        return self.x[self.idx]
+        return self.x[self.idx]  # (Array.__getitem__: clamped like a JAX gather)
 
 
 _DT = {np.float32: torch.float32, np.float64: torch.float64, np.int32: torch.int32, np.int64: torch.int64,

@@ -48,3 +48,15 @@ def adam(learning_rate, b1=0.9, b2=0.999, eps=1e-8, eps_root=0.0):
 
 def apply_updates(params, updates):
     return jax.tree.map(lambda p, u: p + u, params, updates)
+
+
+def sgd(learning_rate):
+    """``optax.sgd`` without momentum: updates = -learning_rate * grads."""
+
+    def init(params):
+        return ()
+
+    def update(grads, state, params=None):
+        return jax.tree.map(lambda g: -learning_rate * g, grads), state
+
+    return GradientTransformation(init, update)
