@@ -395,11 +395,34 @@ def tree_unflatten(treedef, leaves):
     return rec(treedef)
 
 
+def _flatten_up_to(treedef, tree):
+    """The parts of ``tree`` that sit where ``treedef`` has its leaves (``tree`` has ``treedef`` as a PREFIX: a leaf of the
+    first tree may face a whole subtree of the others -- adaptation/base.py:51 maps field NAMES over a tuple of pytrees)."""
+    out = []
+
+    def rec(d, t):
+        kind = d[0]
+        if kind == "leaf":
+            out.append(t)
+        elif kind == "none":
+            assert t is None, "tree_map: trees do not match"
+        elif kind in ("nt", "tuple", "list"):
+            children = d[2] if kind == "nt" else d[1]
+            assert isinstance(t, (tuple, list)) and len(t) == len(children), "tree_map: trees do not match"
+            for c, v in zip(children, t):
+                rec(c, v)
+        else:
+            assert isinstance(t, dict) and sorted(t) == d[1], "tree_map: trees do not match"
+            for k, c in zip(d[1], d[2]):
+                rec(c, t[k])
+
+    rec(treedef, tree)
+    return out
+
+
 def tree_map(f, tree, *rest, is_leaf=None):
     leaves, treedef = tree_flatten(tree)
-    others = [tree_flatten(r)[0] for r in rest]
-    for o in others:
-        assert len(o) == len(leaves), "tree_map: trees do not match"
+    others = [_flatten_up_to(treedef, r) for r in rest]
     return tree_unflatten(treedef, [f(*xs) for xs in zip(leaves, *others)])
 
 
