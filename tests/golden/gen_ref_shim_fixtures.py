@@ -274,9 +274,13 @@ def warmup_case(spec):
     N, D, T = spec["N"], spec["D"], spec["T"]
     fn = make_target(dict(spec["target"], D=D))
     kw = dict(num_integration_steps=spec["L"]) if spec["algorithm"] == "hmc" else dict(max_num_doublings=spec["max_num_doublings"])
+    if spec.get("initial_imm") == "ladder":  # a diagonal start that is not the identity (sigma^2 of a 10^(+-0.3) ladder)
+        s0 = sigma_ladder(D, -0.3, 0.3)
+        kw["initial_inverse_mass_matrix"] = jnp.asarray((s0 * s0).astype(np.float32))
     warm = blackjax.window_adaptation(getattr(blackjax, spec["algorithm"]), fn,
                                       is_mass_matrix_diagonal=spec["diag"],
                                       imm_shrinkage_to_previous=spec.get("shrinkage", 0.0),
+                                      initial_step_size=spec.get("initial_step_size", 1.0),
                                       target_acceptance_rate=spec.get("target_acceptance_rate", 0.8), **kw)
     q0 = initial_positions(spec, N, D)
     run_key = jax.random.key(spec["run_key_seed"])
@@ -306,6 +310,8 @@ WARMUP_CASES = [
     dict(name="warmup_hmc_diag_shrinkage", algorithm="hmc", N=2, D=6, L=4, T=100, diag=True, shrinkage=2.0,
          target_acceptance_rate=0.65, run_key_seed=52, q0_key_seed=53, q0_scale="sigma",
          target=dict(kind="diag_gaussian", lo=-0.4, hi=0.4)),
+    dict(name="warmup_hmc_diag_given_start", algorithm="hmc", N=2, D=6, L=4, T=60, diag=True, initial_step_size=0.3,
+         initial_imm="ladder", run_key_seed=56, q0_key_seed=57, q0_scale="sigma", target=dict(kind="diag_gaussian", lo=-0.4, hi=0.4)),
     dict(name="warmup_nuts_diag_100", algorithm="nuts", N=2, D=6, max_num_doublings=5, T=100, diag=True, run_key_seed=54,
          q0_key_seed=55, q0_scale="sigma", target=dict(kind="diag_gaussian", lo=-0.4, hi=0.4)),
 ]

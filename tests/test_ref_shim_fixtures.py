@@ -206,6 +206,13 @@ def test_run_inference_key_layout_equals_the_reference_code(fx):
     np.testing.assert_allclose(np.stack(P), unhex(r["single_chain_positions"]), rtol=1e-5, atol=5e-6)
 
 
+def _initial_imm(c, D):
+    if c.get("initial_imm") == "ladder":
+        s0 = ladder(D, -0.3, 0.3)
+        return (s0 * s0).astype(f32)
+    return None
+
+
 def _warmup_arrays(c):
     names = ("log_step_size", "log_step_size_avg", "avg_error", "mu", "step_size", "inverse_mass_matrix", "welford_mean", "welford_m2")
     return {k: unhex(c[k]) for k in names}, np.asarray(c["da_step"]), np.asarray(c["welford_n"])
@@ -219,7 +226,7 @@ def test_adaptation_updates_equal_the_reference_code_step_by_step(fx, name):
     N, D, T, diag = c["N"], c["D"], c["T"], c["diag"]
     pos, acc = unhex(c["position"]), unhex(c["acceptance_rate"])
     L, step, wn = _warmup_arrays(c)
-    ws = oad.adapt_init(N, D, 1.0, is_diag=diag)
+    ws = oad.adapt_init(N, D, c.get("initial_step_size", 1.0), is_diag=diag, initial_imm=_initial_imm(c, D))
     n_ends = 0
     for t, (stage, end) in enumerate(oad.build_schedule(T)):
         n_ends += int(bool(end))
@@ -262,8 +269,9 @@ def test_warmup_transitions_equal_the_reference_code_step_by_step(fx, name):
         keys = prng.split(chain_keys[ci], T)
         for t in range(0, T, 1 if T <= 100 else 2):
             q_t = q[ci:ci + 1] if t == 0 else pos[ci:ci + 1, t - 1]
-            e_t = f32(1.0) if t == 0 else eps[ci, t - 1]
-            m_t = (np.ones(D, f32) if diag else np.eye(D, dtype=f32)) if t == 0 else imm[ci, t - 1]
+            e_t = f32(c.get("initial_step_size", 1.0)) if t == 0 else eps[ci, t - 1]
+            m0 = _initial_imm(c, D)
+            m_t = (m0 if m0 is not None else (np.ones(D, f32) if diag else np.eye(D, dtype=f32))) if t == 0 else imm[ci, t - 1]
             st = ohmc.init(q_t, fn)
             with np.errstate(over="ignore", invalid="ignore"):
                 if c["algorithm"] == "hmc":
@@ -514,8 +522,9 @@ def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name)
     L, step, wn = _warmup_arrays(c)
     dv = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
     target, shrink = c.get("target_acceptance_rate", 0.8), c.get("shrinkage", 0.0)
-    ss, _ = ad._da_init(torch.ones(N, device=dev), from_log_avg=False)
-    imm = torch.ones(D, device=dev) if diag else torch.eye(D, device=dev)
+    ss, _ = ad._da_init(torch.full((N,), float(c.get("initial_step_size", 1.0)), device=dev), from_log_avg=False)
+    m0 = _initial_imm(c, D)
+    imm = dv(m0) if m0 is not None else (torch.ones(D, device=dev) if diag else torch.eye(D, device=dev))
     m2_0 = torch.zeros((N, D), device=dev) if diag else torch.zeros((N, D, D), device=dev)
     mm = ad.MassMatrixAdaptationState(imm, ad.WelfordAlgorithmState(torch.zeros((N, D), device=dev), m2_0, 0))
     for t, (stage, end) in enumerate(ad.build_schedule(T)):
