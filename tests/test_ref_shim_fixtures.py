@@ -547,3 +547,57 @@ def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name)
                                              dv(L["avg_error"][:, t]), dv(L["mu"][:, t]))
         mm = ad.MassMatrixAdaptationState(dv(L["inverse_mass_matrix"][:, t]),
                                           ad.WelfordAlgorithmState(dv(L["welford_mean"][:, t]), dv(L["welford_m2"][:, t]), int(wn[0, t])))
+
+
+@pytest.mark.gpu
+@_NOT_YET_ON_HARDWARE
+def test_hip_pooled_warmups_and_ghmc_equal_the_reference_code(dev):
+    """``ghmc`` (three transitions), ``chees_adaptation`` (40 steps) and ``meads_adaptation`` (12 steps) on the HIP path
+    against the reference's records -- the call conventions of tests/test_ghmc_gpu.py / test_chees_gpu.py."""
+    import torch
+
+    import blackjax_amd as bjx
+
+    t2n = lambda x: x.detach().cpu().numpy()  # noqa: E731
+    dv = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    # ---- ghmc
+    g = FX["ghmc"]
+    N, D = g["N"], g["D"]
+    sig = ladder(D, g["lo"], g["hi"])
+    inv_var = (f32(1) / (sig * sig)).astype(f32)
+    q0 = (sig * prng.normal(prng.key(g["q0_key_seed"]), (N, D))).astype(f32)
+    alg = bjx.ghmc(bjx.targets.DiagGaussian(dv(inv_var)), g["eps"], dv(sig), g["alpha"], g["delta"])
+    st = alg.init(dv(q0), np.asarray(g["init_key"], np.uint32))
+    np.testing.assert_allclose(t2n(st.momentum), unhex(g["init_momentum"]), rtol=5e-7, atol=1e-7)
+    for k, rec in zip(np.asarray(g["step_keys"], np.uint32), g["steps"]):
+        st, info = alg.step(k, st)
+        assert t2n(info.is_accepted).astype(int).tolist() == rec["is_accepted"]
+        np.testing.assert_allclose(t2n(st.position), unhex(rec["position"]), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(t2n(st.slice), unhex(rec["slice"]), rtol=2e-4, atol=2e-6)
+    # ---- ChEES
+    c = FX["chees"]
+    N, D, T = c["N"], c["D"], c["T"]
+    sig = ladder(D, c["lo"], c["hi"])
+    fn = bjx.targets.DiagGaussian(dv((f32(1) / (sig * sig)).astype(f32)))
+    warm = bjx.chees_adaptation(fn, N)
+    a = c["adam"]
+    (last, params), info = warm.run(prng.key(c["run_key_seed"]), dv(prng.normal(prng.key(c["q0_key_seed"]), (N, D))),
+                                    c["initial_step_size"], bjx.optim.adam(a["learning_rate"], b1=a["b1"], b2=a["b2"]), T)
+    assert t2n(info.info.num_integration_steps).reshape(T, -1)[:, 0].tolist() == [n[0] for n in c["num_integration_steps"]]
+    np.testing.assert_allclose(t2n(info.adaptation_state.step_size), unhex(c["step_size"]), rtol=2e-5)
+    np.testing.assert_allclose(t2n(info.adaptation_state.trajectory_length), unhex(c["trajectory_length"]), rtol=2e-5)
+    np.testing.assert_allclose(t2n(info.state.position), unhex(c["position"]), rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(float(params["step_size"]), unhex(c["final_step_size"]), rtol=2e-6)
+    # ---- MEADS
+    m = FX["meads"]
+    N, D = m["N"], m["D"]
+    sig = ladder(D, m["lo"], m["hi"])
+    q0 = (f32(m["q0_scale"]) * (sig * prng.normal(prng.key(m["q0_key_seed"]), (N, D))).astype(f32)).astype(f32)
+    warm = bjx.meads_adaptation(bjx.targets.DiagGaussian(dv((f32(1) / (sig * sig)).astype(f32))), N, num_folds=m["num_folds"])
+    (st_g, par_g), info = warm.run(np.asarray(m["run_key"], np.uint32), dv(q0), m["num_steps"])
+    assert t2n(info.info.is_accepted).astype(int).tolist() == m["is_accepted_per_step"]
+    np.testing.assert_allclose(t2n(info.adaptation_state.step_size), unhex(m["step_size_per_step"]), rtol=2e-5)
+    np.testing.assert_allclose(t2n(info.adaptation_state.alpha), unhex(m["alpha_per_step"]), rtol=2e-5)
+    np.testing.assert_allclose(t2n(st_g.position), unhex(m["final_position"]), rtol=1e-4, atol=5e-5)
+    for name, v in m["parameters"].items():
+        np.testing.assert_allclose(t2n(par_g[name]) if hasattr(par_g[name], "cpu") else par_g[name], unhex(v), rtol=2e-5)
