@@ -5,8 +5,8 @@ is faithful enough for the reference's tests of its HMC / NUTS / adaptation code
     python tests/refshim/run_reference_tests.py [--all-in-scope]      # from the repo root, where /root/reference exists
 
 Default: the quick selection tests/test_reference_tests_on_shim.py runs (about a minute).  ``--all-in-scope`` adds the slow
-statistical tests of tests/adaptation/test_adaptation.py (ChEES / MEADS / window adaptation end to end: minutes of Python
-loops).  Nothing is written into /root/reference (no bytecode, no pytest cache); chex / absl are tests/refshim's small
+statistical tests (tests/adaptation/test_adaptation.py: ChEES / MEADS end to end; test_sampling.py's univariate-normal tests
+for hmc / nuts / ghmc and its window-adaptation regression test, 18 parameter sets: about two hours of Python loops).  Nothing is written into /root/reference (no bytecode, no pytest cache); chex / absl are tests/refshim's small
 restatements.  Out of scope and therefore not selected: lbfgs, pareto-k, divergence concentration, isokinetic / implicit
 integrators, low-rank metrics, float64 variants (the stand-in is float32 like JAX's default), thinning, random-walk samplers."""
 import os
@@ -33,13 +33,17 @@ QUICK = [
     "tests/test_diagnostics.py::EssTailTest",
     "tests/adaptation/test_adaptation.py::test_adaptation_schedule",
 ]
-SLOW = [
+SLOW = [  # measured once (NOTEBOOK.md section 16.10): 18 min, 5 min, 103 min
     "tests/adaptation/test_adaptation.py",
+    "tests/mcmc/test_sampling.py::UnivariateNormalTest::test_hmc",
+    "tests/mcmc/test_sampling.py::UnivariateNormalTest::test_nuts",
+    "tests/mcmc/test_sampling.py::UnivariateNormalTest::test_ghmc",
+    "tests/mcmc/test_sampling.py::LinearRegressionTest::test_window_adaptation",
 ]
 DESELECT = ["f64", "float64"]
 
 
-def run(selection, timeout=3600, extra=()):
+def run(selection, timeout=10800, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
         ini = os.path.join(tmp, "pytest.ini")
         with open(ini, "w") as fh:
