@@ -395,6 +395,58 @@ def test_chees_updates_equal_the_reference_code_step_by_step(fx):
             c["random_generator_arg"][t], c["step"][t])
 
 
+def test_product_chees_host_update_equals_the_reference_code_step_by_step(fx):
+    """The PRODUCT's host half of the ChEES update (``blackjax_amd.chees.base(...)[1].scalar_update``: harmonic-mean
+    acceptance, dual averaging, the product's own Adam, clipping, moving averages, trajectory-length clamp) from the
+    reference's state at t to its state at t + 1, on the CPU.  The four pooled sums the device kernels hand it
+    (``bjx_chees_scalars``) are formed here from the reference's recorded proposals with the oracle's criterion."""
+    import importlib
+
+    pchees = importlib.import_module("blackjax_amd.chees")
+    poptim = importlib.import_module("blackjax_amd.optim")
+    from oracle import chees as ochees
+
+    c = fx["chees"]
+    N, D, T = c["N"], c["D"], c["T"]
+    q0 = prng.normal(prng.key(c["q0_key_seed"]), (N, D))
+    max_bits = int(np.ceil(np.log2(T + 1000)))
+    jitter = lambda i: f32(f32(ochees.halton_sequence(i, max_bits) * f32(1.0)) + f32(0.0))  # noqa: E731
+    a = c["adam"]
+    init, update = pchees.base(jitter, lambda i: i + 1, poptim.adam(a["learning_rate"], b1=a["b1"], b2=a["b2"]),
+                               ochees.OPTIMAL_TARGET_ACCEPTANCE_RATE, 0.5, 1000)
+    st = init(0, c["initial_step_size"])
+    pos, pp, pm = unhex(c["position"]), unhex(c["proposal_position"]), unhex(c["proposal_momentum"])
+    acc, div = unhex(c["acceptance_rate"]), np.asarray(c["is_divergent"], bool)
+    names = ("step_size", "log_step_size_ma", "trajectory_length", "log_trajectory_length_ma", "da_log_x", "da_log_x_avg",
+             "da_avg_error", "da_mu", "adam_mu", "adam_nu")
+    F = {k: unhex(c[k]) for k in names}
+    for t in range(T):
+        prev = q0 if t == 0 else pos[t - 1]
+        nd = ~div[t]
+        w = np.where(nd, acc[t], f32(0.0)).astype(f32)
+        per_chain = ochees.chain_criterion(pp[t], pm[t], prev, w, np.ones(D, f32), True)
+        scale = f32(f32(jitter(st.random_generator_arg)) * st.trajectory_length)
+        tg = (scale * per_chain).astype(f32)
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):  # an acceptance probability of 0 gives inf here, as there
+            sums = [(f32(1.0) / acc[t][nd]).astype(np.float64).sum(), float(nd.sum()),
+                    (acc[t][nd].astype(np.float64) * tg[nd].astype(np.float64)).sum(),
+                    (acc[t][nd] + f32(ochees.EPS_FLOAT)).astype(f32).astype(np.float64).sum()]
+        new = update.scalar_update(st, sums)
+        got = {"step_size": new.step_size, "log_step_size_ma": new.log_step_size_moving_average,
+               "trajectory_length": new.trajectory_length, "log_trajectory_length_ma": new.log_trajectory_length_moving_average,
+               "da_log_x": new.da_state.log_x, "da_log_x_avg": new.da_state.log_x_avg, "da_avg_error": new.da_state.avg_error,
+               "da_mu": new.da_state.mu, "adam_mu": new.optim_state.mu, "adam_nu": new.optim_state.nu}
+        for k, v in got.items():
+            np.testing.assert_allclose(v, F[k][t], rtol=2e-5, atol=2e-7, err_msg=f"{k} at step {t}")
+        assert (new.random_generator_arg, new.step, new.da_state.step, new.optim_state.count) == (
+            c["random_generator_arg"][t], c["step"][t], c["da_step"][t], c["adam_count"][t]), t
+        st = pchees.ChEESAdaptationState(  # continue from the REFERENCE's state
+            F["step_size"][t], F["log_step_size_ma"][t], F["trajectory_length"][t], F["log_trajectory_length_ma"][t],
+            pchees.DualAveragingState(F["da_log_x"][t], F["da_log_x_avg"][t], int(c["da_step"][t]), F["da_avg_error"][t], F["da_mu"][t]),
+            poptim.ScaleByAdamState(int(c["adam_count"][t]), F["adam_mu"][t], F["adam_nu"][t]),
+            c["random_generator_arg"][t], c["step"][t])
+
+
 def test_c1_posterior_moments_equal_the_reference_code(fx):
     """BASELINE.json configs[0] over its 100 transitions: every one of the 12 800 accept bits equal, the
     posterior moments over all draws within 1e-6 (north_star asks for 1e-5; measured 5e-9 / 2e-8), the final positions
