@@ -395,6 +395,43 @@ def test_chees_updates_equal_the_reference_code_step_by_step(fx):
             c["random_generator_arg"][t], c["step"][t])
 
 
+@pytest.mark.parametrize("name", sorted(FX["warmup"]))
+def test_product_free_running_table_follows_the_reference_counters(fx, name):
+    """``blackjax_amd.adaptation.free_running_table`` (the per-step scalars a free-running NUTS warm-up reads on the device:
+    ``step + t0``, ``step^-kappa``, ``sqrt(step) / gamma``, the Welford count, the window-end blend coefficients) against the
+    counters the REFERENCE's run went through: its dual-averaging step counter -- re-initialised at every window end -- and
+    its Welford sample size."""
+    from blackjax_amd import _lib
+    from blackjax_amd.adaptation import free_running_table
+
+    c = fx["warmup"][name]
+    T = c["T"]
+    shrink = c.get("shrinkage", 0.0)
+    tab = free_running_table(T, shrink)
+    AT = _lib.NUTS_AT
+    da_after, wn_after = np.asarray(c["da_step"])[0], np.asarray(c["welford_n"])[0]  # chain 0: counters are shared
+    sched = oad.build_schedule(T)
+    wel = 0
+    for t, (stage, end) in enumerate(sched):
+        step_used = 1 if t == 0 else int(da_after[t - 1])  # the counter the update at t reads
+        assert tab[t, AT["DA_REG"]] == f32(step_used) + f32(10.0), t
+        assert tab[t, AT["DA_ETA"]] == f32(float(step_used) ** -0.75), t
+        assert tab[t, AT["DA_COEF"]] == np.sqrt(f32(step_used)) / f32(0.05), t
+        assert int(tab[t, AT["FLAGS"]]) == (1 if stage == 1 else 0) | (2 if end else 0), t
+        if stage == 1:
+            wel += 1
+            assert tab[t, AT["WEL_N"]] == wel, t
+        if end:
+            assert int(da_after[t]) == 1 and int(wn_after[t]) == 0, t      # the reference re-initialised both
+            denom = f32(wel + 5) + f32(shrink)
+            assert tab[t, AT["FIN_NM1"]] == wel - 1 and tab[t, AT["FIN_BETA_DATA"]] == f32(wel) / denom, t
+            assert tab[t, AT["FIN_BETA_PREV"]] == f32(shrink) / denom, t
+            wel = 0
+        else:
+            assert int(da_after[t]) == step_used + 1, t
+            assert int(wn_after[t]) == wel, t
+
+
 def test_product_chees_host_update_equals_the_reference_code_step_by_step(fx):
     """The PRODUCT's host half of the ChEES update (``blackjax_amd.chees.base(...)[1].scalar_update``: harmonic-mean
     acceptance, dual averaging, the product's own Adam, clipping, moving averages, trajectory-length clamp) from the
