@@ -222,6 +222,8 @@ SAMPLER_CASES = [
          target=dict(kind="funnel"), q0_key_seed=24, q0_scale=0.5, step_key_seed=25),
     dict(name="nuts_depth_limit_2", algorithm="nuts", N=16, D=8, eps=0.05, max_num_doublings=2, metric="identity",
          target=dict(kind="diag_gaussian", lo=0.0, hi=0.0), q0_key_seed=26, step_key_seed=27),
+    dict(name="nuts_depth_limit_10", algorithm="nuts", N=4, D=4, eps=0.0005, max_num_doublings=10, metric="identity",
+         target=dict(kind="diag_gaussian", lo=0.0, hi=0.0), q0_key_seed=58, step_key_seed=59),  # 1 023 leaves per chain
     dict(name="nuts_divergent", algorithm="nuts", N=32, D=8, eps=0.52, max_num_doublings=6, metric="identity",
          divergence_threshold=20, target=dict(kind="diag_gaussian", lo=-0.6, hi=0.6), q0_key_seed=28, q0_scale="sigma",
          step_key_seed=29),

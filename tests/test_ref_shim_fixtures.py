@@ -172,6 +172,7 @@ def test_cases_cover_what_they_are_named_for():
     assert any(n not in (1, 3, 7, 15, 31, 63) for n in s["nuts_divergent"]["num_integration_steps"])  # stopped mid-subtree
     assert max(s["nuts_funnel_deep"]["num_trajectory_expansions"]) == s["nuts_funnel_deep"]["max_num_doublings"]
     assert set(s["nuts_depth_limit_2"]["num_integration_steps"]) == {3} and not any(s["nuts_depth_limit_2"]["is_turning"])
+    assert set(s["nuts_depth_limit_10"]["num_integration_steps"]) == {1023} and not any(s["nuts_depth_limit_10"]["is_turning"])
     assert len(set(s["dynamic_hmc"]["num_integration_steps"])) > 3
     assert len(set(s["nuts_funnel"]["num_integration_steps"])) > 1
 
