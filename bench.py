@@ -1447,6 +1447,9 @@ def main():
                                       "control-flow test): NOT a multi-GPU figure")
             if not args.no_rng_pin:
                 out["rng_pin"] = rng_pin_check(ctx.dev)
+            out["oracle_pin"] = ("the oracle the parity blocks check against is itself pinned on the reference's own source executed on a "
+                                 "stand-in for JAX (tests/refshim; tests/golden/ref_shim_fixtures.json, tests/test_ref_shim_fixtures.py): "
+                                 "every discrete outcome equal, positions to ~1e-6; the jax.random bit streams are NOT pinned by that (rng_pin)")
             if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
                 try:
                     out["cpu_baseline"] = cpu_baseline(args.dim or 1024, args.leapfrogs, args.eps)
