@@ -331,6 +331,114 @@ def _try_parity(fn, *a):
         return {"error": repr(e)[:400]}
 
 
+def _r(x, sig=6):
+    """Numbers of the compact line: 6 significant digits."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x == x and abs(x) < 2.0 ** 53 and x.is_integer():
+            return int(x)
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+_PARITY_KEYS = ("chains_checked", "accept_mismatches", "divergence_mismatches", "tree_size_mismatches",
+                "tree_depth_mismatches", "turning_flag_mismatches", "max_abs_dpos", "max_abs_dmean", "max_abs_dvar",
+                "max_abs_dacceptance_rate", "largest_tree_checked", "chain_blocks_covered", "chain_blocks_total",
+                "gemm_tiles_covered", "gemm_tiles_total", "error")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_timed",
+              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "chains_per_launch", "mode",
+              "cache_assisted_frac", "traffic_over_algorithmic", "frac_at_measured_bytes",
+              "busy_phase_tick_frac_measured", "full_ensemble_tick_us", "traffic_build")
+
+
+def compact_line(out, full_path):
+    """The ONE stdout line of the contract, <= 6 KB (the driver keeps an 8 KB tail of stdout: round 5's 25 KB line lost
+    C5's, C3's and the parity blocks' values): headline keys + config + roofline + cpu_baseline + parity + for each of
+    C3 / C4 / C5 {value, ms_per_step, roofline, parity counts} + the non-degenerate ESS/s.  The FULL object goes to
+    stderr and to `full_path`."""
+    c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "mean_acceptance", "end_to_end_frac_of_28B_roofline", "ranks",
+              "backend", "per_rank_ms_per_step")
+    if "roofline" in out:
+        c["roofline"] = _pick(out["roofline"], *_ROOF_KEYS)
+        ts = out["roofline"].get("traffic_source")
+        if ts:
+            c["roofline"]["traffic_source"] = ts[:160]
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = dict(out["cpu_baseline"])
+        if isinstance(c["cpu_baseline"].get("sample"), str):
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:180]
+        if isinstance(c["cpu_baseline"].get("jax_baseline"), str):
+            c["cpu_baseline"]["jax_baseline"] = c["cpu_baseline"]["jax_baseline"][:80]
+    if "parity" in out:
+        c["parity"] = _pick(out["parity"], *_PARITY_KEYS)
+    if isinstance(out.get("ess"), dict):
+        c["ess_per_sec_contract_params"] = out["ess"].get("min_ess_per_sec_all_chains")
+        c["ess_note"] = "contract eps*L = 12.5 ~ 4*pi: degenerate; quote ess_nonresonant"
+    if isinstance(out.get("ess_nonresonant"), dict):
+        c["ess_nonresonant"] = _pick(out["ess_nonresonant"], "min_ess_per_sec_all_chains", "min_ess_subset", "subset_chains",
+                                     "draws_per_chain", "eps", "leapfrogs", "ms_per_step", "mean_acceptance")
+    for name in ("torch_callable_mode", "torch_elementwise_mode", "torch_default_mode", "torch_compile_mode"):
+        if isinstance(out.get(name), dict):
+            c[name] = _pick(out[name], "value", "ms_per_step", "frac_of_28B_roofline", "path", "error")
+    for name in ("c5_dense", "c3_nuts", "c4_shard"):
+        sub = out.get(name)
+        if not isinstance(sub, dict):
+            continue
+        o = _pick(sub, "value", "unit", "steps", "ms_per_step", "mean_acceptance", "error", "end_to_end_frac_of_32B_roofline",
+                  "mean_leapfrogs_per_chain_transition", "utilisation")
+        if isinstance(sub.get("config"), dict) and "workload" in sub["config"]:
+            o["workload"] = sub["config"]["workload"][:140]
+        if isinstance(sub.get("roofline"), dict):
+            o["roofline"] = _pick(sub["roofline"], *_ROOF_KEYS)
+        if isinstance(sub.get("parity"), dict):
+            o["parity"] = _pick(sub["parity"], *_PARITY_KEYS)
+        for k in ("free_running_T400", "lockstep_step"):
+            if isinstance(sub.get(k), dict):
+                o[k] = _pick(sub[k], "value", "ms_per_transition", "frac_of_52B_roofline")
+        c[name] = o
+    for k in ("rng_pin", "oracle_pin"):
+        if isinstance(out.get(k), str):
+            c[k] = out[k][:120]
+    c["full_record"] = full_path
+    c = _r(c)
+    line = json.dumps(c, separators=(",", ":"))
+    # hard bound: drop the least important keys until the line fits
+    for k in ("oracle_pin", "rng_pin", "torch_compile_mode", "torch_callable_mode", "per_rank_ms_per_step", "ess_note"):
+        if len(line) <= 6000:
+            break
+        c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def write_full_record(out):
+    """The full object: stderr (one line, prefixed) + a file under gpurun_out/ (merged back by gpurun) -- copy the ones to
+    be judged into profiles/."""
+    text = json.dumps(out)
+    sys.stderr.write("bench.py FULL RECORD: " + text + "\n")
+    sys.stderr.flush()
+    path = os.environ.get("BJX_BENCH_FULL", os.path.join("gpurun_out", "bench_full_latest.json"))
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as fh:
+            fh.write(text + "\n")
+    except OSError as e:
+        print(f"bench.py: could not write {path}: {e!r}", file=sys.stderr)
+        path = "stderr"
+    return path
+
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -1389,6 +1497,9 @@ def main():
                     help="c2: run ONLY this user-callable mode as the timed region (for rocprofv3 passes)")
     ap.add_argument("--time-every", type=int, default=0,
                     help="bracket every k-th leapfrog launch with HIP events (0 = 16 for short launches, else 1)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL object (~25 KB) as the stdout line instead of the compact <= 6 KB line "
+                         "(the full object always goes to stderr and gpurun_out/bench_full_latest.json)")
     ap.add_argument("--selftest-control-flow", action="store_true",
                     help="CPU-only exercise of the multi-rank control flow (no GPU work, no measurement)")
     args = ap.parse_args()
@@ -1413,7 +1524,7 @@ def main():
         os.dup2(2, 1)
 
     def emit(obj):
-        line = json.dumps(obj) + "\n"
+        line = (obj if isinstance(obj, str) else json.dumps(obj)) + "\n"
         if json_fd is None:
             sys.stdout.write(line)
             sys.stdout.flush()
@@ -1455,7 +1566,10 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(args.dim or 1024, args.leapfrogs, args.eps)
                 except Exception as e:  # the baseline is a reported extra; never fail the GPU number
                     out["cpu_baseline"] = {"value": None, "error": repr(e)}
-            emit(out)
+            if args.full_line:
+                emit(out)
+            else:
+                emit(compact_line(out, write_full_record(out)))
     finally:
         ctx.finish()
 

@@ -44,9 +44,16 @@ class AdaptationInfo(NamedTuple):  # adaptation/base.py:26-29
 
 def return_all_adapt_info(state, info, adaptation_state):
     """adaptation/base.py:32-36.  NOTE: with thousands of chains this retains every step's
-    (N, D) tensors; pass ``get_filter_adapt_info_fn(...)`` to keep only what is needed.  As the DEFAULT of
-    ``window_adaptation`` it is replaced by ``_scalars_only_adapt_info`` (with a one-time warning) when one step's
-    record would exceed ``ALL_INFO_MAX_BYTES`` -- pass it explicitly to keep everything regardless."""
+    (N, D) tensors; pass ``get_filter_adapt_info_fn(...)`` to keep only what is needed.  Passed EXPLICITLY it is
+    always honoured; ``window_adaptation``'s default (``_default_adapt_info``) behaves like it but is replaced by
+    ``_scalars_only_adapt_info`` (with a warning) when one step's record would exceed ``ALL_INFO_MAX_BYTES``."""
+    return AdaptationInfo(state, info, adaptation_state)
+
+
+def _default_adapt_info(state, info, adaptation_state):
+    """The default ``adaptation_info_fn`` of ``window_adaptation`` / ``staged_adaptation``: a private sentinel that
+    records what ``return_all_adapt_info`` records (adaptation/base.py:32-36), distinguishable from an explicit
+    ``adaptation_info_fn=return_all_adapt_info`` (the explicit argument must never be downgraded)."""
     return AdaptationInfo(state, info, adaptation_state)
 
 
@@ -54,7 +61,7 @@ def return_all_adapt_info(state, info, adaptation_state):
 # above this many bytes PER STEP the default keeps the per-chain scalars only (1 GiB at 32 768 x 4 096: a 1 000-step
 # warm-up would otherwise retain 5+ TiB -- the reference's default is fatal at this scale)
 ALL_INFO_MAX_BYTES = 256 << 20
-_WARNED_INFO = [False]
+_WARNED_INFO = set()  # (n, d) shapes the downgrade was announced for
 
 
 def _scalars_only_adapt_info(state, info, adaptation_state):
@@ -64,7 +71,7 @@ def _scalars_only_adapt_info(state, info, adaptation_state):
 
     n = state.position.shape[0]
 
-    def small(t):  # per-chain scalars: (N,) tensors (and Python scalars); the shared (D,) initial metric is dropped too
+    def small(t):  # per-chain scalars: (N,) tensors (and Python scalars)
         if isinstance(t, torch.Tensor):
             return t if (t.ndim == 0 or (t.ndim == 1 and t.shape[0] == n)) else None
         return t
@@ -73,10 +80,34 @@ def _scalars_only_adapt_info(state, info, adaptation_state):
         if tup is None:
             return None
         if isinstance(tup, tuple) and hasattr(tup, "_fields"):
-            return type(tup)(*[filt(v) for v in tup])
+            # the metric is dropped BY NAME: a shared (D,) diagonal has the shape of a per-chain scalar when N == D
+            return type(tup)(*[None if k == "inverse_mass_matrix" else filt(v) for k, v in zip(tup._fields, tup)])
         return small(tup)
 
     return AdaptationInfo(filt(state), filt(info), filt(adaptation_state))
+
+
+def _select_info_fn(adaptation_info_fn, n: int, d: int, is_mass_matrix_diagonal: bool):
+    """What ``window_adaptation.run`` records per step, and whether the Welford buffers may be updated in place.
+    Only the DEFAULT (``_default_adapt_info``) is downgraded to per-chain scalars for large ensembles, with a warning
+    per shape; an explicit ``return_all_adapt_info`` -- or any user function -- is honoured as given."""
+    info_fn = adaptation_info_fn
+    if info_fn is _default_adapt_info and 11 * 4 * n * d > ALL_INFO_MAX_BYTES:
+        info_fn = _scalars_only_adapt_info
+        if (n, d) not in _WARNED_INFO:  # once per shape: every downgraded shape is announced
+            _WARNED_INFO.add((n, d))
+            import warnings
+
+            warnings.warn(
+                f"blackjax_amd.window_adaptation: the default adaptation_info_fn would retain "
+                f"~{11 * 4 * n * d / 2**30:.1f} GiB per warm-up step at {n} x {d}; keeping the per-chain scalars of every "
+                "step instead (state.logdensity, info.acceptance_rate / flags / energy, the dual-averaging state, "
+                "step sizes).  Pass adaptation_info_fn=blackjax_amd.adaptation.return_all_adapt_info explicitly "
+                "(it is then honoured) or get_filter_adapt_info_fn(...) to choose.", RuntimeWarning, stacklevel=3)
+    # the Welford buffers may be updated in place when no per-step record can hold on to them
+    in_place = bool(is_mass_matrix_diagonal) and (
+        info_fn is None or info_fn is _scalars_only_adapt_info or getattr(info_fn, "_bjx_keeps_no_welford", False))
+    return info_fn, in_place
 
 
 def get_filter_adapt_info_fn(state_keys=frozenset(), info_keys=frozenset(),
@@ -265,7 +296,7 @@ def _stack_history(history):
 def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagonal: bool = True,
                       initial_inverse_mass_matrix=None, imm_shrinkage_to_previous: float = 0.0,
                       initial_step_size: float = 1.0, target_acceptance_rate: float = 0.80,
-                      adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
+                      adaptation_info_fn: Optional[Callable] = _default_adapt_info,
                       integrator=integrators.velocity_verlet, _schedule_fn: Optional[Callable] = None,
                       fuse_target: bool = False, **extra_parameters) -> AdaptationAlgorithm:
     """blackjax/adaptation/window_adaptation.py:296-444.  ``algorithm`` is ``blackjax_amd.hmc`` or
@@ -331,7 +362,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             raise NotImplementedError("free_running=True is implemented for blackjax_amd.nuts")
         if not is_mass_matrix_diagonal:
             raise NotImplementedError("free_running=True needs a diagonal mass matrix")
-        if adaptation_info_fn not in (None, return_all_adapt_info):
+        if adaptation_info_fn not in (None, return_all_adapt_info, _default_adapt_info):
             raise ValueError("free_running=True records a NUTSRunInfo, not adaptation_info_fn's output: "
                              "pass adaptation_info_fn=None (or the default) with it")
         if integrator is not integrators.velocity_verlet:
@@ -402,22 +433,7 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
             ss, MassMatrixAdaptationState(imm, WelfordAlgorithmState(zeros, m2_0, 0)), eps0, imm)
         history = []
         info = None
-        info_fn = adaptation_info_fn
-        if info_fn is return_all_adapt_info and 11 * 4 * n * d > ALL_INFO_MAX_BYTES:
-            info_fn = _scalars_only_adapt_info
-            if not _WARNED_INFO[0]:
-                _WARNED_INFO[0] = True
-                import warnings
-
-                warnings.warn(
-                    f"blackjax_amd.window_adaptation: the default adaptation_info_fn (return_all_adapt_info) would retain "
-                    f"~{11 * 4 * n * d / 2**30:.1f} GiB per warm-up step at {n} x {d}; keeping the per-chain scalars of every "
-                    "step instead (state.logdensity, info.acceptance_rate / flags / energy, the dual-averaging state, "
-                    "step sizes).  Pass adaptation_info_fn=blackjax_amd.adaptation.return_all_adapt_info explicitly "
-                    "(it is then honoured) or get_filter_adapt_info_fn(...) to choose.", RuntimeWarning, stacklevel=2)
-        # the Welford buffers may be updated in place when no per-step record can hold on to them
-        welford_in_place = is_mass_matrix_diagonal and (
-            info_fn is None or info_fn is _scalars_only_adapt_info or getattr(info_fn, "_bjx_keeps_no_welford", False))
+        info_fn, welford_in_place = _select_info_fn(adaptation_info_fn, n, d, is_mass_matrix_diagonal)
         schedule = build_schedule(int(num_steps)) if _schedule_fn is None else _as_schedule(
             _schedule_fn(int(num_steps)), int(num_steps))
         for t, (stage, is_window_end) in enumerate(schedule):
@@ -473,7 +489,7 @@ def staged_adaptation(algorithm, logdensity_fn: Callable, metric: str = "welford
                       max_grad_budget=None, n_chains: int = 1, imm_shrinkage_to_previous: float = 0.0,
                       initial_inverse_mass_matrix=None, initial_step_size: float = 1.0,
                       target_acceptance_rate: float = 0.80,
-                      adaptation_info_fn: Optional[Callable] = return_all_adapt_info,
+                      adaptation_info_fn: Optional[Callable] = _default_adapt_info,
                       integrator=integrators.velocity_verlet, schedule_fn: Optional[Callable] = None,
                       initial_metric_state=None, **extra_parameters) -> AdaptationAlgorithm:
     """The engine entry point of blackjax/adaptation/staged_adaptation.py:519-983, of which

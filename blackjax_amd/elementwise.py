@@ -209,12 +209,18 @@ _UN_METHODS = {"exp", "log", "log1p", "expm1", "sqrt", "rsqrt", "tanh", "sigmoid
 
 
 def _is_last_axis(args, kwargs) -> bool:
-    dim = kwargs.get("dim", kwargs.get("axis", args[0] if args else None))
-    if kwargs.get("keepdim", False):
+    """``sum(dim[, keepdim])`` arguments (positional or by name) of a row sum this generator can emit: the last axis of
+    the (N, D) batch, keepdim false, no ``dtype=``.  Anything else is refused (the caller raises NotImplementedError):
+    ``q.sum(-1, True)`` is (N, 1) in PyTorch, not the (N,) row sum."""
+    if len(args) > 2 or set(kwargs) - {"dim", "axis", "keepdim"}:  # extra positionals, dtype=, out= ...
+        return False
+    dim = args[0] if args else kwargs.get("dim", kwargs.get("axis"))
+    keepdim = args[1] if len(args) > 1 else kwargs.get("keepdim", False)
+    if not isinstance(keepdim, (bool, int)) or keepdim:
         return False
     if isinstance(dim, (tuple, list)) and len(dim) == 1:
         dim = dim[0]
-    return dim in (-1, 1)
+    return isinstance(dim, int) and not isinstance(dim, bool) and dim in (-1, 1)  # the batch is 2-D: (N, D)
 
 
 def trace(fn: Callable, dim: int, device="cpu") -> ElementwiseSource:

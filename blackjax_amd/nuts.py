@@ -1436,33 +1436,38 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
         k = (n_, d_, tuple(m.imm.shape), pos.device.index, torch.cuda.current_stream(pos.device).cuda_stream)
         return None if k in free_bad else k
 
+    def _free_step_failed(wkey, state, err):
+        # a recording failed, or the speculative tail's replica check / tick bound fired (first call OR a later rerun):
+        # say so, drop the workspace and keep this shape on the lockstep tree driver, which restarts the transition from
+        # `state` (never modified by the free-running driver before it returns)
+        import warnings
+
+        warnings.warn(f"blackjax_amd.nuts.step: the free-running driver failed for this shape ({err}); "
+                      "falling back to the lockstep tree driver", RuntimeWarning, stacklevel=4)
+        free_bad.add(wkey)
+        free_ws.pop(wkey, None)
+        torch.cuda.synchronize(state.position.device)
+
     def _free_step(wkey, rng_key, state):
         h = free_ws.get(wkey)
-        if h is None:
-            h = {}
-            try:
+        try:
+            if h is None:
+                h = {}
                 new_state, _, ri = run_free(
                     rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, 1, max_num_doublings,
                     divergence_threshold=divergence_threshold, chain_offset=chain_offset, key_layout="step",
                     store_positions=False, use_graph=True if use_graph is True else run_use_graph,
                     integrator=integrator, keep_ends=True, spec_rows=step_spec_rows, _handle=h)
-            except RuntimeError as err:
-                if step_driver == "free":
-                    raise
-                # a recording failed (or the speculative tail's replica check fired): say so, and keep this shape on
-                # the lockstep tree driver, which restarts the transition from `state` (never modified here)
-                import warnings
-
-                warnings.warn(f"blackjax_amd.nuts.step: the free-running driver failed for this shape ({err}); "
-                              "falling back to the lockstep tree driver", RuntimeWarning, stacklevel=3)
-                free_bad.add(wkey)
-                torch.cuda.synchronize(state.position.device)
-                return None
-            while len(free_ws) >= 2:  # a workspace is ~20 (N, D) buffers: keep the two most recent shapes only
-                free_ws.pop(next(iter(free_ws)))
-            free_ws[wkey] = h
-        else:
-            new_state, _, ri = h["rerun"](rng_key, state, step_size, inverse_mass_matrix)
+                while len(free_ws) >= 2:  # a workspace is ~20 (N, D) buffers: keep the two most recent shapes only
+                    free_ws.pop(next(iter(free_ws)))
+                free_ws[wkey] = h
+            else:
+                new_state, _, ri = h["rerun"](rng_key, state, step_size, inverse_mass_matrix)
+        except RuntimeError as err:
+            if step_driver == "free":
+                raise
+            _free_step_failed(wkey, state, err)
+            return None
         w = h["work"]
         b_, rec_f = w["bufs"], w["rec"].view(torch.float32)
         c = lambda t: t.clone()  # noqa: E731

@@ -154,7 +154,7 @@ def test_default_info_keeps_scalars_at_scale_and_in_place_welford_is_bit_identic
     sig = torch.as_tensor((10.0 ** (-1.0 + 2.0 * np.arange(D) / (D - 1))).astype(np.float32), device=dev)
     tgt = bjx.targets.DiagGaussian((1.0 / (sig * sig)).contiguous())
     q0 = torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
-    bad._WARNED_INFO[0] = False
+    bad._WARNED_INFO.clear()
     with pytest.warns(RuntimeWarning, match="per-chain scalars"):
         (st_a, par_a), hist_a = bjx.window_adaptation(bjx.hmc, tgt, num_integration_steps=3).run(bjx.random.key(3), q0, T)
     assert hist_a.state.position is None and hist_a.info.momentum is None
@@ -167,3 +167,28 @@ def test_default_info_keeps_scalars_at_scale_and_in_place_welford_is_bit_identic
     assert torch.equal(torch.as_tensor(par_a["inverse_mass_matrix"]), torch.as_tensor(par_b["inverse_mass_matrix"]))
     assert torch.equal(st_a.position, st_b.position)
     assert float(torch.as_tensor(par_a["inverse_mass_matrix"]).std()) > 0  # the window end did update the metric
+
+
+def test_explicit_return_all_is_honoured_and_n_equals_d_record_is_uniform(dev, monkeypatch):
+    """only the DEFAULT adaptation_info_fn is downgraded above ALL_INFO_MAX_BYTES; an explicit
+    ``return_all_adapt_info`` keeps every tensor (adaptation/base.py:32-36).  With N == D the shared (D,) initial metric
+    has the shape of a per-chain scalar: the scalars-only record drops it by NAME, so the stacked field is uniform."""
+    N = D = 32
+    T = 24
+    tgt = bjx.targets.DiagGaussian(torch.ones(D, device=dev))
+    q0 = torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    monkeypatch.setattr(bad, "ALL_INFO_MAX_BYTES", 1024)
+    bad._WARNED_INFO.clear()
+    with pytest.warns(RuntimeWarning, match="per-chain scalars"):
+        (st_a, par_a), hist_a = bjx.window_adaptation(bjx.hmc, tgt, num_integration_steps=3).run(bjx.random.key(3), q0, T)
+    assert hist_a.state.position is None and hist_a.adaptation_state.inverse_mass_matrix is None
+    assert hist_a.adaptation_state.imm_state is None or hist_a.adaptation_state.imm_state.inverse_mass_matrix is None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # no downgrade, no warning
+        (st_b, par_b), hist_b = bjx.window_adaptation(bjx.hmc, tgt, num_integration_steps=3,
+                                                      adaptation_info_fn=bad.return_all_adapt_info).run(bjx.random.key(3), q0, T)
+    assert tuple(hist_b.state.position.shape) == (T, N, D) and hist_b.info.momentum is not None
+    assert torch.equal(hist_b.state.position[-1], st_b.position)
+    assert torch.equal(st_a.position, st_b.position) and torch.equal(par_a["step_size"], par_b["step_size"])
+    assert torch.equal(hist_a.info.acceptance_rate, hist_b.info.acceptance_rate)

@@ -40,6 +40,10 @@ def test_what_is_refused_says_why():
                       (lambda q: (q @ torch.eye(D)).sum(-1), "shape"),
                       (lambda q: torch.exp((q * q).sum(-1)), "non-linear"),
                       (lambda q: (q * q).sum(0), "last axis"),
+                      (lambda q: (q * q).sum(-1, True), "last axis"),          # positional keepdim: (N, 1), not the row sum
+                      (lambda q: torch.sum(q * q, -1, True), "last axis"),
+                      (lambda q: (q * q).sum(-1, keepdim=True), "last axis"),
+                      (lambda q: (q * q).sum(-1, dtype=torch.float64), "last axis"),
                       (lambda q: q * q, "sum over the last axis")):
         with pytest.raises(NotImplementedError, match=word):
             ew.trace(bad, D)

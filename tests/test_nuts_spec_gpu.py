@@ -14,10 +14,6 @@ from oracle import prng, targets as otargets
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
-# Cases written after the last GPU call of round 5 (the budget was spent): the protocol they exercise is modelled on the
-# CPU (tests/test_spec_protocol_model.py) but they have NOT run on an MI355X yet, so they may not turn the suite red: they
-# report XPASS / XFAIL until a hardware run promotes them (drop the mark then).
-_NOT_YET_ON_HARDWARE = pytest.mark.xfail(strict=False, reason="added after round 5's last GPU call: never run on hardware")
 
 
 def _run(dev, fn, q0, eps, imm, T, max_depth, spec_rows, key=7, integrator=None, **kw):
@@ -49,8 +45,8 @@ def _assert_same(a, b):
     (1, 8, 30, 9, 0.05),      # a single chain
     # two doublings at most: the integrator's tree is exhausted after three leaves / one doubling: every transition is
     # one leaf
-    pytest.param(16, 16, 60, 2, 0.3, marks=_NOT_YET_ON_HARDWARE),
-    pytest.param(16, 16, 80, 1, 0.3, marks=_NOT_YET_ON_HARDWARE),
+    (16, 16, 60, 2, 0.3),
+    (16, 16, 80, 1, 0.3),
 ])
 def test_spec_tail_equals_one_stream_tail_funnel(dev, N, D, T, max_depth, eps):
     g = torch.Generator(device=dev)

@@ -103,7 +103,6 @@ def test_free_step_workspace_reuse_with_run(dev):
     assert torch.equal(info.num_integration_steps[-1], ia.num_integration_steps)
 
 
-@pytest.mark.xfail(strict=False, reason="added after round 5's last GPU call: never run on hardware")
 def test_free_step_shapes_come_and_go(dev):
     """Three ensemble sizes through ONE algorithm object (the driver keeps the two most recent workspaces), shallow
     depth limits, and the lockstep fall-back for a ChainMajorKey."""

@@ -553,12 +553,10 @@ def test_generator_reproduces_the_committed_fixture():
 
 
 # ------------------------------------------------------------------------------------------------ the HIP path
-_NOT_YET_ON_HARDWARE = pytest.mark.xfail(strict=False, reason="written after round 5's last GPU call: never run on hardware")
 _GPU_CASES = [n for n, c in sorted(FX["samplers"].items()) if c["algorithm"] in ("hmc", "mhmc", "nuts")]  # (dynamic: per-chain keys)
 
 
 @pytest.mark.gpu
-@_NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("name", _GPU_CASES)
 def test_hip_transition_equals_the_reference_code(fx, dev, name):
     """The HIP kernels against the reference's own code, no oracle in between (the engine's shared dense metric runs on
@@ -596,7 +594,6 @@ def test_hip_transition_equals_the_reference_code(fx, dev, name):
 
 
 @pytest.mark.gpu
-@_NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("name", sorted(FX["warmup"]))
 def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name):
     """The warm-up's device kernels (``bjx_da_init / bjx_da_update``, ``bjx_welford_update_*``, ``bjx_welford_final_*`` through
@@ -640,7 +637,6 @@ def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name)
 
 
 @pytest.mark.gpu
-@_NOT_YET_ON_HARDWARE
 def test_hip_pooled_warmups_and_ghmc_equal_the_reference_code(dev):
     """``ghmc`` (three transitions), ``chees_adaptation`` (40 steps) and ``meads_adaptation`` (12 steps) on the HIP path
     against the reference's records -- the call conventions of tests/test_ghmc_gpu.py / test_chees_gpu.py."""
