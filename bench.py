@@ -34,8 +34,12 @@ JSON extras (contract in the task statement):
                 part of the traffic never reaches HBM -- it can exceed what HBM alone delivers and
                 is reported under that name only.  ``traffic`` comes from the committed PMC summary
                 (``traffic_source`` says so; it is not measured in this run).
-  torch_callable_mode   the same workload with the user log-density as a plain PyTorch function
-                (autograd), the path north_star names, with its own bytes/element estimate.
+  torch_callable_mode   the same workload with the user log-density as a plain PyTorch function handed to hmc(...) as is
+                (the path north_star names): by default traced on its first call into one generated value-and-gradient
+                kernel; torch_autograd_mode = the same function kept on eager autograd (blackjax_amd.no_trace).
+  stdout        ONE compact JSON line (<= 6 KB: headline keys, roofline, cpu_baseline, parity, per-config value /
+                roofline / parity counts); the FULL object goes to stderr and gpurun_out/bench_full_latest.json
+                ($BJX_BENCH_FULL); --full-line prints the full object on stdout instead.
   ess / ess_nonresonant   min-ESS per second on the contract parameters (eps*L = 12.5 ~ 4 pi: a
                 resonant trajectory length, every transition returns near its start) and on
                 eps = 0.21 (same cost per transition, non-resonant).
@@ -355,6 +359,7 @@ _PARITY_KEYS = ("chains_checked", "accept_mismatches", "divergence_mismatches", 
                 "max_abs_dacceptance_rate", "largest_tree_checked", "chain_blocks_covered", "chain_blocks_total",
                 "gemm_tiles_covered", "gemm_tiles_total", "error")
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_timed",
+              "algorithmic_bytes_per_chain_leapfrog",
               "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "chains_per_launch", "mode",
               "cache_assisted_frac", "traffic_over_algorithmic", "frac_at_measured_bytes",
               "busy_phase_tick_frac_measured", "full_ensemble_tick_us", "traffic_build")
@@ -367,7 +372,7 @@ def compact_line(out, full_path):
     stderr and to `full_path`."""
     c = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "mean_acceptance", "end_to_end_frac_of_28B_roofline", "ranks",
-              "backend", "per_rank_ms_per_step")
+              "backend", "per_rank_ms_per_step", "devices_distinct", "n_gpus_note")
     if "roofline" in out:
         c["roofline"] = _pick(out["roofline"], *_ROOF_KEYS)
         ts = out["roofline"].get("traffic_source")
@@ -387,7 +392,7 @@ def compact_line(out, full_path):
     if isinstance(out.get("ess_nonresonant"), dict):
         c["ess_nonresonant"] = _pick(out["ess_nonresonant"], "min_ess_per_sec_all_chains", "min_ess_subset", "subset_chains",
                                      "draws_per_chain", "eps", "leapfrogs", "ms_per_step", "mean_acceptance")
-    for name in ("torch_callable_mode", "torch_elementwise_mode", "torch_default_mode", "torch_compile_mode"):
+    for name in ("torch_callable_mode", "torch_autograd_mode", "torch_elementwise_mode", "torch_compile_mode"):
         if isinstance(out.get(name), dict):
             c[name] = _pick(out[name], "value", "ms_per_step", "frac_of_28B_roofline", "path", "error")
     for name in ("c5_dense", "c3_nuts", "c4_shard"):
@@ -413,7 +418,8 @@ def compact_line(out, full_path):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     # hard bound: drop the least important keys until the line fits
-    for k in ("oracle_pin", "rng_pin", "torch_compile_mode", "torch_callable_mode", "per_rank_ms_per_step", "ess_note"):
+    for k in ("oracle_pin", "rng_pin", "torch_compile_mode", "torch_elementwise_mode", "per_rank_ms_per_step", "ess_note",
+              "torch_autograd_mode"):
         if len(line) <= 6000:
             break
         c.pop(k, None)
@@ -852,22 +858,41 @@ def bench_c2(args, ctx):
         line["frac_of_roofline_at_those_bytes"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (bpe * D))
         return line
 
-    torch_mode = torch_graph_mode = torch_pair_mode = None
+    torch_mode = torch_autograd_mode = torch_graph_mode = torch_pair_mode = None
     if extras and not args.no_torch_callable:
         k_t = max(2, args.steps // 4)
+        # (0) the DEFAULT path: hmc(torch_logdensity, ...) -- a plain PyTorch function, nothing declared.  Its first call
+        # is evaluated under autograd and, since it returns only logp, traced into ONE generated value-and-gradient
+        # kernel (blackjax_amd._util._try_elementwise -> targets.from_elementwise), checked against that autograd call.
+        def torch_logdensity_default(q):
+            return -0.5 * (q * q * inv_var).sum(-1)
+
+        m0 = measure(blk_auto, False, False, steps=k_t, fn=torch_logdensity_default, timing=False)
+        vg0 = bjx._util.value_and_grad(torch_logdensity_default)
+        traced = [k for k, v in getattr(vg0, "_bjx_elementwise", {}).items() if v is not None]
+        torch_mode = torch_line(m0, k_t, "torch_elementwise" if traced else "torch_autograd",
+                                "lambda q: -0.5 * (q * q * inv_var).sum(-1) handed to hmc(...) as is", 8 if traced else 48)
+        torch_mode["path"] = ("default: traced on first call into one generated HIP value-and-gradient kernel "
+                              "(elementwise.from_elementwise), verified against that call's autograd result" if traced
+                              else "default: eager torch.autograd (the function is outside the element-wise + row-sum shape)")
+        torch_mode["frac_of_28B_roofline"] = m0["value"] / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D))
+        # (1) the same function kept on eager autograd (blackjax_amd.no_trace): what the default path saves
+        bjx.no_trace(torch_logdensity)
         m = measure(blk_auto, False, False, steps=k_t, fn=torch_logdensity, timing=False)
         # elementwise autograd passes (fp32 words per element): q*q r1 w1, *inv_var r1 w1, sum r1,
         # backward through mul/mul r3 w3 (+ accumulation) -> ~12 words vs 2 for a fused callable
-        torch_mode = torch_line(m, k_t, "torch_autograd",
-                                "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad, grad_outputs=ones)", 48)
-        torch_mode["frac_of_68B_roofline"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D))
+        torch_autograd_mode = torch_line(m, k_t, "torch_autograd",
+                                         "lambda q: -0.5 * (q * q * inv_var).sum(-1)  (torch.autograd.grad, grad_outputs=ones)", 48)
+        torch_autograd_mode["path"] = "blackjax_amd.no_trace(fn): eager torch.autograd on every call"
+        torch_autograd_mode["frac_of_68B_roofline"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (68.0 * D))
+        torch_autograd_mode["frac_of_28B_roofline"] = m["value"] / world / (HBM_PEAK_GBS * 1e9 / (28.0 * D))
         if world > 1:
             torch_graph_mode = {"value": None, "skipped": "single-GPU runs only (no graph capture under a process group)"}
         else:
             try:
                 mg = measure(blk_auto, True, False, steps=k_t, fn=torch_logdensity, timing=False)
                 torch_graph_mode = torch_line(mg, k_t, "torch_autograd",
-                                              torch_mode["logdensity"] + ", inner loop as a HIP graph", 48)
+                                              torch_autograd_mode["logdensity"] + ", inner loop as a HIP graph", 48)
             except Exception as e:  # a callable torch cannot record is driven with plain launches: say why
                 torch_graph_mode = {"value": None, "error": repr(e)[:300]}
         mp = measure(blk_auto, False, False, steps=k_t, fn=torch_pair, timing=False)
@@ -1010,6 +1035,7 @@ def bench_c2(args, ctx):
         "scheduling_autotune_ms_per_step": {f"chain_block={cb},hip_graph={gr},streams={ns_}": v
                                             for (cb, gr, ns_), v in tuning.items()} or None,
         "torch_callable_mode": torch_mode,
+        "torch_autograd_mode": torch_autograd_mode,
         "torch_callable_graph_mode": torch_graph_mode,
         "torch_pair_mode": torch_pair_mode,
         "torch_elementwise_mode": torch_elementwise_mode,

@@ -18,7 +18,7 @@ from .adaptation import staged_adaptation, window_adaptation
 from .chees import chees_adaptation
 from .meads import meads_adaptation
 from .base import AdaptationAlgorithm, SamplingAlgorithm
-from ._util import capturable, returns_pair
+from ._util import capturable, no_trace, returns_pair
 
 __version__ = "0.1.0"
 
@@ -63,4 +63,4 @@ hmc_family = [hmc, nuts, mhmc]  # blackjax/__init__.py:188
 # Generalized HMC (blackjax/mcmc/ghmc.py), the sampler the MEADS warm-up tunes
 ghmc = GenerateSamplingAPI(_ghmc.as_top_level_api, _ghmc.init, _ghmc.build_kernel)
 
-__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "dmhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "rtc", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable", "returns_pair"]
+__all__ = ["hmc", "nuts", "mhmc", "hmc_family", "multinomial_hmc", "dynamic_hmc", "dhmc", "dmhmc", "ghmc", "window_adaptation", "staged_adaptation", "chees_adaptation", "meads_adaptation", "chees", "meads", "optim", "adaptation", "diagnostics", "distributed", "util", "metrics", "integrators", "random", "rtc", "targets", "SamplingAlgorithm", "AdaptationAlgorithm", "capturable", "returns_pair", "no_trace"]

@@ -47,9 +47,20 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
             g = _grad(lp, q)
         return lp.detach(), g
 
+    ew: dict = {}  # (D, device) -> generated element-wise target, or None (not of that shape / failed its check)
+
+    def _autograd_or_elementwise(q, first=None):
+        key = (int(q.shape[-1]), q.device)
+        if key in ew:
+            tgt = ew[key]
+            return tgt(q) if tgt is not None else (first if first is not None else _autograd(q))
+        lp, g = first if first is not None else _autograd(q)
+        ew[key] = _try_elementwise(logdensity_fn, q, lp, g)
+        return lp, g
+
     def vg(q):
         if mode["kind"] == "autograd":
-            return _autograd(q)
+            return _autograd_or_elementwise(q)
         if mode["kind"] == "pair":
             return logdensity_fn(q)
         # First call of an UNDECLARED callable: one evaluation decides which kind it is.  It is made
@@ -67,14 +78,83 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
                 return lp, g
             mode["kind"] = "autograd"
             g = _grad(out, qg)
-        return out.detach(), g
+        # a log-density that returns only logp: what jax.value_and_grad + XLA fuse in the reference
+        # (integrators.py:189,204).  Try the one-kernel form first (``elementwise.from_elementwise``: torch.fx trace ->
+        # forward-mode derivative -> ONE generated HIP value-and-gradient kernel), checked here against this very
+        # autograd evaluation; anything it cannot express, or that fails the check, stays on autograd.
+        return _autograd_or_elementwise(q, first=(out.detach(), g))
 
+    vg._bjx_elementwise = ew
     vg._bjx_value_and_grad = True
     try:
         _VG_CACHE[logdensity_fn] = vg
     except TypeError:
         pass
     return vg
+
+
+_WARNED_AUTOGRAD: set = set()
+
+
+def no_trace(logdensity_fn: Callable) -> Callable:
+    """Declare that a log-density must NOT be traced into a generated kernel (it reads Python state that changes
+    between calls, or its eager arithmetic is wanted as is): it is always evaluated eagerly under autograd."""
+    try:
+        logdensity_fn._bjx_no_trace = True
+        return logdensity_fn
+    except AttributeError:
+        w = _Capturable(logdensity_fn)
+        w._bjx_capturable = False
+        w._bjx_no_trace = True
+        return w
+
+
+def _try_elementwise(logdensity_fn, q, lp_ref, g_ref):
+    """The default fast path for a plain PyTorch log-density: ``targets.from_elementwise`` on the
+    user's function, accepted only if its (logp, grad) at ``q`` agree with the autograd evaluation just made
+    (1e-4 of the batch's largest magnitude: a mis-traced function -- data-dependent Python control flow that torch.fx
+    froze, state read at trace time -- differs by far more; rounding differs by ~1e-6).  Returns the target or None;
+    never raises.  Like ``jax.jit`` in the reference, a traced function is the function AS IT WAS when first called:
+    ``blackjax_amd.no_trace(fn)`` (or ``BJX_AUTO_ELEMENTWISE=0``) keeps a callable on eager autograd."""
+    import os
+    import warnings
+
+    why = None
+    if os.environ.get("BJX_AUTO_ELEMENTWISE", "1") == "0" or getattr(logdensity_fn, "_bjx_no_trace", False):
+        why = "tracing disabled for this callable"
+    elif not (q.is_cuda and q.ndim == 2 and q.dtype == torch.float32 and q.shape[0] > 0):
+        why = "not a float32 (N, D) device batch"
+    elif torch.cuda.is_current_stream_capturing():
+        why = "first call made under stream capture"
+    tgt = None
+    if why is None:
+        try:
+            from .targets import from_elementwise
+
+            tgt = from_elementwise(logdensity_fn, int(q.shape[1]), device=q.device)
+            lp, g = tgt(q.detach().contiguous())
+
+            def close(a, b):
+                a, b = a.float(), b.float()
+                fin = torch.isfinite(b)
+                scale = float(b[fin].abs().max()) if bool(fin.any()) else 1.0
+                same_nonfinite = bool(((a == b) | (torch.isnan(a) & torch.isnan(b)))[~fin].all())
+                return same_nonfinite and bool(((a - b)[fin].abs() <= 1e-4 * max(scale, 1e-30)).all())
+
+            if not (close(lp, lp_ref) and close(g, g_ref)):
+                tgt, why = None, "the generated kernel disagreed with autograd on the first batch"
+        except NotImplementedError as e:
+            tgt, why = None, str(e)
+        except Exception as e:  # hiprtc / tracing trouble never takes the sampler down: autograd serves the call
+            tgt, why = None, f"{type(e).__name__}: {e}"
+    if tgt is None and id(logdensity_fn) not in _WARNED_AUTOGRAD and "disabled" not in (why or ""):
+        _WARNED_AUTOGRAD.add(id(logdensity_fn))
+        warnings.warn(
+            "blackjax_amd: this log-density is evaluated eagerly under torch.autograd (about a dozen element-wise passes "
+            f"per gradient: ~3 x slower than the sampler's kernels at large N x D) -- {why}.  Return (logp, grad) "
+            "yourself (blackjax_amd.returns_pair), use blackjax_amd.targets, or torch.compile the pair.",
+            RuntimeWarning, stacklevel=4)
+    return tgt
 
 
 _ONES: dict = {}

@@ -394,9 +394,61 @@ struct Target {{
   }}
 }};
 """
+    # The same element-wise body as a ROW-LOOP kernel for any D (rows longer than 1 024 floats, D % 4 != 0): one wave per
+    # chain row, spans of 4 x 1 KiB requested before they are consumed (row_sweep4), 4-byte accesses when D % 4 != 0.  A
+    # lane meets its elements in ascending column order, exactly as in `eval` above, so for D <= 1 024, D % 4 == 0 the
+    # fp64 partial sums -- and with them logp -- are the struct's bit for bit.  External callable only (the engine's
+    # kernels keep a row in registers: `eval`).
+    p_load_u = "".join(f"pq{i}[u] = ld4(params + {i} * D + j); " for i in range(n_p))
+    p_decl_arr = "".join(f"F4 pq{i}[4]; " for i in range(n_p))
+    p_unpack_u = "".join(f"const float pv{i}[4] = {{pq{i}[u].x, pq{i}[u].y, pq{i}[u].z, pq{i}[u].w}}; " for i in range(n_p))
+    p_scalar = "".join(f"const float P{i} = params[{i} * D + j]; " for i in range(n_p))
+    acc_add_rows = "".join(f"acc{t} += (double){gen.terms[t].v}; " for t in used)
+    rows_source = f"""
+// generated by blackjax_amd.elementwise.from_elementwise -- row-loop form (any D)
+extern "C" __global__ void __launch_bounds__(256) bjx_rtc_ew_rows(long long N, long long D, const float* __restrict__ params,
+                                                                   const float* __restrict__ q, float* __restrict__ logp,
+                                                                   float* __restrict__ grad) {{
+  const int lane = threadIdx.x & 63;
+  const int waves = blockDim.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * waves + (threadIdx.x >> 6); r < N; r += (int64_t)gridDim.x * waves) {{
+    const float* qr = q + r * D;
+    float* gr = grad + r * D;
+    {acc_decl}
+    if (D % 4 == 0) {{
+      F4 xq[4]; {p_decl_arr}
+      row_sweep4<4>(lane, D,
+        [&](int u, int64_t j) {{ xq[u] = ld4(qr + j); {p_load_u}}},
+        [&](int u, int64_t j) {{
+          const float xs[4] = {{xq[u].x, xq[u].y, xq[u].z, xq[u].w}}; {p_unpack_u}
+          float gs[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {{
+            const float x = xs[e]; {p_decl}
+            {body}
+            gs[e] = {g_expr};
+            {acc_add_rows}
+          }}
+          st4(gr + j, F4{{gs[0], gs[1], gs[2], gs[3]}});
+        }});
+    }} else {{
+      for (int64_t j = lane; j < D; j += 64) {{
+        const float x = qr[j]; {p_scalar}
+        {body}
+        gr[j] = {g_expr};
+        {acc_add_rows}
+      }}
+    }}
+    const float lp = (float)({lp_expr});
+    if (lane == 0) logp[r] = lp;
+  }}
+}}
+"""
     params = torch.stack(gen.params).contiguous() if gen.params else None
-    return ElementwiseSource(source, params, len(used),
-                             f"{len(gen.lines)} fp32 ops per element, {n_p} parameter vector(s), {len(used)} row sum(s)")
+    src = ElementwiseSource(source, params, len(used),
+                            f"{len(gen.lines)} fp32 ops per element, {n_p} parameter vector(s), {len(used)} row sum(s)")
+    src.rows_source = rows_source
+    return src
 
 
 class _Wrap(torch.nn.Module):
@@ -410,15 +462,25 @@ class _Wrap(torch.nn.Module):
         return self._fn(q)
 
 
+ROWS_TU = """#include "bjx_traj_dev.h"
+using namespace bjx;
+%(source)s
+"""
+
+
 def from_elementwise(fn: Callable, dim: int, device="cuda"):
     """A ``blackjax_amd.targets.DeviceTarget`` computing ``(fn(q), d fn / d q)`` in one launch (see the module
-    docstring).  ``dim`` = D (rows of at most 1 024 floats, ``D % 4 == 0``: the DeviceTarget's limits)."""
-    from .targets import DeviceTarget
+    docstring).  ``dim`` = D.  Rows of at most 1 024 floats with ``D % 4 == 0`` give a full ``DeviceTarget`` (usable
+    with ``fuse_target=True`` too); any other D gives an ``ElementwiseRowsTarget``: the same generated arithmetic in a
+    row-loop kernel, an external callable only (BASELINE.json configs[3], D = 4 096, is served by it)."""
+    from .targets import DeviceTarget, ElementwiseRowsTarget
 
     dim = int(dim)
-    if dim % 4 != 0 or dim > 1024:
-        raise NotImplementedError("from_elementwise: rows of at most 1 024 floats, D % 4 == 0 (pass the plain callable otherwise)")
+    if dim < 1:
+        raise ValueError("from_elementwise: dim must be >= 1")
     src = trace(fn, dim, device)
+    if dim % 4 != 0 or dim > 1024:
+        return ElementwiseRowsTarget(src, dim)
     tgt = DeviceTarget(src.source, src.params)
     tgt.elementwise = src
     return tgt

@@ -173,11 +173,57 @@ class DeviceTarget(_Target):
         return logp, g
 
 
-def from_elementwise(fn, dim: int, device="cuda") -> DeviceTarget:
+class ElementwiseRowsTarget(_Target):
+    """``from_elementwise`` for rows the register-resident ``DeviceTarget`` cannot hold (D > 1 024 or D % 4 != 0): the
+    generated element-wise value-and-gradient arithmetic in a row-loop kernel (``elementwise.trace(...).rows_source``,
+    hiprtc).  An ordinary recordable external callable ``f(q) -> (logp, grad)`` moving 8 bytes per element; NOT
+    available to ``fuse_target=True`` (the engine's kernels keep a row in registers)."""
+
+    def __init__(self, src, dim: int):
+        self.elementwise, self.dim = src, int(dim)
+        self.params = src.params
+        self._module = None
+
+    def code_object(self) -> bytes:
+        from . import elementwise, rtc
+
+        return rtc.compile(elementwise.ROWS_TU % {"source": self.elementwise.rows_source}, "bjx_elementwise_rows.hip")
+
+    def module(self):
+        if self._module is None:
+            from . import rtc
+
+            self._module = rtc.Module(self.code_object())
+        return self._module
+
+    def _bjx_fused_target(self, dim: int):
+        return None
+
+    def __call__(self, q):
+        import ctypes
+
+        q, logp, g = self._alloc(q)
+        N, D = q.shape
+        if D != self.dim:
+            raise ValueError(f"this target was generated for D = {self.dim}, got {D}")
+        if N == 0:
+            return logp, g
+        if self.params is not None and self.params.device != q.device:
+            raise ValueError(f"params live on {self.params.device}, the chains on {q.device}")
+        grid = min((N + 3) // 4, 1 << 20)
+        self.module().launch("bjx_rtc_ew_rows", grid, 256, _lib.current_stream(), ctypes.c_longlong(N),
+                             ctypes.c_longlong(D), ctypes.c_void_p(0 if self.params is None else self.params.data_ptr()),
+                             ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(g.data_ptr()))
+        return logp, g
+
+
+def from_elementwise(fn, dim: int, device="cuda"):
     """A plain PyTorch log-density of the element-wise + row-sum shape -> ONE generated HIP value-and-gradient kernel
-    (``blackjax_amd.elementwise``: torch.fx trace, forward-mode derivative, hiprtc), returned as a ``DeviceTarget``:
-    an ordinary external callable ``f(q) -> (logp, grad)`` that moves 8 bytes per element instead of autograd's 50-80.
-    The reference gets this fusion from ``jax.value_and_grad`` under XLA (mcmc/integrators.py:189,204)."""
+    (``blackjax_amd.elementwise``: torch.fx trace, forward-mode derivative, hiprtc): an ordinary external callable
+    ``f(q) -> (logp, grad)`` that moves 8 bytes per element instead of autograd's 50-80 -- a ``DeviceTarget`` for rows
+    of at most 1 024 floats with D % 4 == 0, an ``ElementwiseRowsTarget`` (row-loop kernel) for any other D.
+    The reference gets this fusion from ``jax.value_and_grad`` under XLA (mcmc/integrators.py:189,204).
+    ``hmc / nuts(logdensity_fn)`` try this themselves on a plain PyTorch function (``_util.value_and_grad``)."""
     from .elementwise import from_elementwise as _f
 
     return _f(fn, dim, device)

@@ -16,17 +16,39 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 
 def _run(args, env_extra=None, timeout=600):
+    import tempfile
+
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    fd, full = tempfile.mkstemp(prefix="bjx_bench_full_", suffix=".json")
+    os.close(fd)
+    os.unlink(full)
+    env["BJX_BENCH_FULL"] = full  # the FULL record (the stdout line is the compact one, <= 6 KB)
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env,
-                          timeout=timeout, cwd=ROOT)
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=ROOT)
+    r.full_path = full
+    return r
 
 
 def _json_line(stdout):
     lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, stdout
+    assert len(lines[0]) <= 6000, len(lines[0])  # the driver keeps an 8 KB tail of stdout
     return json.loads(lines[0])
+
+
+def _full(r):
+    """The full record bench.py writes next to the compact stdout line (also on stderr)."""
+    try:
+        with open(r.full_path) as fh:
+            j = json.loads(fh.read())
+    finally:
+        if os.path.exists(r.full_path):
+            os.unlink(r.full_path)
+    on_stderr = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py FULL RECORD: ")]
+    assert len(on_stderr) == 1 and json.loads(on_stderr[0][len("bench.py FULL RECORD: "):]) == j
+    return j
 
 
 def test_gpus_flag_refuses_instead_of_running_fewer_ranks():
@@ -61,18 +83,26 @@ TINY = ["--chains", "4096", "--dim", "256", "--leapfrogs", "6", "--steps", "4", 
 def test_bench_c2_tiny_single_rank_json_contract():
     r = _run(TINY)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    c = _json_line(r.stdout)  # the compact line of the contract
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in j, k
-    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["dtype"] == "f32" and j["vs_baseline"] is None
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity",
+              "ess_nonresonant", "full_record"):
+        assert k in c, k
+    assert c["n_gpus"] == 1 and c["steps"] == 4 and c["dtype"] == "f32" and c["vs_baseline"] is None
+    assert c["roofline"]["bound"] == "hbm" and abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-5
+    assert c["parity"]["accept_mismatches"] == 0 and c["parity"]["chains_checked"] > 0
+    assert c["cpu_baseline"]["kind"] in ("port", "reference") and c["cpu_baseline"]["cores"] >= 1
+    j = _full(r)
+    assert abs(j["value"] - c["value"]) <= 1e-5 * j["value"] and j["config"] == c["config"]
     roof = j["roofline"]
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert roof["chains_per_launch"] == 4096 and "streaming" in roof["mode"]
     assert roof["traffic_source"] is None or "NOT measured in this run" in roof["traffic_source"]
     assert j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["value"] > 0
-    tc = j["torch_callable_mode"]
-    assert tc["value"] > 0 and "autograd" in tc["logdensity"]
+    tc = j["torch_callable_mode"]  # a plain PyTorch log-density, as the user writes it: the DEFAULT path (traced)
+    assert tc["value"] > 0 and "elementwise" in tc["path"]
+    ta = j["torch_autograd_mode"]  # the same function kept on eager autograd (blackjax_amd.no_trace)
+    assert ta["value"] > 0 and "autograd" in ta["logdensity"] and "autograd" in ta["path"]
     # the three labelled user-callable lines (autograd, autograd under a HIP graph, plain-torch pair)
     assert j["torch_pair_mode"]["value"] > 0 and "no autograd" in j["torch_pair_mode"]["logdensity"]
     tg = j["torch_callable_graph_mode"]
@@ -89,7 +119,9 @@ def test_bench_two_gloo_ranks_share_one_gpu():
     n_gpus = 2, twice the chains, both ranks seen."""
     r = _run(["--gpus", "2", "--no-cpu-baseline"] + TINY, {"BJX_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    c = _json_line(r.stdout)
+    assert c["n_gpus"] == 1 and c["ranks"] == 2 and "cpu_baseline" not in c
+    j = _full(r)
     # two gloo ranks on ONE device: n_gpus counts distinct devices, `ranks` the processes
     assert j["n_gpus"] == 1 and j["ranks"] == 2 and j["devices_distinct"] == 1 and "n_gpus_note" in j
     assert j["config"]["global_chains"] == 8192
@@ -103,7 +135,8 @@ def test_bench_c4_tiny():
     r = _run(["--config", "c4", "--chains", "1024", "--dim", "512", "--leapfrogs", "5", "--steps", "24",
               "--warmup", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    assert _json_line(r.stdout)["roofline"]["bound"] == "hbm"
+    j = _full(r)
     assert "window_adaptation" in j["metric"] and j["config"]["workload"].startswith("C4")
     assert j["value"] > 0 and j["roofline"]["algorithmic_bytes_per_launch"] == 24.0 * 512 * 1024
 
@@ -112,7 +145,8 @@ def test_bench_c4_tiny():
 def test_bench_c3_tiny():
     r = _run(["--config", "c3", "--chains", "512", "--dim", "64", "--steps", "6", "--warmup", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    assert _json_line(r.stdout)["config"]["workload"].startswith("C3: NUTS")
+    j = _full(r)
     assert j["config"]["workload"].startswith("C3: NUTS") and j["value"] > 0 and j["steps"] == 6
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["algorithmic_bytes_per_chain_leapfrog"] == 52.0 * 64
     assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-12
@@ -123,7 +157,8 @@ def test_bench_c3_tiny():
 def test_bench_c5_tiny():
     r = _run(["--config", "c5", "--chains", "1024", "--dim", "128", "--steps", "3", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    assert _json_line(r.stdout)["roofline"]["bound"] == "mfma"
+    j = _full(r)
     assert j["config"]["workload"].startswith("C5: dense") and j["value"] > 0
     roof = j["roofline"]
     assert roof["bound"] == "mfma" and roof["algorithmic_flops_per_launch"] == 2.0 * 1024 * 128 * 128
@@ -137,7 +172,14 @@ def test_bench_default_line_carries_c3_c5_c4_sub_objects():
     r = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-torch-callable", "--no-ess-nonresonant"],
              timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _json_line(r.stdout)
+    c = _json_line(r.stdout)  # the compact line carries every config's value, roofline fraction and parity counts
+    for k, start in (("c3_nuts", "C3: NUTS"), ("c5_dense", "C5: dense"), ("c4_shard", "C4: window_adaptation")):
+        assert c[k]["value"] > 0 and c[k]["ms_per_step"] > 0 and c[k]["workload"].startswith(start), c[k]
+        assert c[k]["roofline"]["frac"] > 0 and c[k]["roofline"]["bound"] in ("hbm", "mfma")
+    assert c["c5_dense"]["parity"]["accept_mismatches"] == 0 and c["c5_dense"]["parity"]["chains_checked"] > 0
+    assert c["c3_nuts"]["parity"]["tree_size_mismatches"] == 0 and c["c3_nuts"]["parity"]["chains_checked"] > 0
+    assert c["parity"]["accept_mismatches"] == 0
+    j = _full(r)
     for k, start in (("c3_nuts", "C3: NUTS"), ("c5_dense", "C5: dense"), ("c4_shard", "C4: window_adaptation")):
         assert k in j, k
         assert j[k].get("value"), j[k]

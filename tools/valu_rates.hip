@@ -28,7 +28,7 @@ constexpr int ITERS = 2000;
                  INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)                      \
                  INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)                      \
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) \
-                 : "v"(b), "v"(c));                                                           \
+                 : "v"(b), "v"(c) : "vcc", "s10", "s11");                                       \
   }
 
 #define K32(NAME, INS)                                                                                   \
@@ -91,6 +91,15 @@ constexpr int ITERS = 2000;
 #define I_XAD(i) "v_xad_u32 %" #i ", %" #i ", %8, %9\n"
 #define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
 #define I_CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define I_CNDMASK64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define I_CMPVCC(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n"
+#define I_CMPSG(i) "v_cmp_lt_f32_e64 s[10:11], %" #i ", %8\n"
+#define I_CMPCND(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define I_FMAAK(i) "v_fmaak_f32 %" #i ", %" #i ", %8, 0x3fc00000\n"
+#define I_LSHR(i) "v_lshrrev_b32 %" #i ", 9, %" #i "\n"
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define I_MAX32(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define I_MOV(i) "v_mov_b32 %" #i ", %8\n"
 #define I_FMA32(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define I_FMAC32(i) "v_fmac_f32 %" #i ", %8, %9\n"
 #define I_MUL32(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
@@ -115,6 +124,15 @@ K32(k_alignbit, I_ALIGN)
 K32(k_xad_u32, I_XAD)
 K32(k_add3_u32, I_ADD3)
 K32(k_cndmask, I_CNDMASK)
+K32(k_cndmask64, I_CNDMASK64)
+KF32(k_cmp_vcc, I_CMPVCC)
+KF32(k_cmp_sgpr, I_CMPSG)
+KF32(k_cmp_cnd_pair, I_CMPCND)
+KF32(k_fmaak_f32, I_FMAAK)
+K32(k_lshrrev, I_LSHR)
+K32(k_and_b32, I_AND)
+KF32(k_max_f32, I_MAX32)
+K32(k_mov_b32, I_MOV)
 KF32(k_fma_f32, I_FMA32)
 KF32(k_fmac_f32, I_FMAC32)
 KF32(k_mul_f32, I_MUL32)
@@ -201,6 +219,10 @@ int main() {
     kern_t k;
   } ks[] = {{"v_add_u32", k_add_u32},       {"v_xor_b32", k_xor_b32},       {"v_alignbit_b32", k_alignbit},
             {"v_xad_u32", k_xad_u32},       {"v_add3_u32", k_add3_u32},     {"v_cndmask_b32", k_cndmask},
+            {"v_cndmask_b32_e64(sgpr pair)", k_cndmask64}, {"v_cmp_lt_f32->vcc", k_cmp_vcc},
+            {"v_cmp_lt_f32_e64->sgpr", k_cmp_sgpr}, {"v_cmp+v_cndmask(2 insts)", k_cmp_cnd_pair},
+            {"v_fmaak_f32", k_fmaak_f32}, {"v_lshrrev_b32", k_lshrrev}, {"v_and_b32", k_and_b32},
+            {"v_max_f32", k_max_f32}, {"v_mov_b32", k_mov_b32},
             {"v_fma_f32", k_fma_f32},       {"v_fmac_f32", k_fmac_f32},     {"v_mul_f32", k_mul_f32},
             {"v_rcp_f32", k_rcp_f32},       {"v_sqrt_f32", k_sqrt_f32},     {"v_log_f32", k_log_f32},
             {"v_exp_f32", k_exp_f32},       {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32},
