@@ -23,6 +23,7 @@ SIGNATURES = {
     "bjx_rng_normal": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, _f32p],
     "bjx_rng_uniform": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, _f32p],
     "bjx_rng_key_probe": [c_void_p, c_uint32, c_uint32, c_int64, _f32p, _f32p, c_int64, c_void_p],
+    "bjx_log1p_device_check": [c_void_p, c_uint32, c_void_p],
     "bjx_hmc_momentum_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p,
                               c_int64, _f32p, _f32p],
     "bjx_hmc_momentum_kick_diag": [c_void_p, c_uint32, c_uint32, c_int64, c_int64, c_int64, c_int64, _f32p,

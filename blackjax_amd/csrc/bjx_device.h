@@ -74,49 +74,57 @@ __device__ __forceinline__ float key_uniform(Key key) {
   return fmaxf(0.0f, unit_float(key_bits32(key, 0)));
 }
 
-// XLA ErfInv32 (Giles' single-precision polynomial); log1p evaluated in fp64 and rounded once --
-// through the fast correctly-rounded path of bjx_log1p.h, the library log1p only when that path
-// cannot decide the rounding (2^-21 of the inputs; results identical by construction).
+// XLA ErfInv32 (Giles' single-precision polynomial); log1p evaluated in fp64 and rounded once -- through the
+// correctly-rounded table-driven path of bjx_log1p.h (no library call: the few hundred fp32 inputs whose rounding
+// its fast path cannot decide are looked up).
+// OPEN: the caller guarantees |x| < 1 (normal_from_bits: |u| <= 1 - 2^-24), so the |x| == 1 -> +-inf patch is dropped.
+// The central polynomial (w < 5: 99.66 % of uniform draws) is evaluated for every lane; the tail polynomial sits
+// behind a branch that a wave without tail lanes skips (4 of 5 waves at one element per lane).
+template <bool OPEN = false>
 __device__ __forceinline__ float erfinv_f32(float x) {
-  float t = -(x * x);
-  float w;
-  if (!bjx_neg_log1p_fast(t, &w)) w = -(float)log1p((double)t);
-  const bool lt = w < 5.0f;
+  const float t = -(x * x);
+  float w = bjx_neg_log1p(t);
   float p;
-  if (lt) {
-    w = w - 2.5f;
+  {
+    const float wc = w - 2.5f;
     p = 2.81022636e-08f;
-    p = fmaf(p, w, 3.43273939e-07f);
-    p = fmaf(p, w, -3.5233877e-06f);
-    p = fmaf(p, w, -4.39150654e-06f);
-    p = fmaf(p, w, 0.00021858087f);
-    p = fmaf(p, w, -0.00125372503f);
-    p = fmaf(p, w, -0.00417768164f);
-    p = fmaf(p, w, 0.246640727f);
-    p = fmaf(p, w, 1.50140941f);
-  } else {
-    w = sqrtf(w) - 3.0f;
-    p = -0.000200214257f;
-    p = fmaf(p, w, 0.000100950558f);
-    p = fmaf(p, w, 0.00134934322f);
-    p = fmaf(p, w, -0.00367342844f);
-    p = fmaf(p, w, 0.00573950773f);
-    p = fmaf(p, w, -0.0076224613f);
-    p = fmaf(p, w, 0.00943887047f);
-    p = fmaf(p, w, 1.00167406f);
-    p = fmaf(p, w, 2.83297682f);
+    p = fmaf(p, wc, 3.43273939e-07f);
+    p = fmaf(p, wc, -3.5233877e-06f);
+    p = fmaf(p, wc, -4.39150654e-06f);
+    p = fmaf(p, wc, 0.00021858087f);
+    p = fmaf(p, wc, -0.00125372503f);
+    p = fmaf(p, wc, -0.00417768164f);
+    p = fmaf(p, wc, 0.246640727f);
+    p = fmaf(p, wc, 1.50140941f);
+  }
+  if (__builtin_expect(!(w < 5.0f), 0)) {
+    const float wt = sqrtf(w) - 3.0f;
+    float pt = -0.000200214257f;
+    pt = fmaf(pt, wt, 0.000100950558f);
+    pt = fmaf(pt, wt, 0.00134934322f);
+    pt = fmaf(pt, wt, -0.00367342844f);
+    pt = fmaf(pt, wt, 0.00573950773f);
+    pt = fmaf(pt, wt, -0.0076224613f);
+    pt = fmaf(pt, wt, 0.00943887047f);
+    pt = fmaf(pt, wt, 1.00167406f);
+    pt = fmaf(pt, wt, 2.83297682f);
+    p = pt;
   }
   float r = p * x;
-  if (fabsf(x) == 1.0f) r = x * __builtin_inff();
+  if constexpr (!OPEN) {
+    if (fabsf(x) == 1.0f) r = x * __builtin_inff();
+  }
   return r;
 }
 
 // jax.random.normal element from its 32 random bits:
 //   u = max(lo, f*(1-lo)+lo), lo = nextafter(-1,0) ; (1-lo) rounds to 2.0f ; z = sqrt(2)*erfinv(u)
+// The max is the identity here (f >= 0 and rounding is monotone: fma(f, 2, lo) >= lo) and u <= 1 - 3 * 2^-24, so
+// neither it nor erf_inv's |x| == 1 patch is evaluated; same values.
 __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
   const float lo = -0.99999994f;
-  float u = fmaxf(lo, fmaf(unit_float(bits), 2.0f, lo));
-  return 1.41421354f * erfinv_f32(u);
+  const float u = fmaf(unit_float(bits), 2.0f, lo);
+  return 1.41421354f * erfinv_f32<true>(u);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -54,6 +54,35 @@ __global__ void __launch_bounds__(kBlock) k_rng_key_probe(Key key, int64_t D, fl
   if (i == 0 && u) u[0] = key_uniform(key);
 }
 
+// Exhaustive device check of bjx_log1p.h: every fp32 t in (-1, 0] (bit patterns 0x80000000 .. 0xBF7FFFFF, and +0.0)
+// through the product's bjx_neg_log1p against the device library's fp64 log1p rounded once.  counts[0] = inputs
+// checked, [1] = results that differ, [2] = inputs the fast path deferred to the table, [3] = first differing bits.
+__global__ void __launch_bounds__(kBlock) k_log1p_check(uint32_t first, uint64_t n, uint32_t stride,
+                                                         unsigned long long* __restrict__ counts) {
+  unsigned long long bad = 0, deferred = 0, seen = 0;
+  uint32_t first_bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t b = (uint64_t)first + i * stride;
+    const uint32_t bits = b < 0xBF800000ull ? (uint32_t)b : 0u;  // past the last negative input: +0.0
+    const float t = __uint_as_float(bits);
+    float wf;
+    if (!bjx_neg_log1p_fast(t, &wf)) ++deferred;
+    const float got = bjx_neg_log1p(t);
+    const float want = (float)(-log1p((double)t));
+    ++seen;
+    if (!(got == want)) {
+      if (!bad) first_bad = bits;
+      ++bad;
+    }
+  }
+  atomicAdd(&counts[0], seen);
+  if (bad) {
+    atomicAdd(&counts[1], bad);
+    atomicCAS(&counts[3], 0ull, (unsigned long long)first_bad);
+  }
+  if (deferred) atomicAdd(&counts[2], deferred);
+}
+
 // ------------------------------------------------------------------------------ momentum draw
 // p0 = (1/sqrt(imm)) * normal(km, (D,)) ; ke0 = 0.5 * sum (imm*p0)*p0   (fp64 accumulate)
 // KICK: the opening half kick and the drift of the trajectory's first leapfrog in the same launch (the
@@ -709,6 +738,19 @@ int bjx_rng_key_probe(void* stream, uint32_t key0, uint32_t key1, int64_t D, flo
   hipLaunchKernelGGL(k_rng_key_probe, dim3((unsigned)((n > 0 ? n : 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
                      (hipStream_t)stream, Key{key0, key1}, D, z_out, u_out, n_children, children_out);
   return bjx_check_launch("bjx_rng_key_probe");
+}
+
+int bjx_log1p_device_check(void* stream, uint32_t stride, unsigned long long* counts_out) {
+  BJX_CHECK_ARG(stride >= 1 && counts_out, "bjx_log1p_device_check: bad arguments");
+  const uint32_t first = 0x80000000u;
+  const uint64_t span = 0xBF800000ull - first;       // negative inputs in (-1, -0.0]
+  const uint64_t n = (span + stride - 1) / stride + 1;  // + one iteration for +0.0
+  if (hipMemsetAsync(counts_out, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) {
+    bjx_set_error("%s", "bjx_log1p_device_check: hipMemsetAsync failed");
+    return 2;
+  }
+  hipLaunchKernelGGL(k_log1p_check, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, first, n, stride, counts_out);
+  return bjx_check_launch("bjx_log1p_device_check");
 }
 
 int bjx_hmc_momentum_diag(void* stream, uint32_t key0, uint32_t key1, int64_t chain_offset,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BJX_ABI_VERSION 6 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
+#define BJX_ABI_VERSION 7 /* 2: bjx_nuts_t gained int_kick / int_drift (round 3); 3: bjx_nuts_async_t gained int_stages /
                              int_mid_kick / int_mid_drift, bjx_rng_key_probe added (round 4); 4: bjx_nuts_async_t gained
                              gemm_pc .. gemm_cap (round 4); 5 (round 5): same entry points and layouts -- bjx_nuts_async_tick now
                              has ONE kernel per shape and reads no environment switch (an engine-resident target is ticked
@@ -45,7 +45,8 @@ extern "C" {
                              only used in GEMM mode), multi-stage integrators tick free for rows of up to 1 024 floats, and the
                              shared-dense entry points REFUSE whole 128 x 128 tiles on buffers that are not 16-byte aligned
                              instead of reading imm transposed; 6 (round 5): bjx_nuts_spec_t and bjx_nuts_spec_enter / _integrate /
-                             _book added (two-stream speculative tail of a free-running run), nothing else changed */
+                             _book added (two-stream speculative tail of a free-running run), nothing else changed; 7 (round 6):
+                             bjx_log1p_device_check added, nothing else changed */
 
 const char* bjx_last_error(void);
 int bjx_abi_version(void);
@@ -71,6 +72,13 @@ int bjx_rng_uniform(void* stream, uint32_t key0, uint32_t key1, int64_t chain_of
  * blackjax/util.py:90, mcmc/proposal.py:226, mcmc/hmc.py:299. */
 int bjx_rng_key_probe(void* stream, uint32_t key0, uint32_t key1, int64_t D, float* z_out, float* u_out,
                       int64_t n_children, uint32_t* children_out);
+
+/* Device self-check of the correctly-rounded fp32 -log1p inside jax.random.normal's erf_inv (csrc/bjx_log1p.h): every
+ * stride-th fp32 t in (-1, 0] through the product's function against the device library's fp64 log1p rounded once.
+ * counts_out: device uint64[4] = {inputs checked, results that differ, inputs resolved by the slow table, bit
+ * pattern of the first differing input}.  stride 1 = exhaustive (1 065 353 217 inputs, ~0.1 s).
+ * Checks the arithmetic behind: jax.random.normal as used at blackjax/util.py:88-91. */
+int bjx_log1p_device_check(void* stream, uint32_t stride, unsigned long long* counts_out);
 
 /* Momentum draw for a diagonal metric + initial kinetic energy.
  *   k_i = split(key, .)[chain_offset+i]; km = split(k_i, 2)[0]

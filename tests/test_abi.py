@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert s in syms, f"{s} bound in _lib.py but not declared in include/*.h"
     assert lib.bjx_pool_workspace_bytes(0, 8) == 0
     assert lib.bjx_pool_workspace_bytes(65536, 1024) == 512 * 4 * 1024 * 8  # 512 slabs x K=4 x D doubles
-    assert lib.bjx_abi_version() == 6  # 6 (round 5): + the speculative-tail entry points (bjx_nuts_spec_*)
+    assert lib.bjx_abi_version() == 7  # 7 (round 6): + bjx_log1p_device_check
 
 
 def test_error_reporting_without_gpu():

@@ -49,6 +49,20 @@ def test_rng_normal_uniform(dev, N, D):
     np.testing.assert_allclose(zz, z_ref, rtol=2e-7, atol=0)
 
 
+def test_device_log1p_exhaustive(dev):
+    """csrc/bjx_log1p.h on the DEVICE, every fp32 t in (-1, 0]: the product's table-driven correctly-rounded -log1p
+    equals the device library's fp64 log1p rounded once for all 1 065 353 217 inputs (the host run of the same source,
+    tests/test_log1p_host.py, pins it on the C library's); the inputs its fast path defers are resolved by the
+    generated slow table.  Arithmetic behind jax.random.normal (blackjax/util.py:88-91)."""
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    _lib.call("bjx_log1p_device_check", _lib.current_stream(), 1, counts.data_ptr())
+    torch.cuda.synchronize()
+    checked, bad, deferred, first_bad = (int(v) for v in counts.tolist())
+    assert checked == 1065353217
+    assert bad == 0, f"{bad} inputs differ, first t bits 0x{first_bad:08x}"
+    assert 0 < deferred < 2000
+
+
 def test_device_rng_matches_jax_docs_values(dev):
     """Row a34: the DEVICE threefry / uniform / erf_inv code (bjx_rng_key_probe: key used as is) against
     the six jax.random values printed in JAX's own documentation (tests/golden/reference_kats.json
