@@ -64,6 +64,7 @@ def test_logdensity_evaluations_per_transition(dev):
     into a HIP graph, so there are no warm-up evaluations either)."""
     calls = {"n": 0}
 
+    @bjx.no_trace  # eager autograd on every call (the default for a plain function is tested below)
     def fn(q):
         calls["n"] += 1
         return -0.5 * (q * q).sum(-1)
@@ -86,3 +87,22 @@ def test_logdensity_evaluations_per_transition(dev):
         for k in bjx.random.split(bjx.random.key(2), 3):
             state, _ = alg.step(k, state)
         assert calls["n"] == 1 + 3 * per_step, (per_step, calls["n"])
+
+
+def test_a_plain_function_is_evaluated_once_and_traced_once(dev):
+    """The reference's tests/test_compilation.py:19-100 asks that the log-density be TRACED at most twice per kernel:
+    here a plain PyTorch function is evaluated once (init, under autograd), traced once (torch.fx -> generated
+    value-and-gradient kernel, checked against that evaluation) and its Python code never runs again."""
+    calls = {"n": 0}
+
+    def fn(q):
+        calls["n"] += 1
+        return -0.5 * (q * q).sum(-1)
+
+    q0 = torch.randn(64, 8, device=dev)
+    alg = bjx.hmc(fn, 0.1, torch.ones(8, device=dev), 7)
+    state = alg.init(q0)
+    assert calls["n"] == 2
+    for k in bjx.random.split(bjx.random.key(2), 3):
+        state, info = alg.step(k, state)
+    assert calls["n"] == 2 and bool(info.is_accepted.any())
