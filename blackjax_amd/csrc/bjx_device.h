@@ -127,6 +127,59 @@ __device__ __forceinline__ float normal_from_bits(uint32_t bits) {
   return 1.41421354f * erfinv_f32<true>(u);
 }
 
+// Four normals at once (the 16-byte piece a lane owns in the row kernels): the four threefry blocks, argument
+// reductions and table fetches of bjx_log1p.h are independent straight-line code the scheduler interleaves, and the
+// two rare paths -- an input the Ziv test defers, a tail-polynomial lane -- sit behind ONE branch each per piece
+// instead of one per element.  Element for element the arithmetic of normal_from_bits: same values.
+__device__ __forceinline__ void normal4_from_bits(const uint32_t (&bits)[4], float (&z)[4]) {
+  const float lo = -0.99999994f;
+  float x[4], w[4];
+  bool defer = false, tail = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[e] = fmaf(unit_float(bits[e]), 2.0f, lo);
+    defer |= !bjx_neg_log1p_fast(-(x[e] * x[e]), &w[e]);
+  }
+  if (__builtin_expect(defer, 0)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = bjx_neg_log1p(-(x[e] * x[e]));
+  }
+  float p[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float wc = w[e] - 2.5f;
+    float q = 2.81022636e-08f;
+    q = fmaf(q, wc, 3.43273939e-07f);
+    q = fmaf(q, wc, -3.5233877e-06f);
+    q = fmaf(q, wc, -4.39150654e-06f);
+    q = fmaf(q, wc, 0.00021858087f);
+    q = fmaf(q, wc, -0.00125372503f);
+    q = fmaf(q, wc, -0.00417768164f);
+    q = fmaf(q, wc, 0.246640727f);
+    p[e] = fmaf(q, wc, 1.50140941f);
+    tail |= !(w[e] < 5.0f);
+  }
+  if (__builtin_expect(tail, 0)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!(w[e] < 5.0f)) {
+        const float wt = sqrtf(w[e]) - 3.0f;
+        float q = -0.000200214257f;
+        q = fmaf(q, wt, 0.000100950558f);
+        q = fmaf(q, wt, 0.00134934322f);
+        q = fmaf(q, wt, -0.00367342844f);
+        q = fmaf(q, wt, 0.00573950773f);
+        q = fmaf(q, wt, -0.0076224613f);
+        q = fmaf(q, wt, 0.00943887047f);
+        q = fmaf(q, wt, 1.00167406f);
+        p[e] = fmaf(q, wt, 2.83297682f);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z[e] = 1.41421354f * (p[e] * x[e]);
+}
+
 // ---------------------------------------------------------------------------------------
 // wave64 reductions (all lanes receive the result)
 //

@@ -83,6 +83,9 @@ __global__ void __launch_bounds__(kBlock) k_log1p_check(uint32_t first, uint64_t
   if (deferred) atomicAdd(&counts[2], deferred);
 }
 
+#ifndef BJX_NORMAL4
+#define BJX_NORMAL4 1
+#endif
 // ------------------------------------------------------------------------------ momentum draw
 // p0 = (1/sqrt(imm)) * normal(km, (D,)) ; ke0 = 0.5 * sum (imm*p0)*p0   (fp64 accumulate)
 // KICK: the opening half kick and the drift of the trajectory's first leapfrog in the same launch (the
@@ -124,11 +127,20 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
       } else {
         m[0] = im[j];
       }
+      float zs[VEC];
+      if constexpr (VEC == 4 && BJX_NORMAL4) {
+        uint32_t bits[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bits[e] = key_bits32(km, (uint64_t)(j + e));
+        normal4_from_bits(bits, zs);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) zs[e] = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
+      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float z = normal_from_bits(key_bits32(km, (uint64_t)(j + e)));
         const float ms = msv ? msv[e] : 1.0f / sqrtf(m[e]);  // metrics.py:704-709 (two roundings)
-        pv[e] = ms * z;
+        pv[e] = ms * zs[e];
         const float v = m[e] * pv[e];
         acc += (double)v * (double)pv[e];
       }

@@ -118,3 +118,117 @@ def test_pytree_positions_through_ravel(dev):
         assert torch.equal(ia.num_integration_steps, ib.num_integration_steps)
         assert torch.allclose(sa.position, sb.position, atol=1e-6)
     assert unravel(sa.position)["loc"].shape == (N, 5)
+
+
+# ---------------------------------------------------------------------------------------------- re-entrancy
+def _steps(alg, st, keys, stream=None):
+    """`len(keys)` steps; returns the states / infos as CPU tensors (position, logdensity, the per-chain info scalars)."""
+    import contextlib
+
+    out = []
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        for k in keys:
+            st, info = alg.step(k, st)
+            out.append((st.position.clone(), st.logdensity.clone(), info.acceptance_rate.clone(),
+                        info.num_integration_steps.clone() if torch.is_tensor(info.num_integration_steps) else None))
+    return st, out
+
+
+def _same_runs(a, b):
+    assert len(a) == len(b)
+    for (pa, la, aa, na), (pb, lb, ab, nb) in zip(a, b):
+        assert torch.equal(pa, pb) and torch.equal(la, lb) and torch.equal(aa, ab)
+        assert (na is None and nb is None) or torch.equal(na, nb)
+
+
+@pytest.mark.timeout(600)
+def test_algorithm_objects_interleaved_on_streams_and_threads(dev, monkeypatch):
+    """The purity contract of base.py:24-85 -- `step(rng_key, state)` is a function of its arguments -- against the
+    state the drivers keep behind it (persistent NUTS workspaces keyed per algorithm object, shape and stream; recorded
+    graphs; caches; BJX_* switches read at call time): two `nuts` objects and one `hmc` object stepped ALTERNATELY on two
+    streams, then concurrently from two Python threads, then with the environment switches changed in mid-run, give
+    bit for bit the results of each object stepped alone."""
+    import threading
+
+    D = 32
+    imm = torch.ones(D, device=dev)
+    funnel = bjx.targets.NealFunnel()
+    gauss = bjx.targets.DiagGaussian(torch.linspace(0.5, 2.0, D, device=dev))
+    gen = torch.Generator(device=dev).manual_seed(11)
+    q_a = 0.3 * torch.randn(96, D, device=dev, generator=gen)
+    q_b = 0.3 * torch.randn(160, D, device=dev, generator=gen)
+    q_c = torch.randn(200, D, device=dev, generator=gen)
+    make = {"a": lambda: bjx.nuts(funnel, 0.2, imm, max_num_doublings=6),
+            "b": lambda: bjx.nuts(funnel, 0.15, imm, max_num_doublings=5),
+            "c": lambda: bjx.hmc(gauss, 0.2, imm, 5)}
+    q0 = {"a": q_a, "b": q_b, "c": q_c}
+    keys = list(bjx.random.split(bjx.random.key(3), 5))
+    # each object alone, on the default stream
+    alone = {}
+    for n in "abc":
+        alg = make[n]()
+        alone[n] = _steps(alg, alg.init(q0[n]), keys)[1]
+    torch.cuda.synchronize()
+
+    # (1) alternately, on two streams (a and c share one)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s1.wait_stream(torch.cuda.current_stream(dev))
+    s2.wait_stream(torch.cuda.current_stream(dev))
+    algs = {n: make[n]() for n in "abc"}
+    stream_of = {"a": s1, "b": s2, "c": s1}
+    st, got = {}, {n: [] for n in "abc"}
+    for n in "abc":
+        with torch.cuda.stream(stream_of[n]):
+            st[n] = algs[n].init(q0[n])
+    for k in keys:
+        for n in "abc":
+            st[n], o = _steps(algs[n], st[n], [k], stream_of[n])
+            got[n] += o
+    torch.cuda.synchronize()
+    for n in "abc":
+        _same_runs(got[n], alone[n])
+
+    # (2) concurrently from two Python threads, each with its own stream and its own objects
+    res, errs = {}, []
+
+    def worker(names, stream):
+        try:
+            for n in names:
+                alg = make[n]()
+                with torch.cuda.stream(stream):
+                    s0 = alg.init(q0[n])
+                res[n] = _steps(alg, s0, keys, stream)[1]
+            stream.synchronize()
+        except BaseException as e:  # surfaced in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(("a", "c"), s1)), threading.Thread(target=worker, args=(("b",), s2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a worker thread did not finish"
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for n in "abc":
+        _same_runs(res[n], alone[n])
+
+    # (3) the BJX_* switches the drivers read at call time, changed in mid-run: scheduling only, never results
+    algs = {n: make[n]() for n in "abc"}
+    st = {n: algs[n].init(q0[n]) for n in "abc"}
+    got = {n: [] for n in "abc"}
+    settings = [{}, {"BJX_NUTS_SPEC_ROWS": "16", "BJX_CHAIN_BLOCK": "64"}, {"BJX_NUTS_SYNC_EVERY": "2", "BJX_NUTS_TAIL_ROWS": "64"},
+                {"BJX_NUTS_STEP_DRIVER": "lockstep"}, {}]
+    names = ("BJX_NUTS_SPEC_ROWS", "BJX_CHAIN_BLOCK", "BJX_NUTS_SYNC_EVERY", "BJX_NUTS_TAIL_ROWS", "BJX_NUTS_STEP_DRIVER")
+    for k, env in zip(keys, settings):
+        for name in names:
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        for n in "abc":
+            st[n], o = _steps(algs[n], st[n], [k])
+            got[n] += o
+    torch.cuda.synchronize()
+    for n in "abc":
+        _same_runs(got[n], alone[n])

@@ -426,10 +426,6 @@ def test_hmc_default_driver_graph_and_fallback(dev):
         assert float(lp.sum().item()) < float("inf")  # host sync: cannot be recorded
         return lp
 
-    imm = torch.ones(D, device=dev)
-    ref = bjx.hmc(plain, 0.2, imm, L, use_graph=False)
-    st = ref.init(q0)
-    keys = prng.split(prng.key(6), 3)
     def undeclared(q):
         return -0.5 * (q * q * iv).sum(-1)
 
@@ -437,6 +433,11 @@ def test_hmc_default_driver_graph_and_fallback(dev):
     # host): keep them all on eager autograd (the traced form accumulates logp in fp64: other last bits)
     for f in (plain, syncing, undeclared):
         bjx.no_trace(f)
+    imm = torch.ones(D, device=dev)
+    ref = bjx.hmc(plain, 0.2, imm, L, use_graph=False)
+    st = ref.init(q0)
+    keys = prng.split(prng.key(6), 3)
+
     for fn in (bjx.capturable(plain), bjx.capturable(syncing), undeclared):
         alg = bjx.hmc(fn, 0.2, imm, L)  # default driver
         s_r, s_a = st, st

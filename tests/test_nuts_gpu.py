@@ -169,11 +169,15 @@ def test_nuts_default_driver_falls_back_for_a_syncing_callable(dev):
         calls["n"] += int(lp.numel() > 0 and float(lp.sum().item()) == float("inf"))  # host sync
         return lp
 
+    def undeclared(q):
+        return -0.5 * (q * q * iv).sum(-1)
+
+    # compared bit for bit, and `syncing` cannot be traced into a generated kernel: all three stay on eager autograd
+    for f in (plain, syncing, undeclared):
+        bjx.no_trace(f)
     ref = bjx.nuts(plain, 0.3, torch.ones(D, device=dev), max_num_doublings=5, use_graph=False)
     st = ref.init(q0)
     keys = prng.split(prng.key(4), 3)
-    def undeclared(q):
-        return -0.5 * (q * q * iv).sum(-1)
 
     for fn in (bjx.capturable(plain), bjx.capturable(syncing), undeclared):
         alg = bjx.nuts(fn, 0.3, torch.ones(D, device=dev), max_num_doublings=5)  # default driver

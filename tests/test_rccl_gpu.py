@@ -93,7 +93,9 @@ def test_bench_control_flow_over_rccl_with_one_rank():
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-600:]
     j = _last_json(r.stdout)
     assert j["backend"] == "nccl" and j["n_gpus"] == 1 and j["ranks"] == 1 and j["devices_distinct"] == 1
-    assert j["value"] > 0 and j["final_draws_gathered"] == [256, 1024]
+    assert j["value"] > 0
+    full = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py FULL RECORD: ")]
+    assert len(full) == 1 and json.loads(full[0][len("bench.py FULL RECORD: "):])["final_draws_gathered"] == [256, 1024]
 
 
 WORKER_WARMUPS = textwrap.dedent("""
