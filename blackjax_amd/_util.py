@@ -1,12 +1,32 @@
 """Host-side plumbing shared by the kernels' Python drivers."""
 from __future__ import annotations
 
+import threading
 import weakref
 from typing import Callable
 
 import torch
 
 _VG_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_CAPTURE_LOCK = threading.RLock()
+
+
+def record_graph(graph, **kw):
+    """``torch.cuda.graph(graph, capture_error_mode="thread_local")`` under a process-wide lock.  Two stream captures
+    under way at once -- two Python threads stepping two algorithm objects, each recording its inner loop -- crash the
+    process on ROCm 7 (SIGSEGV / abort inside the capture, measured round 6: tools/scratch/thread_probe.py), so
+    recordings are serialised; replays, plain launches and allocations of other threads are not."""
+    import contextlib
+
+    lock = _CAPTURE_LOCK
+
+    @contextlib.contextmanager
+    def ctx():
+        with lock:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):  # other threads (the RCCL watchdog) may poll events
+                yield
+
+    return ctx()
 
 
 def value_and_grad(logdensity_fn: Callable) -> Callable:

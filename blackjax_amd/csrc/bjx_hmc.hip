@@ -127,6 +127,20 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
       } else {
         m[0] = im[j];
       }
+      // KICK: the leapfrog's operands are requested BEFORE the ~2 000 cycles of RNG arithmetic of this piece, so their
+      // HBM round trip runs under it (round 6: requested after it, the kernel took the sum of its arithmetic and its
+      // 20 bytes per element instead of the larger of the two)
+      [[maybe_unused]] float gg[VEC], qq[VEC];
+      if constexpr (KICK) {
+        if constexpr (VEC == 4) {
+          const F4 a = ld4(g0 + r * D + j), b = ld4(q0 + r * D + j);
+          gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w;
+          qq[0] = b.x; qq[1] = b.y; qq[2] = b.z; qq[3] = b.w;
+        } else {
+          gg[0] = g0[r * D + j];
+          qq[0] = q0[r * D + j];
+        }
+      }
       float zs[VEC];
       if constexpr (VEC == 4 && BJX_NORMAL4) {
         uint32_t bits[4];
@@ -147,15 +161,7 @@ k_momentum_diag(Key key, int64_t off, int64_t fold, int64_t N, int64_t D, const 
       if constexpr (VEC == 4) st4(pr + j, F4{pv[0], pv[1], pv[2], pv[3]});
       else pr[j] = pv[0];
       if constexpr (KICK) {
-        float gg[VEC], qq[VEC], ph[VEC], qn[VEC];
-        if constexpr (VEC == 4) {
-          const F4 a = ld4(g0 + r * D + j), b = ld4(q0 + r * D + j);
-          gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w;
-          qq[0] = b.x; qq[1] = b.y; qq[2] = b.z; qq[3] = b.w;
-        } else {
-          gg[0] = g0[r * D + j];
-          qq[0] = q0[r * D + j];
-        }
+        float ph[VEC], qn[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           ph[e] = fmaf(h, gg[e], pv[e]);

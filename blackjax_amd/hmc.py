@@ -17,7 +17,7 @@ from typing import Callable, NamedTuple
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import (check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+from ._util import (record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
                     warn_eager_driver)
 from .base import SamplingAlgorithm
 from .random import key_spec
@@ -274,7 +274,7 @@ class _GraphedTrajectory:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may poll events
+        with record_graph(self.graph):
             self.logp, self.g = self._body()
 
     def _body(self):

@@ -30,7 +30,7 @@ from typing import Callable, NamedTuple, Optional
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import (check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+from ._util import (record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
                     warn_eager_driver)
 from .base import SamplingAlgorithm
 from .hmc import HMCState, IntegratorState, init
@@ -183,7 +183,7 @@ class _GraphWorkspace:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread may poll events
+            with record_graph(graph):
                 keep = self._chunk_body(k, n_cap)
             self.ctl.copy_(saved)
             g = self.graphs[(k, n_cap)] = (graph, keep)
@@ -892,7 +892,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 lp_s, g_s = self.logp_f.clone(), self.gf.clone()
                 try:
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                    with record_graph(cg):
                         lp_e, g_e = self.chunk(n_ticks, lp_s, g_s)
                         if lp_e is not lp_s:
                             lp_s.copy_(lp_e)
@@ -1026,7 +1026,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             if can_record:
                 try:
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                    with record_graph(cg):
                         self._body(k, n)
                     self.graph[(k, self.view)] = (cg, n)
                 except Exception:
@@ -1125,7 +1125,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             if can_record:
                 try:
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                    with record_graph(cg):
                         self._seq_a(self.SEQ)
                     self.graph = cg
                 except Exception:
