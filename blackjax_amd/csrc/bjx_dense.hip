@@ -50,7 +50,7 @@ struct GemmArgs {
   // otherwise its momentum and position are copied through untouched.  NULL = every row advances.
   const int32_t* n_steps = nullptr;
   int32_t step_idx = 0;
-#if defined(BJX_DENSE_PROBE) || defined(BJX_DENSE_PROBE2)
+#ifdef BJX_DENSE_PROBE
   // PROBE builds only (tools/dense_timeline.py): four wall-clock stamps per workgroup -- entry, first K-tile staged,
   // end of the main loop, end of the epilogue.  The shipped library has no such field.
   unsigned long long* probe = nullptr;
@@ -335,20 +335,9 @@ constexpr int LDK = BK + 4;
 // four-wave form of this tile -- 64 x 64 per wave, 172 VGPRs, two waves per SIMD, 2 % slower -- behind BJX_DENSE_TN8=0;
 // removed in round 5.)
 constexpr int kThreads8 = 512;
-#ifdef BJX_DENSE_PROBE2
-// PROBE2 builds only (tools/dense_phases.py): shader-clock stamps of waves 0 and 4 (one SIMD pair) at four points of
-// every K-tile; 256 slots per workgroup in the probe buffer.  Never compiled into the shipped library.
-#define BJX_STAMP(i_)                                                                                   \
-  do {                                                                                                  \
-    if (a.probe && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0 && (i_) < 128)             \
-      a.probe[(int64_t)blockIdx.x * 256 + (threadIdx.x >> 8) * 128 + (i_)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define BJX_STAMP(i_) do {} while (0)
-#endif
 
-template <int EPI, int KICKS, bool PP = false>
-__global__ void __launch_bounds__(kThreads8, 4) k_dense_gemm_tn8(GemmArgs a) {  // 4 waves per SIMD = two workgroups per CU
+template <int EPI, int KICKS>
+__global__ void __launch_bounds__(kThreads8) k_dense_gemm_tn8(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
   static_assert(2 * BM * LDK + 2 * BN * LDK >= 8 * 32 * 32, "epilogue staging needs 32 KiB");
   static_assert(BK == 16, "the k pairing below assumes two 8-wide halves");
@@ -383,155 +372,6 @@ __global__ void __launch_bounds__(kThreads8, 4) k_dense_gemm_tn8(GemmArgs a) {  
   }
 #endif
 
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-  const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
-  const int lm = lane & 31, lk = lane >> 5;
-  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
-  const int b_off = (wn * 32 + lm) * LDK + lk * 8;
-
-  if constexpr (PP) {
-    // PING-PONG main loop (round 6).  The eight waves of a workgroup sit two to a SIMD (waves w and w + 4), and in the
-    // loop below every wave stages, waits at the K-tile barrier and computes at the same time as its SIMD partner: the
-    // matrix pipe idles while both stage, and both queue for it while both compute (measured: ~0.65 of the pipe with
-    // one workgroup on a CU, ~0.78 with two).  Here the halves take turns: in phase A of K-tile t the waves 0-3
-    // (rows 0-63 of the tile) issue their 16 MFMAs from fragments already in registers, while the waves 4-7 read
-    // their fragments of tile t and stage ALL of tile t + 1 (global loads requested one tile period earlier, kick, LDS
-    // writes, the store of the kicked momentum); in phase B the waves 4-7 compute and the waves 0-3 read their
-    // fragments of tile t + 1.  One wave per SIMD owns the pipe at any time and its partner's memory work runs in
-    // that shadow.  Same MFMAs in the same order per accumulator: bit-identical to the loop below.
-    const bool stager = wm == 1;  // waves 4-7 stage A (p, g: the kick); waves 0-3 stage B (the matrix)
-    const int ytid = tid & 255;
-    const int s_row = ytid >> 2, s_k = (ytid & 3) * 4;  // rows s_row and s_row + 64 of the tile this wave group stages
-    // ONE pair of source pointers per role (the two roles never need each other's)
-    const float* x_src = (stager ? a.A + (row0 + s_row) * D : a.B + (col0 + s_row) * D) + s_k;
-    const float* g_src = KICKS > 0 ? a.G + (row0 + s_row) * D + s_k : nullptr;
-    float* a_out = (KICKS > 0 && a.A_out) ? a.A_out + (row0 + s_row) * D + s_k : nullptr;
-    float* lds_dst = (stager ? As0 : Bs0) + s_row * LDK + s_k;
-    float ha[2] = {0.0f, 0.0f}, hb[2] = {0.0f, 0.0f};
-    bool kick_row[2] = {true, true};
-    if (KICKS > 0 && stager) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float e = a.eps_pc ? a.eps_pc[row0 + s_row + 64 * h] : a.eps;
-        ha[h] = e * a.kick_a;
-        hb[h] = e * a.kick_b;
-        kick_row[h] = gemm_row_active(a, row0 + s_row + 64 * h);
-      }
-    }
-    // Two K-tiles of operands in flight per role, in the SAME registers for both roles (x = p rows for the stagers of
-    // A, matrix rows for the stagers of B; g only for A): a request has two tile periods (~4 us) to come back.
-    struct Regs {
-      F4 x[2], g[2];
-    };
-    Regs R0, R1;
-    auto load_tiles = [&](Regs& r, int64_t k0) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        r.x[h] = ld4(x_src + 64 * h * D + k0);
-        if constexpr (KICKS > 0) {
-          if (stager) r.g[h] = ld4(g_src + 64 * h * D + k0);
-        }
-      }
-    };
-    auto kick = [&](F4& x, const F4& g, float h) {
-      x.x = fmaf(h, g.x, x.x); x.y = fmaf(h, g.y, x.y); x.z = fmaf(h, g.z, x.z); x.w = fmaf(h, g.w, x.w);
-    };
-    auto store_tiles = [&](Regs& r, int buf, int64_t k0) {  // buf: the LDS stage of THIS role's operand
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if constexpr (KICKS > 0) {
-          if (stager && kick_row[h]) {
-            kick(r.x[h], r.g[h], ha[h]);
-            if constexpr (KICKS == 2) kick(r.x[h], r.g[h], hb[h]);
-          }
-        }
-        st4(lds_dst + buf * BM * LDK + 64 * h * LDK, r.x[h]);
-      }
-      if constexpr (KICKS > 0) {  // stores last: nothing waits for them before the next tile's staging (vmcnt order)
-        if (stager && a_out && k0 / BN == col_blk) {
-          st4(a_out + k0, r.x[0]);
-          st4(a_out + 64 * D + k0, r.x[1]);
-        }
-      }
-    };
-    static_assert(BM == BN, "one LDS stage stride for both operands");
-    float fa0[8], fa1[8], fb[8];
-    auto read_frags = [&](int buf) {
-      const float* as = As0 + buf * BM * LDK + a_off;
-      const float* bs = Bs0 + buf * BN * LDK + b_off;
-      *reinterpret_cast<F4*>(fa0) = ld4(as);
-      *reinterpret_cast<F4*>(fb) = ld4(bs);
-      *reinterpret_cast<F4*>(fa1) = ld4(as + 32 * LDK);
-      *reinterpret_cast<F4*>(fa0 + 4) = ld4(as + 4);
-      *reinterpret_cast<F4*>(fb + 4) = ld4(bs + 4);
-      *reinterpret_cast<F4*>(fa1 + 4) = ld4(as + 32 * LDK + 4);
-    };
-    auto mfma16 = [&]() {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb[u], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb[u], acc[1], 0, 0, 0);
-      }
-    };
-    // Schedule (t = K-tile; LDS stage of a tile = t & 1 for both operands):
-    //   phase A(t): waves 0-3 MFMA(t)            | waves 4-7 read their fragments of t, stage A(t + 1), request A(t + 3)
-    //   phase B(t): waves 4-7 MFMA(t)            | waves 0-3 read their fragments of t + 1, stage B(t + 2), request B(t + 4)
-    // A(t + 1) lands in the stage tile t - 1 left (last read in phase A(t - 1)); B(t + 2) in the stage tile t left (last
-    // read in phase A(t)): every write is at least one barrier behind the last read of what it replaces.
-    if (stager) {  // A(0) staged, A(1) and A(2) requested
-      load_tiles(R0, 0);
-      load_tiles(R1, BK);
-      store_tiles(R0, 0, 0);
-      if (2 < n_tiles) load_tiles(R0, 2 * BK);
-    } else {       // B(0), B(1) staged, B(2) and B(3) requested
-      load_tiles(R0, 0);
-      load_tiles(R1, BK);
-      store_tiles(R0, 0, 0);
-      store_tiles(R1, 1, BK);
-      if (2 < n_tiles) load_tiles(R0, 2 * BK);
-      if (3 < n_tiles) load_tiles(R1, 3 * BK);
-    }
-    __syncthreads();
-    if (!stager) read_frags(0);
-#ifdef BJX_DENSE_PROBE
-    if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 1] = wall_clock64();
-#endif
-    auto pp_tile = [&](int64_t t, Regs& ra, Regs& rb) {  // ra: holds A(t + 1); rb: holds B(t + 2)
-      const int buf = (int)(t & 1);
-      BJX_STAMP(4 * t);
-      if (!stager) {
-        mfma16();
-      } else {
-        read_frags(buf);
-        if (t + 1 < n_tiles) {
-          store_tiles(ra, buf ^ 1, (t + 1) * BK);
-          if (t + 3 < n_tiles) load_tiles(ra, (t + 3) * BK);
-        }
-      }
-      BJX_STAMP(4 * t + 1);
-      __syncthreads();
-      BJX_STAMP(4 * t + 2);
-      if (stager) {
-        mfma16();
-      } else {
-        if (t + 1 < n_tiles) read_frags(buf ^ 1);
-        if (t + 2 < n_tiles) {
-          store_tiles(rb, buf, (t + 2) * BK);
-          if (t + 4 < n_tiles) load_tiles(rb, (t + 4) * BK);
-        }
-      }
-      BJX_STAMP(4 * t + 3);
-      __syncthreads();
-    };
-    for (int64_t t = 0; t < n_tiles; t += 2) {
-      pp_tile(t, R1, R0);      // A(t + 1) odd -> R1 ; B(t + 2) even -> R0
-      pp_tile(t + 1, R0, R1);  // A(t + 2) even -> R0 ; B(t + 3) odd -> R1
-    }
-  } else {
   // staging: thread -> (tile row tid/4, 4 consecutive k starting at (tid&3)*4) of A and of Bt
   const int s_row = tid >> 2, s_k = (tid & 3) * 4;
   const float* a_src = a.A + (row0 + s_row) * D + s_k;
@@ -576,6 +416,16 @@ __global__ void __launch_bounds__(kThreads8, 4) k_dense_gemm_tn8(GemmArgs a) {  
     }
   };
 
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  const int64_t n_tiles = D / BK;  // even: D is a multiple of 128
+  const int lm = lane & 31, lk = lane >> 5;
+  const int a_off = (wm * 64 + lm) * LDK + lk * 8;
+  const int b_off = (wn * 32 + lm) * LDK + lk * 8;
   load_tiles(R0, 0);
   load_tiles(R1, BK);
   store_tiles(R0, 0, 0);
@@ -588,7 +438,6 @@ __global__ void __launch_bounds__(kThreads8, 4) k_dense_gemm_tn8(GemmArgs a) {  
     const float* as = As0 + buf * BM * LDK + a_off;
     const float* bs = Bs0 + buf * BN * LDK + b_off;
     float fa0[8], fa1[8], fb[8];
-    BJX_STAMP(4 * t);
     // the operands of the first four k-steps first (measured: no difference to any other order, with or
     // without a scheduling barrier between the halves -- round 3, call 24)
     *reinterpret_cast<F4*>(fa0) = ld4(as);
@@ -603,23 +452,19 @@ __global__ void __launch_bounds__(kThreads8, 4) k_dense_gemm_tn8(GemmArgs a) {  
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb[u], acc[1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the staging work here, behind 8 queued MFMAs
-    BJX_STAMP(4 * t + 1);
     if (t + 1 < n_tiles) store_tiles(stage, buf ^ 1, (t + 1) * BK);
     if (t + 2 < n_tiles) load_tiles(refill, (t + 2) * BK);
-    BJX_STAMP(4 * t + 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 4; u < 8; ++u) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[u], fb[u], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[u], fb[u], acc[1], 0, 0, 0);
     }
-    BJX_STAMP(4 * t + 3);
     __syncthreads();
   };
   for (int64_t t = 0; t < n_tiles; t += 2) {
     tile(t, R1, R0);
     tile(t + 1, R0, R1);
-  }
   }
 #ifdef BJX_DENSE_PROBE
   if (a.probe && tid == 0) a.probe[blockIdx.x * 8 + 2] = wall_clock64();
@@ -1043,7 +888,7 @@ int launch_pc(hipStream_t s, int epi, const PcArgs& pa) {
   return bjx_check_launch("bjx_dense_pc gemv");
 }
 
-#if defined(BJX_DENSE_PROBE) || defined(BJX_DENSE_PROBE2)
+#ifdef BJX_DENSE_PROBE
 static unsigned long long* g_probe_buf = nullptr;
 #endif
 
@@ -1061,17 +906,10 @@ int launch_gemm(hipStream_t s, int epi, const GemmArgs& ga_in) {
     return 1;
   }
   if (ga.b_symmetric && aligned && full) {
-#if defined(BJX_DENSE_PROBE) || defined(BJX_DENSE_PROBE2)
+#ifdef BJX_DENSE_PROBE
     ga.probe = g_probe_buf;
 #endif
-    // BJX_DENSE_PP=0: the lockstep K-tile loop of rounds 3-5 instead of the ping-pong loop (same results bit for bit;
-    // A/B aid, read once)
-    static const bool pp = [] { const char* e = getenv("BJX_DENSE_PP"); return !e || atoi(e) != 0; }();
-#define BJX_LAUNCH_TN(E, K)                                                                             \
-  do {                                                                                                  \
-    if (pp) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K, true>), grid, dim3(kThreads8), 0, s, ga);        \
-    else hipLaunchKernelGGL((k_dense_gemm_tn8<E, K, false>), grid, dim3(kThreads8), 0, s, ga);          \
-  } while (0)
+#define BJX_LAUNCH_TN(E, K) hipLaunchKernelGGL((k_dense_gemm_tn8<E, K>), grid, dim3(kThreads8), 0, s, ga)
     int kicks = ga.G ? ga.n_kicks : 0;
 #ifdef BJX_DENSE_PROBE
     // BJX_DENSE_ABLATE (measurement aid, RESULTS INVALID -- compiled only into PROBE builds, `make
@@ -1460,7 +1298,7 @@ int bjx_mhmc_step_dense_coef(void* stream, uint32_t key0, uint32_t key1, int64_t
                          prop_p, prop_g, prop_logp, prop_energy, n_steps, kick_coef);
 }
 
-#if defined(BJX_DENSE_PROBE) || defined(BJX_DENSE_PROBE2)
+#ifdef BJX_DENSE_PROBE
 /* PROBE builds only: device buffer of 4 x (number of workgroups) 64-bit stamps, or NULL. */
 int bjx_dense_probe_set(void* buf) {
   g_probe_buf = (unsigned long long*)buf;
