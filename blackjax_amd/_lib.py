@@ -149,8 +149,8 @@ NUTS_F = {"H0": 0, "LLOGP": 1, "RLOGP": 2, "PLOGP": 3, "PENERGY": 4, "PW": 5, "P
 NUTS_NF = 12
 NUTS_I = {"ACTIVE": 0, "SUB_ACTIVE": 1, "DIR": 2, "NSTATES": 3, "SUBN": 4, "SDIV": 5, "STURN": 6,
           "DIV": 7, "TURN": 8, "DEPTH": 9, "KT": 10, "KTB": 11, "KP": 12, "KPB": 13, "IK": 14, "IKB": 15,
-          "LAZY": 16}
-NUTS_NI = 17
+          "LAZY": 16, "STAGE": 17}
+NUTS_NI = 18
 
 SIGNATURES.update({
     "bjx_nuts_init": [c_void_p, POINTER(NutsDesc), _f32p, _f32p],

@@ -370,8 +370,8 @@ def window_adaptation(algorithm, logdensity_fn: Callable, is_mass_matrix_diagona
 
             if fuse_target or not free_running_supports(integrator, "diag", state.position.shape[1]):
                 raise NotImplementedError(
-                    "free_running=True with a multi-stage integrator: 16-byte rows of at most 1 024 floats, no "
-                    "fuse_target (nuts.free_running_supports)")
+                    "free_running=True with a multi-stage integrator: no fuse_target, at most "
+                    "NUTS_MAX_MID middle stages (nuts.free_running_supports)")
         if _schedule_fn is not None:
             raise NotImplementedError("free_running=True uses the Stan schedule (build_schedule)")
         n, d = state.position.shape

@@ -945,6 +945,22 @@ __device__ __forceinline__ bool async_leaf_chain(const bjx_nuts_t& nt, const bjx
                                                  const float* __restrict__ gf, int64_t c, int64_t b) {
   static_assert(!DENSE || NI == 0, "the register-resident leaf is for the diagonal metric");
   const int lane = threadIdx.x & 63;
+  if (ax.int_stages > 1) {
+    // multi-stage palindromic integrator (integrators.py:128-146) on the general kernel (round 6: rows beyond 1 024
+    // floats, 4-byte rows, per-chain dense metrics; the lean tick kernel keeps its own counter in the record): a leaf
+    // lasts int_stages ticks.  The first int_stages - 1 gradients drive a middle stage on the integrating end --
+    // k_nuts_mid's arithmetic: p += (dir eps b_i) g ; q += (dir eps a_i) M^-1 p -- and only the last one closes the leaf.
+    const int st = __builtin_amdgcn_readfirstlane(IS(BJX_NUTS_I_STAGE, c));
+    if (st < ax.int_stages - 1) {
+      const int dir = IS(BJX_NUTS_I_DIR, c);
+      const float deps = (float)dir * chain_eps(nt, c);
+      nuts_open_half<VEC, DENSE>(nt, c, dir, deps * ax.int_mid_drift[st], deps * ax.int_mid_kick[st], gf + b * nt.D,
+                                 qf + b * nt.D);
+      if (lane == 0) IS(BJX_NUTS_I_STAGE, c) = st + 1;
+      return false;
+    }
+    if (lane == 0) IS(BJX_NUTS_I_STAGE, c) = 0;
+  }
   const StepCtx cx = async_ctx(nt, ax, ax.t[c]);
   const int32_t depth = IS(BJX_NUTS_I_DEPTH, c);
   const int32_t s = IS(BJX_NUTS_I_SUBN, c);  // states already in the subtree = index of this leaf
@@ -1044,8 +1060,8 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
       if (grow) {
         const int dir = nuts_begin_doubling(nt, cx, c, depth + 1);
         const float deps = (float)dir * chain_eps(nt, c);
-        nuts_open_half<VEC, DENSE>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
-                                   qrow);
+        nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), deps * int_kick(nt),
+                                   (dir > 0 ? nt.Rg : nt.Lg) + base, qrow);  // (deps, deps / 2 for velocity Verlet)
         if (lane == 0) ax.phase[c] = 1;
         return;
       }
@@ -1135,8 +1151,8 @@ __device__ __forceinline__ void async_boundary_chain(const bjx_nuts_t& nt, const
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const int dir = nuts_begin_doubling(nt, cx, c, 0);
     const float deps = (float)dir * chain_eps(nt, c);
-    nuts_open_half<VEC, DENSE>(nt, c, dir, deps, deps * 0.5f, (dir > 0 ? nt.Rg : nt.Lg) + base,
-                               qrow);
+    nuts_open_half<VEC, DENSE>(nt, c, dir, deps * int_drift(nt), deps * int_kick(nt),
+                               (dir > 0 ? nt.Rg : nt.Lg) + base, qrow);
     if (lane == 0) ax.phase[c] = 1;
   }
 }

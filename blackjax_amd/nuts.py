@@ -463,12 +463,14 @@ def _os_environ():
 
 def free_running_supports(integrator, metric_kind: str, dim: int) -> bool:
     """Can the free-running tick kernels integrate with ``integrator``?  Velocity Verlet: always.  A general
-    palindromic list: on the low-traffic kernels (diagonal metric, 16-byte rows of at most 1 024 floats; 513 .. 1 024
-    since round 5) with at most ``NUTS_MAX_MID`` middle stages."""
+    palindromic list with at most ``NUTS_MAX_MID`` middle stages: on the low-traffic kernels (diagonal metric, 16-byte
+    rows of at most 1 024 floats) and -- round 6 -- on the general tick kernel for every other row length and for
+    per-chain dense metrics (a leaf lasts K ticks either way).  What is left to lockstep steps is ONE shared dense
+    matrix with D >= 128, whose products run on the MFMA GEMM (``run`` is then made of such steps by design)."""
+    del dim
     if integrator is integrators.velocity_verlet:
         return True
-    return (metric_kind == "diag" and dim % 4 == 0 and dim <= 1024
-            and integrator.num_gradients_per_step - 1 <= _lib.NUTS_MAX_MID)
+    return metric_kind in ("diag", "dense") and integrator.num_gradients_per_step - 1 <= _lib.NUTS_MAX_MID
 
 
 _SIDE_STREAMS: dict = {}  # (device index, main stream handle) -> a stream that runs CONCURRENTLY with it, or False
@@ -679,9 +681,8 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     kick_c, drift_c = integrator.coefficients[0::2], integrator.coefficients[1::2]
     if general and (fuse_target or not free_running_supports(integrator, metric.kind, D)):
         raise NotImplementedError(
-            "free-running ticks with a multi-stage integrator: diagonal metric, D % 4 == 0, D <= 1024, at most "
-            f"{_lib.NUTS_MAX_MID + 1} gradients per leapfrog and no fuse_target (nuts(...).run falls back to "
-            "lockstep steps for other shapes)")
+            f"free-running ticks with a multi-stage integrator: at most {_lib.NUTS_MAX_MID + 1} gradients per leapfrog "
+            "and no fuse_target")
     if metric.kind != "diag" and adaptation is not None:
         raise NotImplementedError("free-running per-chain adaptation is implemented for the diagonal metric")
     gemm = bool(dense_gemm)

@@ -46,7 +46,8 @@ extern "C" {
                              shared-dense entry points REFUSE whole 128 x 128 tiles on buffers that are not 16-byte aligned
                              instead of reading imm transposed; 6 (round 5): bjx_nuts_spec_t and bjx_nuts_spec_enter / _integrate /
                              _book added (two-stream speculative tail of a free-running run), nothing else changed; 7 (round 6):
-                             bjx_log1p_device_check added, nothing else changed */
+                             bjx_log1p_device_check added; the NUTS `is` table gained the slot BJX_NUTS_I_STAGE
+                             (BJX_NUTS_NI 17 -> 18: multi-stage integrators on the general free-running tick kernel) */
 
 const char* bjx_last_error(void);
 int bjx_abi_version(void);

@@ -66,7 +66,9 @@ enum {
   BJX_NUTS_I_LAZY = 16,      /* free-running chains: bit 1/2 = the left/right trajectory end, 4 = the
                                 proposal, 8 = the momentum sum is still the transition's initial state
                                 (its rows are then read from q0 / p0 / g0 instead of being copied) */
-  BJX_NUTS_NI = 17
+  BJX_NUTS_I_STAGE = 17,     /* free-running chains on the GENERAL tick kernel with a multi-stage integrator
+                                (bjx_nuts_async_t.int_stages > 1): gradients of the leaf in flight already used */
+  BJX_NUTS_NI = 18
 };
 
 typedef struct {
@@ -292,8 +294,10 @@ typedef struct {
                                  evaluated in place, so nothing separates two leapfrogs of a chain but the
                                  wave's own stores); 0 or 1: one tick per launch */
   const float* target_vec;
-  /* Multi-stage palindromic integrators [b1, a1, b2, a2, ..., b1] (blackjax/mcmc/integrators.py:270-369; round 4,
-   * low-traffic tick kernels only: diagonal metric, rec / front_p given): int_stages = gradients per leapfrog
+  /* Multi-stage palindromic integrators [b1, a1, b2, a2, ..., b1] (blackjax/mcmc/integrators.py:270-369; round 4:
+   * low-traffic tick kernels, stage counter in the record; round 6: the general tick kernel too -- any row length,
+   * per-chain dense metrics --, stage counter in the slot BJX_NUTS_I_STAGE, which the caller zeroes before the first
+   * tick; NOT the shared-dense GEMM mode): int_stages = gradients per leapfrog
    * (0 or 1: velocity Verlet / any one-gradient integrator; b1, a1 are bjx_nuts_t.int_kick / int_drift).  A leaf
    * then lasts int_stages ticks: after the opening (b1, a1) each of the first int_stages - 1 gradients drives a
    * middle stage p += (dir eps int_mid_kick[i]) g ; q += (dir eps int_mid_drift[i]) M^-1 p, i = 0 .. int_stages - 2

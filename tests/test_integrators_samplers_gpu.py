@@ -194,7 +194,10 @@ def test_dynamic_hmc_general_integrator_dense_metric(dev):
 
 @pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("N,D,key_layout", [(40, 64, "step_major"), (300, 256, "chain_major"), (25, 132, "step_major"),
-                                            (36, 1024, "step_major"), (70, 640, "chain_major")])
+                                            (36, 1024, "step_major"), (70, 640, "chain_major"),
+                                            # round 6: the general tick kernel -- rows beyond 1 024 floats, 4-byte rows
+                                            (12, 1028, "step_major"), (9, 2048, "chain_major"), (7, 1023, "step_major"),
+                                            (33, 37, "chain_major"), (20, 6, "step_major")])
 def test_nuts_free_running_with_a_multi_stage_integrator(dev, name, N, D, key_layout):
     """Round 4: ``run`` with mclachlan / yoshida / omelyan stays on the FREE-RUNNING tick kernels (a leaf lasts
     K ticks: K - 1 middle stages + the closing tick, ``bjx_nuts_async_t.int_stages``) instead of degrading to
@@ -242,20 +245,47 @@ def test_where_general_integrators_are_not_available():
     with pytest.raises(NotImplementedError):
         bjx.hmc.build_kernel(object())
     # (mhmc / dmhmc with dense metrics take them since round 4: tests/test_frows_dense_gpu.py)
-    # free-running NUTS ticks: diagonal metric, 16-byte rows of at most 1 024 floats (round 5; 512 before) -- a wider
-    # row is refused by run_free itself (nuts(...).run then takes lockstep steps instead, with a warning)
+    # free-running NUTS ticks take multi-stage integrators at EVERY diagonal shape and with per-chain dense metrics since
+    # round 6 (the general tick kernel keeps a stage counter per chain): no degradation to lockstep steps, no warning
+    import warnings
+
     from blackjax_amd.nuts import free_running_supports, run_free
 
-    assert not free_running_supports(bjx.integrators.mclachlan, "diag", 1028)
-    assert free_running_supports(bjx.integrators.yoshida, "diag", 1024)
-    assert not free_running_supports(bjx.integrators.mclachlan, "dense", 64)
+    assert free_running_supports(bjx.integrators.mclachlan, "diag", 1028)
+    assert free_running_supports(bjx.integrators.yoshida, "diag", 1023)
+    assert free_running_supports(bjx.integrators.mclachlan, "dense", 64)
     D = 1028
-    alg = bjx.nuts(bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), integrator=bjx.integrators.mclachlan,
-                   max_num_doublings=3)
+    fn = bjx.targets.NealFunnel()
+    alg = bjx.nuts(fn, 0.1, torch.ones(D, device="cuda"), integrator=bjx.integrators.mclachlan, max_num_doublings=3)
     st = alg.init(0.1 * torch.ones(5, D, device="cuda"))
-    with pytest.raises(NotImplementedError):
-        run_free(bjx.random.key(0), st, bjx.targets.NealFunnel(), 0.1, torch.ones(D, device="cuda"), 2, 3,
-                 integrator=bjx.integrators.mclachlan)
-    with pytest.warns(RuntimeWarning, match="lockstep"):  # never degrade silently
-        final, pos, info = alg.run(bjx.random.key(0), st, 2)  # falls back to lockstep steps
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        final, pos, info = alg.run(bjx.random.key(0), st, 2)
     assert pos.shape == (2, 5, D)
+    # the engine-resident target path integrates with velocity Verlet only
+    with pytest.raises(NotImplementedError):
+        run_free(bjx.random.key(0), st, fn, 0.1, torch.ones(D, device="cuda"), 2, 3, integrator=bjx.integrators.mclachlan,
+                 fuse_target=True)
+
+
+@pytest.mark.parametrize("name", ["mclachlan", "yoshida"])
+def test_nuts_free_running_multi_stage_with_per_chain_dense_metrics(dev, name):
+    """Round 6: per-chain dense metrics (fp64-accumulated mat-vec ticks) with a multi-stage integrator run free as well:
+    `run(T)` equals T lockstep `step`s bit for bit (trajectory.py:242-395 with integrators.py:104-150)."""
+    N, D, T = 24, 20, 3
+    g = torch.Generator(device=dev).manual_seed(8)
+    A = torch.randn(N, D, D, device=dev, generator=g) * 0.2
+    imm = (A @ A.transpose(1, 2) + torch.eye(D, device=dev)).contiguous()  # one SPD matrix per chain
+    q0 = torch.randn(N, D, device=dev, generator=g)
+    fn = bjx.targets.DiagGaussian(torch.linspace(0.5, 2.0, D, device=dev))
+    alg = bjx.nuts(fn, 0.2, imm, max_num_doublings=5, integrator=getattr(bjx.integrators, name))
+    st0 = alg.init(q0)
+    final, positions, info = alg.run(prng.key(3), st0, T)
+    st = st0
+    for t, k in enumerate(prng.split(prng.key(3), T)):
+        st, inf = alg.step(k, st)
+        assert torch.equal(info.num_integration_steps[t], inf.num_integration_steps), t
+        assert torch.equal(positions[t], st.position), t
+        assert torch.equal(info.acceptance_rate[t], inf.acceptance_rate)
+    assert torch.equal(final.logdensity_grad, st.logdensity_grad)
+    assert int(info.num_integration_steps.max()) > 3
