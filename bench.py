@@ -803,7 +803,9 @@ def bench_c2(args, ctx):
                     roofline["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc passes of an "
                                                   "earlier run, committed; scaled per chain; NOT measured in "
                                                   "this run; counters sit at the L2 memory-side interface and "
-                                                  "include Infinity-Cache hits)")
+                                                  "include Infinity-Cache hits; passes taken on build: "
+                                                  f"{tj.get('measured_on_build', 'round 5 final')})")
+                    roofline["traffic_build"] = tj.get("measured_on_build", "round 5 final")
             except Exception:
                 pass
         # what an empty event bracket costs, behind a kernel of the same kind

@@ -1051,9 +1051,10 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         RING = 64      # ring slots per row
         LEAD = 4       # records the integrator may run ahead of the bookkeeper's consumed count (2: stalls; 4 .. 63: flat at
                        # D = 256, where a record costs the bookkeeper 3.2 us against 4.9 us per leaf on stream A)
-        SEQ = 64       # leapfrogs per recorded sequence of stream A (32 / 64 / 128 measured within 4 % of each other)
+        SEQ = int(_os.environ.get("BJX_NUTS_SPEC_SEQ", 64))  # leapfrogs per recorded sequence of stream A (32 / 64 / 128 measured within 4 % of each other)
         SEQ0 = 8       # plain leapfrogs before the recording (kernels, allocator warm)
-        REPS = 2       # sequences queued per host poll
+        REPS = int(_os.environ.get("BJX_NUTS_SPEC_REPS", 1))  # sequences queued per host poll (round 6: 1 -- the host learns of the
+                       # run's end one batch late, and a batch of 128 leapfrogs past the end cost `step` 4 % at C3)
         TIMEOUT_US = 20000
 
         def __init__(self, cap):

@@ -36,6 +36,18 @@ def counter_avg(sub, counter):
     return sum(vals) / len(vals), len(vals), sorted(grids)
 
 
+def _build():
+    import subprocess
+    try:
+        rev = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs %s"], capture_output=True, text=True).stdout.strip()
+        return rev[:100] or "unknown"
+    except Exception:
+        return "unknown"
+
+
+BUILD = _build()  # the commit whose library the PMC passes profiled (collect right after the GPU call, before further commits)
+
+
 def main():
     global KERNEL
     tag = sys.argv[1]
@@ -76,6 +88,7 @@ def main():
         "bench_hip_events": {"stream_avg_us": roof.get("avg_launch_us"),
                              "cache_avg_us": (roof.get("cache_assisted") or {}).get("avg_launch_us")},
         "source": f"profiles/{rnd}/bench_c2_pmc_{tag}.json",
+        "measured_on_build": BUILD,
     }
     json.dump(pmc, open(os.path.join(out_dir, f"bench_c2_pmc_{tag}.json"), "w"), indent=1)
     json.dump(pmc, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)

@@ -13,7 +13,8 @@ OUT=$R/gpurun_out/round_prof
 rm -rf $OUT
 mkdir -p $OUT
 cd $R
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+BJX_BENCH_FULL=$OUT/bench_default_full.json python bench.py > $OUT/bench_default_compact.json 2> $OUT/bench_default.err
+cp $OUT/bench_default_full.json $OUT/bench_default.json   # the FULL record (the stdout line is the compact one)
 CB=$(python -c "import json,sys; j=json.loads(open('$OUT/bench_default.json').read().strip().splitlines()[-1]); print(j['roofline']['cache_assisted']['chains_per_launch'] if j['roofline'].get('cache_assisted') else j['config']['chain_block'])")
 cd /tmp; export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --headline-only"

@@ -12,9 +12,9 @@ rm -rf $O; mkdir -p $O
 cd $R
 (time timeout 1500 python -m pytest tests/ -q -m gpu) > $O/gpu_tests.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-BJX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --headline-only --no-cpu-baseline > $O/bench_c2_2ranks_one_gpu.json 2> $O/bench_2r.err
-python bench.py --config c4 > $O/bench_c4.json 2> $O/bench_c4.err   # default: the 1 000-step warm-up of configs[3]
+BJX_BENCH_FULL=$O/bench_c2.json python bench.py > $O/bench_c2_compact.json 2> $O/bench_c2.err
+BJX_BENCH_FULL=$O/bench_c2_2ranks_one_gpu.json BJX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --headline-only --no-cpu-baseline > /dev/null 2> $O/bench_2r.err
+BJX_BENCH_FULL=$O/bench_c4.json python bench.py --config c4 > /dev/null 2> $O/bench_c4.err   # default: the 1 000-step warm-up of configs[3]
 for T in 20 100 400; do timeout 600 python tools/bench_nuts.py --free-running --steps $T --no-tick-timing > $O/nuts_c3_T$T.json 2>> $O/nuts.err; done
 timeout 600 python tools/bench_nuts.py --use-graph --steps 8 --warmup 4 > $O/nuts_c3_lockstep.json 2>> $O/nuts.err   # warm-up 4: the bucket graphs are recorded before the timed steps
 # the same C3 runs with the funnel evaluated INSIDE the tick kernels (fuse_target=True: engine-resident target,
