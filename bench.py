@@ -1326,7 +1326,9 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
                     "busy_phase_tick_GBps_measured": both.get("GBps_measured"),
                     "busy_phase_tick_frac_measured": both.get("frac_of_8TBps_measured"),
                     "traffic_source": "profiles/nuts_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
-                                      "earlier run, committed; NOT measured in this run; Infinity-Cache hits are counted)"})
+                                      "earlier run, committed; NOT measured in this run; Infinity-Cache hits are counted; "
+                                      f"passes taken on build: {tj.get('measured_on_build', 'round 5 final')})",
+                    "traffic_build": tj.get("measured_on_build", "round 5 final")})
         except Exception:
             pass
     return {

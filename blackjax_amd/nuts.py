@@ -11,7 +11,7 @@ chains are always at the same (doubling, leaf) position -- with ACTIVE-CHAIN COM
 user's log-density callable and the kernels only see the chains that are still building a tree
 (re-compacted at every doubling and every ``recompact_every`` leapfrogs inside a doubling).
 All tree arithmetic (progressive sampling, momentum sums, U-turn checkpoints, merge) runs in
-``bjx_nuts.hip``.
+``bjx_nuts_lockstep.hip`` / ``bjx_nuts_tick.hip`` / ``bjx_nuts_spec.hip`` (device functions: ``bjx_nuts_chain.h``, ``bjx_nuts_tick_dev.h``).
 
 Two drivers with identical results:
 * eager (``use_graph=False``): three launches per leapfrog (pre, callable, post) issued from Python;
@@ -801,7 +801,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 "fuse_target=True needs a blackjax_amd.targets log-density the tick kernels can evaluate "
                 "(NealFunnel; DiagGaussian with D > 128), a diagonal metric, D % 4 == 0 and D <= 512")
         if spec[0] == "rtc":
-            # a user-written device target (targets.DeviceTarget): the multi-tick kernel of csrc/bjx_nuts.hip is
+            # a user-written device target (targets.DeviceTarget): the multi-tick kernel of csrc/bjx_nuts_tick_dev.h is
             # compiled around it by hiprtc (blackjax_amd/rtc.py) and launched through the module API; every
             # chunk of ticks is one launch (the library's one-tick kernels do not know the target)
             rtc_target = spec[1]

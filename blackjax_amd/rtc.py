@@ -151,7 +151,7 @@ def ni_for(dim: int) -> int:
     return 1 if dim <= 256 else (2 if dim <= 512 else 4)
 
 
-# The free-running NUTS multi-tick kernel (csrc/bjx_nuts.hip: async_multi_tick_row) around a user target:
+# The free-running NUTS multi-tick kernel (csrc/bjx_nuts_tick_dev.h: async_multi_tick_row) around a user target:
 # hiprtc compiles the SAME source file the library is built from, device code only, with the user's struct as
 # BJX_RTC_USER_TARGET.  One wave per workgroup and row, two waves per SIMD, as k_nuts_async_multi.
 NUTS_TU = """#include "bjx_traj_dev.h"
@@ -160,7 +160,7 @@ using namespace bjx;
 %(source)s
 // ---- the engine's NUTS device code around it
 #define BJX_RTC_USER_TARGET %(struct)s
-#include "bjx_nuts.hip"
+#include "bjx_nuts_tick_dev.h"
 #define BJX_RTC_NUTS(NI_, FULL_, NAME_)                                                                      \\
   extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))                   \\
   NAME_(bjx_nuts_t nt, bjx_nuts_async_t ax, float* qf, float* logp_f, float* gf) {                           \\

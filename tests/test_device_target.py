@@ -134,7 +134,7 @@ def test_device_target_samples_its_density(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,D,T", [(700, 256, 4), (90, 320, 5), (9000, 128, 3)])
 def test_device_target_inside_the_nuts_tick_kernel_equals_the_external_callable_path(dev, N, D, T):
-    """Free-running NUTS with the user's eval compiled into the multi-tick kernel of csrc/bjx_nuts.hip (hiprtc
+    """Free-running NUTS with the user's eval compiled into the multi-tick kernel of csrc/bjx_nuts_tick_dev.h (hiprtc
     compiles the library's own source file around it): positions, records and the final state are bit for bit
     those of the run where the same object is an external callable between two ticks."""
     tgt, _, a = _quartic(dev, D, c=0.6)
@@ -158,7 +158,7 @@ def test_device_target_inside_the_nuts_tick_kernel_equals_the_external_callable_
 @pytest.mark.gpu
 def test_device_target_through_the_free_running_warmup_and_step(dev):
     """window_adaptation(nuts).run(free_running=True, fuse_target=True) and nuts(..., fuse_target=True).step with a
-    user target: the per-chain adaptation code of csrc/bjx_nuts.hip is part of the run-time kernel too."""
+    user target: the per-chain adaptation code of csrc/bjx_nuts_tick_dev.h is part of the run-time kernel too."""
     N, D, T = 300, 256, 40
     tgt, _, a = _quartic(dev, D, c=0.6)
     g = torch.Generator(device=dev)
@@ -197,7 +197,7 @@ def test_fuse_target_switches_validate_their_arguments_without_a_gpu():
 
 
 def test_nuts_translation_unit_compiles_for_gfx950_without_a_gpu():
-    """hiprtc compiles csrc/bjx_nuts.hip itself (device part) around the user's struct: guards against a host
+    """hiprtc compiles csrc/bjx_nuts_tick_dev.h (the device functions the library is built from) around the user's struct: guards against a host
     include or host-only construct slipping into the device part of that file."""
     code = bjx.rtc.compile(bjx.rtc.NUTS_TU % {"source": QUARTIC, "struct": "Target"}, "nuts_user_test.hip")
     assert code[:4] == b"\x7fELF" and b"bjx_rtc_nuts_multi_1_full" in code

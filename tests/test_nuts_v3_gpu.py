@@ -1,4 +1,4 @@
-"""The free-running tick of the contract path, k_nuts_async_tick3<NI, W> (csrc/bjx_nuts.hip: lean leaf + deferred
+"""The free-running tick of the contract path, k_nuts_async_tick3<NI, W> (csrc/bjx_nuts_tick.hip: lean leaf + deferred
 transition ends, one launch per tick; NI = 1 .. 4 sixteen-byte pieces per lane = rows of at most 256 .. 1 024 floats),
 at every row width against the LOCKSTEP kernels -- an independent implementation of the same transitions
 (bjx_nuts_pre / post / merge) -- and against the oracle.  Round 5 removed the tick variants this file used to

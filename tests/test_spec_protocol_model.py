@@ -1,5 +1,5 @@
 """A CPU model of the two-stream speculative tail's PROTOCOL (include/bjx_nuts.h "Speculative tail";
-csrc/bjx_nuts.hip k_nuts_spec_integrate / k_nuts_spec_book): one row, the integrator ("A") and the bookkeeper ("B") as
+csrc/bjx_nuts_spec.hip k_nuts_spec_integrate / k_nuts_spec_book): one row, the integrator ("A") and the bookkeeper ("B") as
 the state machines the kernels implement, driven by an adversarial random scheduler.  It checks what the GPU parity tests
 cannot enumerate -- every interleaving the memory protocol allows:
 
