@@ -89,6 +89,7 @@ def test_logdensity_evaluations_per_transition(dev):
         assert calls["n"] == 1 + 3 * per_step, (per_step, calls["n"])
 
 
+@pytest.mark.gpu
 def test_a_plain_function_is_evaluated_once_and_traced_once(dev):
     """The reference's tests/test_compilation.py:19-100 asks that the log-density be TRACED at most twice per kernel:
     here a plain PyTorch function is evaluated once (init, under autograd), traced once (torch.fx -> generated
