@@ -1240,11 +1240,20 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
     acc = torch.zeros((), device=dev, dtype=torch.float64)
     st_box = {"state": state}
 
+    step_host_ms = []
+
     def one_step(i):
+        t_h = time.perf_counter()
         st, info = alg.step(keys[n_warm + i], st_box["state"])
         st_box["state"] = st
         acc.add_(info.num_integration_steps.sum())
+        step_host_ms.append((time.perf_counter() - t_h) * 1e3)  # step() returns when the transition is done (it polls)
 
+    # two untimed calls right before the region: the runs above went through other drivers of the same object, and the
+    # first `step` after them re-records its tail sequences (measured: 27-67 ms for that one call, 4.4-8.3 ms after)
+    for t in range(2):
+        st_w, _ = alg.step(keys[t], st_box["state"])
+    del st_w
     dt_l, per_l, _ = timed_region(ctx, one_step, lockstep_steps)
     tot_l = float(ctx.gather_rows(acc.reshape(1, 1)).sum())
     # the same calls on the lockstep tree driver (step_driver="lockstep": rounds 1-4's `step`), rank 0 of a one-GPU run
@@ -1352,7 +1361,7 @@ def bench_c3(args, ctx, T=None, lockstep_steps=8):
         "free_running_T400": t400,
         "lockstep_step": {
             "value": tot_l / dt_l, "unit": "chain-leapfrog-steps/s", "steps": lockstep_steps,
-            "ms_per_transition": dt_l / lockstep_steps * 1e3,
+            "ms_per_transition": dt_l / lockstep_steps * 1e3, "host_ms_of_each_call": step_host_ms,
             "mean_leapfrogs_per_chain_transition": tot_l / (world * N * lockstep_steps),
             "frac_of_52B_roofline": tot_l / dt_l / world / peak_rate,
             "step_driver": "auto -> one free-running transition on a persistent workspace (two-stream speculative tail)",

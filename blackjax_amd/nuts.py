@@ -531,7 +531,8 @@ def auto_row_block(n_rows: int, dim: int) -> int:
     ``row_block=n`` to ``run_free``) was measured SLOWER at the C3 shape (32 768 x
     256: one group 138.6 M/s, groups of 16 384 / 8 192 / 4 096 rows 124.6 / 114.2 / 88.9 M/s; on the
     final kernels 184-191 vs 164 / 131): a tick moves more than the cache holds between two uses of
-    a row whatever the grouping, and the smaller launches cost (NOTEBOOK.md section 7)."""
+    a row whatever the grouping, and the smaller launches cost (NOTEBOOK.md section 7).  Round 6: two half-size
+    groups on two CONCURRENT streams (one group's tick under the other's callable): 276 vs 279 M/s at T = 100, no gain."""
     return int(n_rows)
 
 
