@@ -26,7 +26,7 @@ def steps(n, tag):
 steps(5, "cold")
 c0 = count["n"]; alg.run(bjx.random.key(5), st, 2, store_positions=False); torch.cuda.synchronize(); print("run(T=2) recordings", count["n"] - c0)
 steps(3, "after run(2)")
-c0 = count["n"]; alg.run(bjx.random.key(6), st, 100, store_positions=False); torch.cuda.synchronize(); print("run(T=100) recordings", count["n"] - c0)
-steps(3, "after run(100)")
+c0 = count["n"]; alg.run(bjx.random.key(6), st, 400, store_positions=False); torch.cuda.synchronize(); print("run(T=400) recordings", count["n"] - c0)
+steps(3, "after run(400)")
 c0 = count["n"]; alg.run(bjx.random.key(7), st, 100, store_positions=False); torch.cuda.synchronize(); print("run(T=100) again recordings", count["n"] - c0)
 steps(3, "after run(100) #2")
