@@ -186,3 +186,34 @@ def test_bench_default_line_carries_c3_c5_c4_sub_objects():
         assert j[k]["config"]["workload"].startswith(start)
         assert j[k]["roofline"]["frac"] > 0
     assert j["c3_nuts"]["steps"] == 100 and j["c4_shard"]["steps"] == 200
+
+
+def test_compact_line_of_a_committed_full_record_fits_the_drivers_tail():
+    """the driver keeps an 8 KB tail of stdout.  `bench.compact_line` on the committed full record of
+    round 6 (profiles/r06/bench_final_r06.json, ~26 KB): at most 6 000 bytes, one JSON object, and it carries the
+    contract keys, the roofline / cpu_baseline objects, every config's value, roofline fraction and parity counts."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bjx_bench", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = [BENCH]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_final_r06.json")))
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(full, "gpurun_out/bench_full_latest.json")
+    assert len(line) <= 6000 and "\n" not in line
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "ess_nonresonant"):
+        assert k in c, k
+    assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["vs_baseline"] is None
+    assert c["roofline"]["frac"] == pytest.approx(c["roofline"]["achieved"] / c["roofline"]["peak"], rel=1e-5)
+    assert c["roofline"]["algorithmic_bytes_per_launch"] == 20 * 1024 * c["roofline"]["chains_per_launch"]  # integers stay exact
+    for k in ("c3_nuts", "c5_dense", "c4_shard"):
+        assert c[k]["value"] > 0 and c[k]["ms_per_step"] > 0 and 0 < c[k]["roofline"]["frac"] < 1
+    assert c["c5_dense"]["parity"]["accept_mismatches"] == 0 and c["c3_nuts"]["parity"]["tree_size_mismatches"] == 0
+    assert c["c3_nuts"]["lockstep_step"]["value"] > 0 and c["c3_nuts"]["free_running_T400"]["value"] > 0
