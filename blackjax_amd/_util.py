@@ -69,11 +69,35 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
 
     ew: dict = {}  # (D, device) -> generated element-wise target, or None (not of that shape / failed its check)
 
+    calls: dict = {}  # (D, device) -> calls served by the generated kernel
+
     def _autograd_or_elementwise(q, first=None):
         key = (int(q.shape[-1]), q.device)
         if key in ew:
             tgt = ew[key]
-            return tgt(q) if tgt is not None else (first if first is not None else _autograd(q))
+            if tgt is None:
+                return first if first is not None else _autograd(q)
+            n = calls[key] = calls.get(key, 0) + 1
+            if n in _RECHECK_AT or n % _RECHECK_EVERY == 0:
+                # A traced function is the function AS IT WAS at its first call (as under jax.jit).  A closure over Python
+                # state that changes later -- a tempering beta held as a float, a minibatch index -- would go stale
+                # silently, so the generated kernel is re-checked against eager autograd on the live batch at calls 16,
+                # 256 and every 4 096th (one autograd pass each); a disagreement puts the callable back on autograd.
+                if not (q.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    lp_a, g_a = _autograd(q)
+                    lp_k, g_k = tgt(q)
+                    if _close(lp_k, lp_a) and _close(g_k, g_a):
+                        return lp_k, g_k
+                    ew[key] = None
+                    import warnings
+
+                    warnings.warn(
+                        "blackjax_amd: the kernel generated from this log-density no longer agrees with the function "
+                        f"itself (call {n}: it reads Python state that changed after its first call?) -- evaluating it "
+                        "eagerly under torch.autograd from here on; declare such callables with blackjax_amd.no_trace.",
+                        RuntimeWarning, stacklevel=3)
+                    return lp_a, g_a
+            return tgt(q)
         lp, g = first if first is not None else _autograd(q)
         ew[key] = _try_elementwise(logdensity_fn, q, lp, g)
         return lp, g
@@ -114,6 +138,18 @@ def value_and_grad(logdensity_fn: Callable) -> Callable:
 
 
 _WARNED_AUTOGRAD: set = set()
+_RECHECK_AT = (16, 256)   # calls at which a generated kernel is re-checked against eager autograd ...
+_RECHECK_EVERY = 4096     # ... and every this many calls after
+
+
+def _close(a, b) -> bool:
+    """Generated kernel vs autograd on one batch: within 1e-4 of the batch's largest finite magnitude, same non-finite
+    entries (rounding differs by ~1e-6; a mis-traced or stale function by far more)."""
+    a, b = a.float(), b.float()
+    fin = torch.isfinite(b)
+    scale = float(b[fin].abs().max()) if bool(fin.any()) else 1.0
+    same_nonfinite = bool(((a == b) | (torch.isnan(a) & torch.isnan(b)))[~fin].all())
+    return same_nonfinite and bool(((a - b)[fin].abs() <= 1e-4 * max(scale, 1e-30)).all())
 
 
 def no_trace(logdensity_fn: Callable) -> Callable:
@@ -154,14 +190,7 @@ def _try_elementwise(logdensity_fn, q, lp_ref, g_ref):
             tgt = from_elementwise(logdensity_fn, int(q.shape[1]), device=q.device)
             lp, g = tgt(q.detach().contiguous())
 
-            def close(a, b):
-                a, b = a.float(), b.float()
-                fin = torch.isfinite(b)
-                scale = float(b[fin].abs().max()) if bool(fin.any()) else 1.0
-                same_nonfinite = bool(((a == b) | (torch.isnan(a) & torch.isnan(b)))[~fin].all())
-                return same_nonfinite and bool(((a - b)[fin].abs() <= 1e-4 * max(scale, 1e-30)).all())
-
-            if not (close(lp, lp_ref) and close(g, g_ref)):
+            if not (_close(lp, lp_ref) and _close(g, g_ref)):
                 tgt, why = None, "the generated kernel disagreed with autograd on the first batch"
         except NotImplementedError as e:
             tgt, why = None, str(e)

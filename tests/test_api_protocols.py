@@ -93,7 +93,8 @@ def test_logdensity_evaluations_per_transition(dev):
 def test_a_plain_function_is_evaluated_once_and_traced_once(dev):
     """The reference's tests/test_compilation.py:19-100 asks that the log-density be TRACED at most twice per kernel:
     here a plain PyTorch function is evaluated once (init, under autograd), traced once (torch.fx -> generated
-    value-and-gradient kernel, checked against that evaluation) and its Python code never runs again."""
+    value-and-gradient kernel, checked against that evaluation) and its Python code does not run again -- except for the
+    sparse re-checks of the generated kernel against the live function (calls 16, 256, every 4 096th: one evaluation each)."""
     calls = {"n": 0}
 
     def fn(q):
@@ -104,6 +105,35 @@ def test_a_plain_function_is_evaluated_once_and_traced_once(dev):
     alg = bjx.hmc(fn, 0.1, torch.ones(8, device=dev), 7)
     state = alg.init(q0)
     assert calls["n"] == 2
-    for k in bjx.random.split(bjx.random.key(2), 3):
-        state, info = alg.step(k, state)
+    state, info = alg.step(bjx.random.key(2), state)  # 7 gradient evaluations: kernel calls 1 .. 7
     assert calls["n"] == 2 and bool(info.is_accepted.any())
+    for k in bjx.random.split(bjx.random.key(3), 3):    # kernel calls 8 .. 28: the re-check at call 16 evaluates fn once
+        state, info = alg.step(k, state)
+    assert calls["n"] == 3
+
+
+@pytest.mark.gpu
+def test_a_traced_function_that_goes_stale_is_caught_and_put_back_on_autograd(dev):
+    """A traced function is the function as it was at its first call (as under jax.jit).  One that closes over Python
+    state which changes later is caught by the re-check (call 16 here) and evaluated eagerly from then on, with a
+    RuntimeWarning -- never silently stale for more than a re-check interval."""
+    from blackjax_amd import _util
+
+    box = {"beta": 1.0}
+
+    def tempered(q):
+        return -0.5 * box["beta"] * (q * q).sum(-1)
+
+    q = torch.randn(32, 16, device=dev)
+    vg = _util.value_and_grad(tempered)
+    lp, g = vg(q)                                # first call: autograd, then traced with beta = 1
+    assert torch.allclose(g, -q) and list(vg._bjx_elementwise.values())[0] is not None
+    box["beta"] = 3.0                            # the user changes the temperature: the kernel still has beta = 1 ...
+    for _ in range(14):
+        lp, g = vg(q)
+        assert torch.allclose(g, -q)
+    with pytest.warns(RuntimeWarning, match="no longer agrees"):
+        lp, g = vg(q)                            # ... until kernel call 16 re-checks it against the live function
+    assert torch.allclose(g, -3.0 * q) and list(vg._bjx_elementwise.values())[0] is None
+    lp, g = vg(q)
+    assert torch.allclose(g, -3.0 * q)           # eager autograd from here on
