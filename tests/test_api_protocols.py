@@ -129,7 +129,7 @@ def test_a_traced_function_that_goes_stale_is_caught_and_put_back_on_autograd(de
     lp, g = vg(q)                                # first call: autograd, then traced with beta = 1
     assert torch.allclose(g, -q) and list(vg._bjx_elementwise.values())[0] is not None
     box["beta"] = 3.0                            # the user changes the temperature: the kernel still has beta = 1 ...
-    for _ in range(14):
+    for _ in range(15):                          # kernel calls 1 .. 15
         lp, g = vg(q)
         assert torch.allclose(g, -q)
     with pytest.warns(RuntimeWarning, match="no longer agrees"):
