@@ -593,6 +593,46 @@ def test_hip_transition_equals_the_reference_code(fx, dev, name):
     _check_sampler(c, n(st.position), d, c["algorithm"] == "nuts")
 
 
+_PLAIN_CASES = [n for n in _GPU_CASES if FX["samplers"][n]["target"]["kind"] == "diag_gaussian"
+                and not np.ndim(FX["samplers"][n].get("metric_dense", 0))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _PLAIN_CASES)
+def test_hip_transition_with_a_plain_pytorch_logdensity_equals_the_reference_code(fx, dev, name):
+    """Round 6: the DEFAULT user path -- the log-density written as a plain PyTorch function, as the reference's user
+    writes it in jnp (`hmc.py:90-92`: value_and_grad(logdensity_fn)) -- traced on its first call into the generated
+    value-and-gradient kernel, against the reference's own code on the same seeds and inputs."""
+    import torch
+
+    import blackjax_amd as bjx
+    from blackjax_amd import _util
+
+    c = fx["samplers"][name]
+    N, D = c["N"], c["D"]
+    s_ = ladder(D, c["target"]["lo"], c["target"]["hi"])
+    inv_var = torch.as_tensor((f32(1) / (s_ * s_)).astype(f32), device=dev)
+    fn = lambda q: -0.5 * (q * q * inv_var).sum(-1)  # noqa: E731
+    imm = torch.as_tensor(metric_of(c, D), device=dev)
+    integ = getattr(bjx.integrators, c.get("integrator", "velocity_verlet"))
+    kw = dict(integrator=integ, divergence_threshold=c.get("divergence_threshold", 1000))
+    if c["algorithm"] == "nuts":
+        alg = bjx.nuts(fn, c["eps"], imm, max_num_doublings=c["max_num_doublings"], **kw)
+    else:
+        alg = getattr(bjx, c["algorithm"])(fn, c["eps"], imm, c["L"], **kw)
+    st0 = alg.init(torch.as_tensor(initial_positions(c, N, D), device=dev))
+    assert [type(v).__name__ for v in _util.value_and_grad(fn)._bjx_elementwise.values()] in (["DeviceTarget"], ["ElementwiseRowsTarget"])
+    st, info = alg.step(np.asarray(c["step_key"], np.uint32), st0)
+    n = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else x  # noqa: E731
+    d = {k: n(v) for k, v in info._asdict().items() if not isinstance(v, tuple)}
+    if c["algorithm"] == "nuts":
+        d["leftmost_position"] = n(info.trajectory_leftmost_state.position)
+        d["rightmost_position"] = n(info.trajectory_rightmost_state.position)
+    else:
+        d["proposal_position"] = n(info.proposal.position)
+    _check_sampler(c, n(st.position), d, c["algorithm"] == "nuts")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(FX["warmup"]))
 def test_hip_adaptation_updates_equal_the_reference_code_step_by_step(dev, name):
