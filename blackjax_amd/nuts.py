@@ -553,7 +553,7 @@ class NUTSRunInfo(NamedTuple):
 def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inverse_mass_matrix,
              num_steps: int, max_num_doublings: int = 10, *, divergence_threshold: float = 1000,
              chain_offset: int = 0, key_layout: str = "step_major", store_positions: bool = True,
-             sync_every=None, use_graph="auto", graph_max_rows: int = 2048, adaptation=None,
+             sync_every=None, use_graph="auto", graph_max_rows: int = 8192, adaptation=None,
              row_block=None, fuse_target: bool = False, integrator=integrators.velocity_verlet,
              dense_gemm: bool = False, dense_gemm_cap=None, spec_rows=None, keep_ends: bool = False,
              _handle: Optional[dict] = None):
@@ -649,10 +649,18 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     persistent = _handle is not None
-    if persistent and (key_layout != "step" or adaptation is not None or fuse_target or dense_gemm
-                       or bjx_random.key_spec(rng_key)[2] >= 0 or N == 0):
-        raise ValueError("a persistent free-running workspace serves key_layout='step' with a plain key, without "
-                         "adaptation, fuse_target or dense_gemm")
+    if persistent and (key_layout not in ("step", "step_major") or adaptation is not None or fuse_target or dense_gemm
+                       or bjx_random.key_spec(rng_key)[2] >= 0 or N == 0 or T == 0):
+        raise ValueError("a persistent free-running workspace serves key_layout='step' / 'step_major' with a plain key, "
+                         "without adaptation, fuse_target or dense_gemm")
+    # A persistent ``step_major`` workspace is built for a CAPACITY of transitions (``_handle["capacity"]`` >= T): the
+    # recorded launches carry ``n_steps`` by value, so a call of T <= capacity transitions starts every chain's counter at
+    # t0 = capacity - T and uses rows t0 .. capacity - 1 of the key table and of the output arrays (the kernels index
+    # both by the chain's absolute counter: csrc/bjx_nuts_tick_dev.h, async_ctx and the transition end)
+    Tc = T
+    if persistent and key_layout == "step_major":
+        Tc = max(T, int(_handle.get("capacity", T)))
+    cur = {"T": T, "t0": Tc - T}
     adapt_fields = {}
     out_step_size = None
     if adaptation is not None:
@@ -701,18 +709,19 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                                    or metric.imm.data_ptr() != adaptation["imm"].data_ptr()
                                    or metric.imm_stride != D):
         raise RuntimeError("adaptation buffers were copied on the way to the kernels")
-    info = NUTSRunInfo(torch.empty((T, N), **f32), torch.empty((T, N), **f32), torch.empty((T, N), **f32),
-                       torch.empty((T, N), **i32), torch.empty((T, N), **i32),
-                       torch.empty((T, N), dtype=torch.bool, device=dev),
-                       torch.empty((T, N), dtype=torch.bool, device=dev), out_step_size)
-    positions = torch.empty((T, N, D), **f32) if store_positions else None
+    info = NUTSRunInfo(torch.empty((Tc, N), **f32), torch.empty((Tc, N), **f32), torch.empty((Tc, N), **f32),
+                       torch.empty((Tc, N), **i32), torch.empty((Tc, N), **i32),
+                       torch.empty((Tc, N), dtype=torch.bool, device=dev),
+                       torch.empty((Tc, N), dtype=torch.bool, device=dev), out_step_size)
+    positions = torch.empty((Tc, N, D), **f32) if store_positions else None
     if T == 0 or N == 0:
         return HMCState(q, logp, g), positions, info
 
     t_first = 0
     if key_layout == "step_major":
         keys = bjx_random.split(rng_key, T)
-        step_keys = torch.as_tensor(keys.view(np.int32), device=dev).contiguous()
+        step_keys = torch.zeros((Tc, 2), **i32)
+        step_keys[Tc - T:].copy_(torch.as_tensor(np.ascontiguousarray(keys).view(np.int32).reshape(T, 2)))
         k0 = k1 = 0
     elif key_layout == "step":
         k0, k1, fold = bjx_random.key_spec(rng_key)
@@ -732,7 +741,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     is_ = torch.zeros((_lib.NUTS_NI, N), **i32)
     p = torch.empty_like(q)
     qf = torch.zeros_like(q)
-    t_done = torch.zeros(N, **i32)
+    t_done = torch.full((N,), Tc - T, **i32)
     phase = torch.zeros(N, **i32)
     # work buffers of the low-traffic tick kernels (include/bjx_nuts.h: rec / front_p; diagonal metric)
     dense_f = _dense_fields(metric.kind, metric.imm, N, D, max_depth, dev)
@@ -764,7 +773,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         is_=is_.data_ptr(), **{n: b.data_ptr() for n, b in bufs.items()}, **dense_f["fields"],
         int_kick=kick_c[0] if general else 0.0, int_drift=drift_c[0] if general else 0.0)
     run = _lib.NutsAsync(
-        step_keys=_lib.ptr(step_keys), t_first=t_first, n_steps=T, q=q.data_ptr(), g=g.data_ptr(),
+        step_keys=_lib.ptr(step_keys), t_first=t_first, n_steps=Tc, q=q.data_ptr(), g=g.data_ptr(),
         logp=logp.data_ptr(), p=p.data_ptr(), t=t_done.data_ptr(), phase=phase.data_ptr(),
         n_done=n_done.data_ptr(), rows=None, n_rows=N, out_position=_lib.ptr(positions),
         out_logdensity=info.logdensity.data_ptr(), out_acceptance_rate=info.acceptance_rate.data_ptr(),
@@ -816,13 +825,17 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     stream = _lib.current_stream()
     # K ticks per leaf; + one tick per transition: the busy-phase leaf kernel finishes a transition in the
     # tick AFTER the one that completed its tree (deferred transition ends, k_nuts_async_tick3<.., DEFER>)
-    max_ticks = T * (((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 1) + 4
-    if gemm_bufs is not None:
-        # a chain may wait for a slot of the momentum list.  Slots are handed out by atomicAdd in arbitrary order and a
-        # waiting chain competes again in the next tick, so ceil(N / cap) - 1 ticks per start is the EXPECTED wait, not a
-        # strict bound: twice that plus a constant, so that a starved chain cannot trip the "did not finish
-        # within its tick bound" error spuriously (the bound only exists to stop a runaway loop)
-        max_ticks += 2 * T * (-(-N // gemm_bufs[5])) + 64
+    def ticks_bound(T_):
+        b_ = T_ * (((1 << max_depth) - 1) * max(1, len(drift_c) if general else 1) + 1) + 4
+        if gemm_bufs is not None:
+            # a chain may wait for a slot of the momentum list.  Slots are handed out by atomicAdd in arbitrary order and
+            # a waiting chain competes again in the next tick, so ceil(N / cap) - 1 ticks per start is the EXPECTED wait,
+            # not a strict bound: twice that plus a constant, so that a starved chain cannot trip the "did not
+            # finish within its tick bound" error spuriously (the bound only exists to stop a runaway loop)
+            b_ += 2 * T_ * (-(-N // gemm_bufs[5])) + 64
+        return b_
+
+    max_ticks = ticks_bound(T)
     if sync_every is None:
         sync_every = 128 if fused else 16
     sync_every = int(_os_environ().get("BJX_NUTS_SYNC_EVERY", sync_every))
@@ -918,14 +931,15 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
         compaction cannot work in place.
 
         Round 3: the launch geometry and the callable's batch follow TIERS of the live-row count
-        (``cap``, then 512, 128, 32 rows: prefix views of the same buffers, one recording each) instead
+        (``cap``, then 4 096, 2 048, 512, 128, 32 rows: prefix views of the same buffers, one recording each) instead
         of staying at ``cap`` to the end: with three live chains the callable used to be evaluated on
-        all ``cap`` (up to 2 048) rows every tick.  Rows of a view beyond the live count always hold a
+        all ``cap`` rows every tick.  Round 6: ``cap`` is up to 8 192 rows (2 048 before) -- between 2 048 and 8 192 live
+        rows a tick is 16-20 us of GPU work and plain launches from Python took 33 us (NOTEBOOK section 19).  Rows of a view beyond the live count always hold a
         VALID position (the buffers start as copies of a current chain state and are only ever
         overwritten with pending positions), so a log-density that validates its support never sees
         zeros or garbage there."""
 
-        TIERS = (32, 128, 512)
+        TIERS = (32, 128, 512, 2048, 4096)
 
         def __init__(self, cap, n_ticks, reps):
             # a recorded sequence of n_ticks ticks, replayed `reps` times per host sync: recording
@@ -1160,6 +1174,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # blocking .item() (0.5-1 us per tick of a 12 us tick).  The count only grows: a stale (smaller)
     # value is safe for the tier choice, and the run ends at most one batch late (ticks over finished
     # chains do nothing).
+    lag_busy = _os.environ.get("BJX_NUTS_LAG_BUSY", "1") != "0"
     pinned = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
     poll_ev = [torch.cuda.Event() for _ in range(2)]
     poll = {"slot": 0, "primed": False, "last": 0}
@@ -1184,8 +1199,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
     # against 7.9 with the schedule of a long run (a look every 16 ticks, compaction at one half) and 7.4 with a look
     # every 8 ticks.  Runs of many transitions keep the old schedule: their chains desynchronise within a transition.
     cohort_plan, compact_frac = None, 0.5
-    if T == 1 and not fused and gemm_bufs is None:
-        cohort_plan, compact_frac = [(1 << d_) + 1 for d_ in range(4, max_depth + 1)], 0.7
+    cohort_ok = not fused and gemm_bufs is None
     static = {"tail": None, "spec": None}  # persistent workspace: the tails (and their recorded sequences) of earlier calls
 
     def to_spec(src_rref, src_qf, n_live):
@@ -1204,7 +1218,11 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 
     def execute():
         """The run itself, on the buffers set up above (a persistent workspace calls it once per transition)."""
-        nonlocal groups, tail_ctx, spec_ctx, ticks_left
+        nonlocal groups, tail_ctx, spec_ctx, ticks_left, max_ticks, cohort_plan, compact_frac
+        max_ticks = ticks_bound(cur["T"])
+        cohort_plan, compact_frac = None, 0.5
+        if cur["T"] == 1 and cohort_ok:
+            cohort_plan, compact_frac = [(1 << d_) + 1 for d_ in range(4, max_depth + 1)], 0.7
         # Row groups: the ensemble may be ticked group by group, each advanced by a chunk of ticks before
         # the next one gets its turn (chains are independent, so the results do not depend on the
         # grouping).  One group by default -- see auto_row_block for the measurement.
@@ -1254,7 +1272,16 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     use_graph is True or len(groups) > 1 or (tail and g_.eager_chunks >= 4))
                 g_.advance(n_ticks, rec_now)
             ticks_left -= n_ticks
-            n_active = N - int(n_done.item())  # one host sync per chunk
+            if lag_busy and n_rows > graph_max_rows and cohort_plan is None:
+                # busy phase of a long run: the count of the PREVIOUS chunk (read behind this chunk's launches, so the
+                # GPU never drains while the host waits); it only grows, so a stale value delays a compaction by one
+                # chunk at most, and the exact count is read before anything is sized by it
+                n_active = N - poll_done()
+                if n_active <= int(n_rows * compact_frac):
+                    n_active = N - int(n_done.item())
+            else:
+                n_active = N - int(n_done.item())  # one host sync per chunk
+                poll.update(primed=False, last=N - n_active)
             if n_active == 0:
                 break
             if spec_ok and n_active <= spec_rows and len(groups) == 1:
@@ -1272,7 +1299,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                     else:
                         tail_ctx = _Tail(n_active, sync_every, 4)
                     tail_ctx.enter(groups, n_active)
-                    poll["last"] = N - n_active
+                    poll.update(primed=False, last=N - n_active)
                     groups = []
                     continue
                 rows_all = torch.empty(n_rows, **i32)
@@ -1301,7 +1328,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             spec_ctx.finish()
         groups = []
         if persistent:  # the buffers are reused by the next call
-            c = lambda t: None if t is None else t.clone()  # noqa: E731
+            c = lambda t: None if t is None else t[cur["t0"]:].clone()  # noqa: E731
             return (HMCState(q.clone(), logp.clone(), g.clone()), c(positions),
                     NUTSRunInfo(*[c(getattr(info, f)) for f in NUTSRunInfo._fields]))
         return HMCState(q, logp, g), positions, info
@@ -1324,26 +1351,37 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
 
     kind0, imm_shape0 = metric.kind, tuple(imm_buf.shape)
 
-    def rerun(rng_key2, state2, step_size2, inverse_mass_matrix2):
-        """One more run on this workspace: new key, state, step size and metric; no allocation, no recording."""
+    def rerun(rng_key2, state2, step_size2, inverse_mass_matrix2, num_steps2=None):
+        """One more run on this workspace: new key, state, step size and metric (``step_major`` workspaces: and any
+        number of transitions up to the capacity); no allocation, no recording."""
         k0_, k1_, fold_ = bjx_random.key_spec(rng_key2)
         m2 = metrics.default_metric(inverse_mass_matrix2, N, D, dev)
         if fold_ >= 0 or m2.kind != kind0 or tuple(m2.imm.shape) != imm_shape0:
             raise ValueError("persistent free-running workspace: the key kind or the metric's shape changed")
+        T2 = cur["T"] if num_steps2 is None else int(num_steps2)
+        if not 1 <= T2 <= Tc or (key_layout == "step" and T2 != 1):
+            raise ValueError(f"persistent free-running workspace: {T2} transitions asked of a capacity of {Tc}")
+        cur.update(T=T2, t0=Tc - T2)
         q.copy_(check_batch(state2.position, "state.position"))
         logp.copy_(check_batch(state2.logdensity, "state.logdensity"))
         g.copy_(check_batch(state2.logdensity_grad, "state.logdensity_grad"))
         e2, epc2 = step_size_args(step_size2, N, dev)
         eps_buf.fill_(e2) if epc2 is None else eps_buf.copy_(epc2)
         imm_buf.copy_(m2.imm)
-        # the key's two words as integer fills (no host-to-device copy, hence no host synchronisation)
-        step_keys[0, 0].fill_(int(np.uint32(k0_).astype(np.int32)))
-        step_keys[0, 1].fill_(int(np.uint32(k1_).astype(np.int32)))
-        for b_ in (t_done, phase, n_done, rec):
+        if key_layout == "step":
+            # the key's two words as integer fills (no host-to-device copy, hence no host synchronisation)
+            step_keys[0, 0].fill_(int(np.uint32(k0_).astype(np.int32)))
+            step_keys[0, 1].fill_(int(np.uint32(k1_).astype(np.int32)))
+        else:
+            keys2 = np.ascontiguousarray(bjx_random.split(rng_key2, T2)).view(np.int32).reshape(T2, 2)
+            step_keys[Tc - T2:].copy_(torch.as_tensor(keys2))
+        for b_ in (phase, n_done, rec):
             b_.zero_()
+        t_done.fill_(Tc - T2)
         return guarded()
 
     _handle["rerun"] = rerun
+    _handle["capacity"] = Tc
     _handle["work"] = {"p": p, "bufs": bufs, "rec": rec}
     # EVERY device buffer the descriptors point to must outlive this call: the kernels of later reruns reach them through
     # raw pointers, and a tensor that only this frame referenced (checkpoints, slot tables, the front momentum ...) would
@@ -1422,8 +1460,9 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     free_bad: set = set()
     step_driver = _os_environ().get("BJX_NUTS_STEP_DRIVER", step_driver)
 
-    def _free_step_key(rng_key, state):
-        if step_driver == "lockstep" or fuse_default or use_graph is False or run_use_graph is False:
+    def _free_step_key(rng_key, state, for_run=False):
+        if ((step_driver == "lockstep" and not for_run) or fuse_default or use_graph is False
+                or run_use_graph is False):
             return None
         if not is_capturable(logdensity_fn):
             return None
@@ -1481,6 +1520,51 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             ri.num_trajectory_expansions[0], ri.num_integration_steps[0], ri.acceptance_rate[0])
         return new_state, info
 
+    # ``run`` on a persistent workspace too (round 6): a run's buffers (two checkpoint stacks, ~20 (N, D) arrays) and,
+    # above all, the recorded tick sequences of its tail -- one per tier of the live-row count, plus the speculative
+    # tail's -- are built once per (shape, stream) and serve every later ``run`` of at most ``capacity`` transitions.
+    # Recording is ~40 us per tick: ~10 ms of a 200 ms C3 run (T = 100) were recordings (NOTEBOOK section 19).
+    run_ws: dict = {}
+    run_bad: set = set()
+    RUN_WS_MAX_POSITION_BYTES = 2 << 30  # a workspace keeps its (capacity, N, D) position array: beyond this, per-call buffers
+
+    def _run_ws_enabled():
+        return _os_environ().get("BJX_NUTS_RUN_WS", "1") != "0"
+
+    def _persistent_run(wkey, rng_key, state, T, store_positions):
+        if wkey in run_bad:
+            return None
+        n_, d_ = state.position.shape
+        h = run_ws.get(wkey)
+        if h is not None and h["capacity"] < T:
+            run_ws.pop(wkey)
+            h = None
+        cap = T if store_positions else max(T, 512)  # (capacity, N) info arrays only: 22 B per chain and transition
+        if h is None and store_positions and cap * n_ * d_ * 4 > RUN_WS_MAX_POSITION_BYTES:
+            return None
+        try:
+            if h is None:
+                run_ws.clear()  # one run workspace per algorithm object
+                h = {"capacity": cap}
+                out = run_free(
+                    rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, T, max_num_doublings,
+                    divergence_threshold=divergence_threshold, chain_offset=chain_offset, key_layout="step_major",
+                    store_positions=store_positions, use_graph=True if use_graph is True else run_use_graph,
+                    integrator=integrator, _handle=h)
+                run_ws[wkey] = h
+                return out
+            return h["rerun"](rng_key, state, step_size, inverse_mass_matrix, T)
+        except RuntimeError as err:
+            # a recording failed or the speculative tail's replica check fired: the per-call driver restarts from `state`
+            import warnings
+
+            warnings.warn(f"blackjax_amd.nuts.run: the persistent workspace failed for this shape ({err}); "
+                          "falling back to per-call buffers", RuntimeWarning, stacklevel=3)
+            run_bad.add(wkey)
+            run_ws.pop(wkey, None)
+            torch.cuda.synchronize(state.position.device)
+            return None
+
     def init_fn(position, rng_key=None):
         del rng_key
         return init(position, logdensity_fn)
@@ -1526,6 +1610,13 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             if not free_running_supports(integrator, kind, d_):
                 _warn_lockstep_run(integrator, kind, d_)
                 return _run_lockstep(step_fn, rng_key, state, num_steps, key_layout, store_positions)
+        wkey = None
+        if key_layout == "step_major" and not fuse_target and int(num_steps) >= 1 and _run_ws_enabled():
+            wkey = _free_step_key(rng_key, state, for_run=True)
+        if wkey is not None:
+            out = _persistent_run(wkey + (bool(store_positions),), rng_key, state, int(num_steps), store_positions)
+            if out is not None:
+                return out
         return run_free(rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, num_steps,
                         max_num_doublings, divergence_threshold=divergence_threshold,
                         chain_offset=chain_offset, key_layout=key_layout,

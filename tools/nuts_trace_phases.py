@@ -13,6 +13,8 @@ bucket = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 
 
 def kind(name):
+    if "spec_integrate" in name:  # the speculative tail's stream-A integrator: one launch per leapfrog
+        return "leaf"
     if "async_tick3<" in name:  # round 4: the lean leaf (with deferred transition ends: the whole tick)
         return "leaf"
     if "async_tick2<" in name:  # k_nuts_async_tick2<NI, MODE, WAVES> (traces of rounds 2-4 only: removed in round 5): MODE 0 leaf, 1 end, 2 fused
