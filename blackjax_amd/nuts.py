@@ -1544,7 +1544,8 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             return None
         try:
             if h is None:
-                run_ws.clear()  # one run workspace per algorithm object
+                while len(run_ws) >= 2:  # a workspace is ~20 (N, D) buffers + two checkpoint stacks: the two most recent
+                    run_ws.pop(next(iter(run_ws)))
                 h = {"capacity": cap}
                 out = run_free(
                     rng_key, state, logdensity_fn, step_size, inverse_mass_matrix, T, max_num_doublings,

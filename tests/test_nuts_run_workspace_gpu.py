@@ -93,3 +93,82 @@ def test_run_workspace_grows_past_its_capacity(dev):
     for T in (4, 600, 30):  # capacity 512 -> rebuilt at 600 -> reused
         key = bjx.random.key(T)
         _same_run(alg.run(key, state, T, store_positions=False), ref.run(key, state, T, store_positions=False))
+
+
+@pytest.mark.timeout(600)
+def test_run_workspaces_interleaved_on_streams_and_threads(dev):
+    """The purity contract (blackjax/base.py:24-85) against the run workspace: two `nuts` objects whose `run` and
+    `step` calls alternate on two streams, then run concurrently from two threads, give the results of each alone."""
+    import threading
+
+    D = 32
+    imm = torch.ones(D, device=dev)
+    fn = bjx.targets.NealFunnel()
+    gen = torch.Generator(device=dev).manual_seed(4)
+    q0 = {"a": 0.3 * torch.randn(96, D, device=dev, generator=gen), "b": 0.3 * torch.randn(160, D, device=dev, generator=gen)}
+    make = {"a": lambda: bjx.nuts(fn, 0.2, imm, max_num_doublings=6), "b": lambda: bjx.nuts(fn, 0.15, imm, max_num_doublings=5)}
+    plan = [("run", 1, 4), ("step", 2, 0), ("run", 3, 2), ("run", 4, 6), ("step", 5, 0)]
+
+    def drive(alg, st, items, stream=None):
+        import contextlib
+
+        out = []
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            for kind, seed, T in items:
+                if kind == "run":
+                    st, pos, info = alg.run(bjx.random.key(seed), st, T)
+                    out.append((pos.clone(), info.num_integration_steps.clone(), info.energy.clone()))
+                else:
+                    st, info = alg.step(bjx.random.key(seed), st)
+                    out.append((st.position.clone(), info.num_integration_steps.clone(), info.energy.clone()))
+        return st, out
+
+    def same(x, y):
+        assert len(x) == len(y)
+        for u, v in zip(x, y):
+            for s, t in zip(u, v):
+                assert torch.equal(torch.nan_to_num(s.float(), nan=-7.0), torch.nan_to_num(t.float(), nan=-7.0))
+
+    alone = {}
+    for n in "ab":
+        alg = make[n]()
+        alone[n] = drive(alg, alg.init(q0[n]), plan)[1]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for s in (s1, s2):
+        s.wait_stream(torch.cuda.current_stream(dev))
+    stream_of = {"a": s1, "b": s2}
+    algs = {n: make[n]() for n in "ab"}
+    st, got = {}, {"a": [], "b": []}
+    for n in "ab":
+        with torch.cuda.stream(stream_of[n]):
+            st[n] = algs[n].init(q0[n])
+    for item in plan:
+        for n in "ab":
+            st[n], o = drive(algs[n], st[n], [item], stream_of[n])
+            got[n] += o
+    torch.cuda.synchronize()
+    for n in "ab":
+        same(got[n], alone[n])
+    res, errs = {}, []
+
+    def worker(n, stream):
+        try:
+            alg = make[n]()
+            with torch.cuda.stream(stream):
+                s0 = alg.init(q0[n])
+            res[n] = drive(alg, s0, plan, stream)[1]
+            stream.synchronize()
+        except BaseException as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=("a", s1)), threading.Thread(target=worker, args=("b", s2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a worker thread did not finish"
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for n in "ab":
+        same(res[n], alone[n])
