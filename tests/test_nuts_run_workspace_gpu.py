@@ -172,3 +172,27 @@ def test_run_workspaces_interleaved_on_streams_and_threads(dev):
     torch.cuda.synchronize()
     for n in "ab":
         same(res[n], alone[n])
+
+
+def test_run_workspace_per_chain_step_size_and_metric(dev, monkeypatch):
+    """Per-chain step sizes and a per-chain diagonal metric (what window_adaptation hands to the sampler) go through the
+    workspace's static copies; a multi-stage integrator runs on it too."""
+    N, D = 150, 24
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    fn = bjx.targets.NealFunnel()
+    eps = 0.05 + 0.1 * torch.rand(N, device=dev, generator=g)
+    imm = 0.5 + torch.rand(N, D, device=dev, generator=g)
+    q0 = 0.3 * torch.randn(N, D, device=dev, generator=g)
+    for integrator in (bjx.integrators.velocity_verlet, bjx.integrators.mclachlan):
+        ws = bjx.nuts(fn, eps, imm, max_num_doublings=6, integrator=integrator)
+        ref = bjx.nuts(fn, eps, imm, max_num_doublings=6, integrator=integrator)
+        state = ws.init(q0)
+        for seed, T in ((1, 3), (2, 5), (3, 2)):
+            key = bjx.random.key(seed)
+            out_ws = ws.run(key, state, T)
+            monkeypatch.setenv("BJX_NUTS_RUN_WS", "0")
+            out_ref = ref.run(key, state, T)
+            monkeypatch.delenv("BJX_NUTS_RUN_WS")
+            _same_run(out_ws, out_ref)
+            state = out_ws[0]
