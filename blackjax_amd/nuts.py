@@ -1544,7 +1544,9 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
             return None
         try:
             if h is None:
-                while len(run_ws) >= 2:  # a workspace is ~20 (N, D) buffers + two checkpoint stacks: the two most recent
+                # a workspace is ~20 (N, D) buffers + two checkpoint stacks: the two most recent are kept, one when they are large
+                ws_bytes = 4 * n_ * d_ * (20 + 2 * int(max_num_doublings))
+                while len(run_ws) >= (2 if ws_bytes < (4 << 30) else 1):
                     run_ws.pop(next(iter(run_ws)))
                 h = {"capacity": cap}
                 out = run_free(
