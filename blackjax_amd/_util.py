@@ -9,22 +9,74 @@ import torch
 
 _VG_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _CAPTURE_LOCK = threading.RLock()
+_CAPTURE_TLS = threading.local()  # .depth > 0: this thread is inside a stream capture
+_GRAVEYARD: list = []  # graphs whose last reference died inside a capture of the SAME thread: destroyed right after it
+
+
+class LockedGraph(torch.cuda.CUDAGraph):
+    """``torch.cuda.CUDAGraph`` whose DESTRUCTION is serialised with stream captures.  On ROCm 7 destroying a graph
+    (``hipGraphExecDestroy`` / ``hipGraphDestroy`` / the release of its private pool) in one thread while another thread
+    is between ``capture_begin`` and ``capture_end`` aborts the process -- seen as ``Fatal Python error: Aborted`` in 3 of
+    9 runs of the GPU suite (round 6: one thread dropping a NUTS workspace, or finishing and releasing its algorithm
+    objects, while the other recorded a tail sequence; ``gpurun_out/soak`` logs, NOTEBOOK section 19.2).  Every graph the
+    drivers record is one of these: its last reference going away -- by reference count or by the cyclic collector, in
+    whatever thread -- waits for the capture lock before the graph is reset; inside a capture of the same thread the
+    reset is deferred to the end of that capture."""
+
+    def __del__(self):
+        try:
+            if getattr(_CAPTURE_TLS, "depth", 0) > 0:
+                _GRAVEYARD.append(self)  # (resurrected: reset explicitly by _drain_graveyard)
+                return
+            with _CAPTURE_LOCK:
+                self.reset()
+        except Exception:  # interpreter shutdown, a graph that never captured anything
+            pass
+
+
+def new_graph() -> "LockedGraph":
+    return LockedGraph()
+
+
+def _drain_graveyard():
+    while _GRAVEYARD:
+        g = _GRAVEYARD.pop()
+        try:
+            g.reset()
+        except Exception:
+            pass
 
 
 def record_graph(graph, **kw):
     """``torch.cuda.graph(graph, capture_error_mode="thread_local")`` under a process-wide lock.  Two stream captures
     under way at once -- two Python threads stepping two algorithm objects, each recording its inner loop -- crash the
-    process on ROCm 7 (SIGSEGV / abort inside the capture, measured round 6: tools/scratch/thread_probe.py), so
-    recordings are serialised; replays, plain launches and allocations of other threads are not."""
+    process on ROCm 7 (SIGSEGV / abort inside the capture, measured round 6: tools/scratch/thread_probe.py), and so does
+    a graph destroyed by one thread while another captures (``LockedGraph``), so recordings AND graph destruction are
+    serialised; replays, plain launches and allocations of other threads are not."""
     import contextlib
+    import sys
 
     lock = _CAPTURE_LOCK
 
     @contextlib.contextmanager
     def ctx():
         with lock:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):  # other threads (the RCCL watchdog) may poll events
+            cm = torch.cuda.graph(graph, capture_error_mode="thread_local", **kw)  # other threads (the RCCL watchdog) may poll events
+            # its __enter__ runs gc.collect() BEFORE capture_begin: dead workspaces' graphs are reset there (depth still 0,
+            # the lock is ours), not inside the capture
+            cm.__enter__()
+            _CAPTURE_TLS.depth = getattr(_CAPTURE_TLS, "depth", 0) + 1
+            ok = False
+            try:
                 yield
+                ok = True
+            finally:
+                try:
+                    cm.__exit__(None, None, None) if ok else cm.__exit__(*sys.exc_info())
+                finally:
+                    _CAPTURE_TLS.depth -= 1
+                    if _CAPTURE_TLS.depth == 0:
+                        _drain_graveyard()
 
     return ctx()
 

@@ -17,7 +17,7 @@ from typing import Callable, NamedTuple
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import (record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+from ._util import (new_graph, record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
                     warn_eager_driver)
 from .base import SamplingAlgorithm
 from .random import key_spec
@@ -273,7 +273,7 @@ class _GraphedTrajectory:
             self._body()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = new_graph()
         with record_graph(self.graph):
             self.logp, self.g = self._body()
 

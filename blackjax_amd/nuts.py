@@ -30,7 +30,7 @@ from typing import Callable, NamedTuple, Optional
 import torch
 
 from . import _lib, integrators, metrics
-from ._util import (record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
+from ._util import (new_graph, record_graph, check_batch, eval_logdensity, is_capturable, step_size_args, value_and_grad,
                     warn_eager_driver)
 from .base import SamplingAlgorithm
 from .hmc import HMCState, IntegratorState, init
@@ -182,7 +182,7 @@ class _GraphWorkspace:
                 self._chunk_body(1, n_cap)  # warm-up outside capture
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
+            graph = new_graph()
             with record_graph(graph):
                 keep = self._chunk_body(k, n_cap)
             self.ctl.copy_(saved)
@@ -906,7 +906,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
                 # recording does not execute anything, so the chains' state is untouched by it
                 lp_s, g_s = self.logp_f.clone(), self.gf.clone()
                 try:
-                    cg = torch.cuda.CUDAGraph()
+                    cg = new_graph()
                     with record_graph(cg):
                         lp_e, g_e = self.chunk(n_ticks, lp_s, g_s)
                         if lp_e is not lp_s:
@@ -1041,7 +1041,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             issued = self.n_ticks
             if can_record:
                 try:
-                    cg = torch.cuda.CUDAGraph()
+                    cg = new_graph()
                     with record_graph(cg):
                         self._body(k, n)
                     self.graph[(k, self.view)] = (cg, n)
@@ -1141,7 +1141,7 @@ def run_free(rng_key, state: HMCState, logdensity_fn: Callable, step_size, inver
             self._seq_a(n0)
             if can_record:
                 try:
-                    cg = torch.cuda.CUDAGraph()
+                    cg = new_graph()
                     with record_graph(cg):
                         self._seq_a(self.SEQ)
                     self.graph = cg
