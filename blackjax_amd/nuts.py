@@ -1523,7 +1523,7 @@ def as_top_level_api(logdensity_fn: Callable, step_size, inverse_mass_matrix, *,
     # ``run`` on a persistent workspace too (round 6): a run's buffers (two checkpoint stacks, ~20 (N, D) arrays) and,
     # above all, the recorded tick sequences of its tail -- one per tier of the live-row count, plus the speculative
     # tail's -- are built once per (shape, stream) and serve every later ``run`` of at most ``capacity`` transitions.
-    # Recording is ~40 us per tick: ~10 ms of a 200 ms C3 run (T = 100) were recordings (NOTEBOOK section 19).
+    # Measured at C3 (NOTEBOOK section 19): recordings + allocation were ~4 ms of a 205 ms run (T = 100).
     run_ws: dict = {}
     run_bad: set = set()
     RUN_WS_MAX_POSITION_BYTES = 2 << 30  # a workspace keeps its (capacity, N, D) position array: beyond this, per-call buffers
